@@ -1,0 +1,207 @@
+/* rjprt.h -- C-ABI of librjprt.so, the MI355X (gfx950) line-of-sight radiative-transfer core
+ * behind RaJePy's JetModel.
+ *
+ * The reference (SimonP2207/RaJePy) has no FFI: its hot path is reached only through Python
+ * methods of `JetModel` (classes.py:1101-1541).  Each entry point below names the reference
+ * method(s) whose NumPy body it replaces; `rajepy_amd/_lib.py` is the ctypes binding and
+ * INTEGRATION.md shows the stub a RaJePy maintainer would add.
+ *
+ * Conventions
+ *  - every function returns an int status: 0 = RJP_OK, negative = error; the message for the
+ *    last error of a context is `rjp_last_error(ctx)`.  No exceptions, no exit().
+ *  - all array arguments named `d_*` are CALLER-OWNED DEVICE pointers (e.g.
+ *    torch.Tensor.data_ptr()); the library never frees or retains them.  Arguments named
+ *    `h_*` are host pointers to small per-channel / per-epoch tables (copied on the stream).
+ *  - work is enqueued on the caller's `stream` (a hipStream_t passed as void*; NULL = the
+ *    default stream) and is asynchronous; the caller synchronises.
+ *  - a context is bound to one device and is not thread-safe: one context per rank.
+ *  - grids are C-contiguous (n_x, n_y, n_z), line of sight = axis 1 (classes.py:46,
+ *    363-367); maps are (n_x, n_z) row-major, P = n_x*n_z pixels.
+ */
+#ifndef RJPRT_H
+#define RJPRT_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RJP_VERSION 100          /* 0.1.0 */
+#define RJP_MAX_BURSTS 8         /* per jet (red / blue) */
+#define RJP_MAX_EPOCH_TILE 8     /* epochs evaluated per grid pass */
+
+enum rjp_status {
+  RJP_OK = 0,
+  RJP_ERR_ARG = -1,        /* bad argument (null pointer, shape, dtype tag ...) */
+  RJP_ERR_HIP = -2,        /* a HIP runtime call failed */
+  RJP_ERR_NODEVICE = -3,   /* no usable gfx950 device */
+  RJP_ERR_WORKSPACE = -4   /* workspace too small */
+};
+
+enum rjp_dtype { RJP_F32 = 4, RJP_F64 = 8 };   /* storage width of the 3-D fields */
+
+enum rjp_gff_mode {
+  RJP_GFF_SCALAR = 0,      /* q_T == 0: one Gaunt factor per channel (classes.py:1388-1389) */
+  RJP_GFF_POWERLAW = 1     /* 11.95 T^0.15 nu^-0.1 per cell        (classes.py:1393, 1426) */
+};
+
+typedef struct rjp_ctx rjp_ctx;
+
+/* Device-resident model state: the five (continuum) / six (RRL) per-cell fields of
+ * SURVEY.md 8(d).  Layout produced by rjp_pack_field / rjp_build_fields:
+ *   nd   |value| = steady-state number density `_nd` [cm^-3] (classes.py:889-897);
+ *        SIGN BIT = 1 where the cell belongs to the red jet (rr < 0, classes.py:866, 895)
+ *   xi   ionisation fraction (classes.py:910-936)
+ *   temp temperature [K] (classes.py:942-969)
+ *   pf   path-length factor fill_factor / areas (classes.py:1118, 1185, 1396-1397)
+ *   ts   launch time `_ts` [s] (classes.py:847-853); may be NULL when there are no bursts
+ *   vy   line-of-sight velocity vel[1] [km/s] (classes.py:1093); RRL only, else NULL
+ * NaN marks "outside the jet" exactly as in the reference. */
+typedef struct rjp_fields {
+  const void* d_nd;
+  const void* d_xi;
+  const void* d_temp;
+  const void* d_pf;
+  const void* d_ts;
+  const void* d_vy;
+  int32_t nx, ny, nz;
+  int32_t dtype;            /* enum rjp_dtype */
+  double csize_au;          /* cell size [au] */
+} rjp_fields;
+
+/* Ejection bursts (classes.py:399-463): mdot(t)/mdot_ss = 1 + sum_b amp_rel_b *
+ * exp(-(t - t0_b)^2 * inv2s2_b); index 0 = red jet, 1 = blue jet. */
+typedef struct rjp_bursts {
+  int32_t n[2];
+  double t0[2][RJP_MAX_BURSTS];        /* [s] */
+  double amp_rel[2][RJP_MAX_BURSTS];   /* (peak_jml - ss_jml) / ss_jml */
+  double inv2s2[2][RJP_MAX_BURSTS];    /* 1 / (2 sigma^2) [s^-2] */
+} rjp_bursts;
+
+/* One radio recombination line, host-side scalars of maths/rrls.py (LTE path). */
+typedef struct rjp_line {
+  double nu_rest;      /* rrl_nu_0 [Hz] (rrls.py:14-29) */
+  double kG;           /* deltanu_g / (nu0 sqrt(T)) = sqrt(4 ln2 2k/(m c^2)) (rrls.py:116-118) */
+  double kL;           /* deltanu_l / n_e = 8.2 (n/100)^4.5 (1 + 2.25 dn/n) (rrls.py:101) */
+  double kappa0;       /* 1.0991132675738456e-17 n^2 f_n1n2 * n_i/n_e (rrls.py:383-389, 73-83) */
+  double en_over_k;    /* Z^2 E_n / k_cgs [K] (rrls.py:386) */
+  double h_over_k;     /* h_cgs / k_cgs [K/Hz] (rrls.py:387) */
+} rjp_line;
+
+int rjp_version(void);
+int rjp_device_count(void);
+int rjp_ctx_create(int device, rjp_ctx** out);
+int rjp_ctx_destroy(rjp_ctx* ctx);
+const char* rjp_last_error(const rjp_ctx* ctx);   /* ctx may be NULL: last create error */
+
+/* ---- field upload layout -------------------------------------------------------------- */
+
+/* d_dst[i] = (dtype)d_src[i]; with d_red != NULL additionally sets the sign bit where
+ * d_red[i] != 0 (and clears it elsewhere) -> the packed `nd` field; with d_den != NULL
+ * stores d_src[i]/d_den[i] -> the `pf` field from fill_factor and areas. */
+int rjp_pack_field(rjp_ctx* ctx, const double* d_src, const double* d_den,
+                   const uint8_t* d_red, void* d_dst, int64_t n, int dtype, void* stream);
+
+/* ---- K1: free-free / emission-measure scan -------------------------------------------
+ * Replaces the y-reductions of JetModel.emission_measure (classes.py:1116-1120),
+ * .optical_depth_ff (1375-1432) and the nanmean of .intensity_ff (1471-1472, 1484-1485),
+ * with number_density = _nd * chi_xyz (classes.py:861-875) evaluated in registers for
+ * each of E epochs.  One pass over the grid per tile of RJP_MAX_EPOCH_TILE epochs.
+ *   d_sumA [E*P]  sum_y T^-1.5 (n x)^2 pf          (RJP_GFF_SCALAR)
+ *                 sum_y T^-1.35 (n x)^2 pf         (RJP_GFF_POWERLAW)   [cm^-6 K^-1.5|-1.35]
+ *   d_em   [E*P]  emission measure [pc cm^-6]      (may be NULL)
+ *   d_tavg [P]    nanmean_y(T where T > 0) [K], NaN on empty sightlines (may be NULL)
+ * h_epochs_s: model times [s] (JetModel.time), E >= 1.
+ * d_work: scratch of at least rjp_ff_scan_workspace() bytes. */
+size_t rjp_ff_scan_workspace(int32_t nx, int32_t ny, int32_t nz, int32_t n_epochs);
+int rjp_ff_scan(rjp_ctx* ctx, const rjp_fields* fields, const rjp_bursts* bursts,
+                const double* h_epochs_s, int32_t n_epochs, int32_t gff_mode,
+                double* d_sumA, double* d_em, double* d_tavg,
+                void* d_work, size_t work_bytes, void* stream);
+
+/* ---- K2: per-channel map stage --------------------------------------------------------
+ * Replaces the map-level arithmetic of optical_depth_ff / intensity_ff / flux_ff
+ * (classes.py:1395-1397, 1473-1475, 1519-1521):
+ *   tau[e,f,p]  = h_ctau[f] * sumA[e,p]
+ *   flux[e,f,p] = h_cflux[f] * tavg[p] * (1 - exp(-tau))      [Jy/pixel]
+ *   ftot[e,f]   = nansum_p flux[e,f,p]
+ * h_ctau[f]  = 0.018 nu^-2 gff(nu,T_0) csize au 100      (scalar mode)
+ *            = 0.018 nu^-2 11.95 nu^-0.1 csize au 100    (power-law mode)
+ * h_cflux[f] = 2 nu^2 k / c^2 * arctan(csize au / (dist pc))^2 / 1e-26
+ * Any of d_tau / d_flux / d_ftot may be NULL.  d_work >= rjp_ff_maps_workspace(). */
+size_t rjp_ff_maps_workspace(int64_t n_pix, int32_t n_epochs, int32_t n_chan);
+int rjp_ff_maps(rjp_ctx* ctx, const double* d_sumA, const double* d_tavg, int64_t n_pix,
+                int32_t n_epochs, const double* h_ctau, const double* h_cflux, int32_t n_chan,
+                double* d_tau, double* d_flux, double* d_ftot,
+                void* d_work, size_t work_bytes, void* stream);
+
+/* ---- K3: recombination-line scan ------------------------------------------------------
+ * Replaces JetModel.optical_depth_rrl (classes.py:1159-1214): per cell Doppler-shifted rest
+ * frequency, thermal + Stark widths, Voigt profile Re w(z) (rrls.py:350-354), LTE kappa_L
+ * (rrls.py:383-389), summed along y for every channel.
+ *   d_tau_rrl [F*P]
+ * One epoch per call (time_s). */
+int rjp_rrl_scan(rjp_ctx* ctx, const rjp_fields* fields, const rjp_bursts* bursts,
+                 double time_s, const rjp_line* line, const double* h_nu, int32_t n_chan,
+                 double* d_tau_rrl, void* stream);
+
+/* Map stage of intensity_rrl / flux_rrl (classes.py:1280-1282, 1339-1343;
+ * rrls.py:444-449; physics.py:571-574):
+ *   I_L = B_nu(tavg) exp(-tau_ff) (1 - exp(-tau_rrl)) 1e-3 ; S = I_L * omega / 1e-26
+ *   flux[f,p] = S (+ flux_ff[f,p] when d_flux_ff != NULL, i.e. contsub=False)
+ * h_cflux_rrl[f] = omega/1e-26 * 1e-3 * 2 h_cgs nu^3 / c_cgs^2 ; h_hnu_k[f] = h nu / k. */
+int rjp_rrl_maps(rjp_ctx* ctx, const double* d_tau_rrl, const double* d_tau_ff,
+                 const double* d_tavg, const double* d_flux_ff, int64_t n_pix,
+                 const double* h_cflux_rrl, const double* h_hnu_k, int32_t n_chan,
+                 double* d_flux, double* d_ftot, void* d_work, size_t work_bytes,
+                 void* stream);
+
+/* ---- K4: geometry -> fields on the device --------------------------------------------
+ * Replaces the lazily cached grids of JetModel (fill_factor/areas classes.py:657-669,
+ * 763-764; grid_rwp 521-525; rreff 549-555; _nd 877-897; ion_fraction 915-934;
+ * temperature 950-967; ts 847-853 with maths/geometry.py:150-178; vel[1] 1042-1093).
+ * Writes the packed device layout directly. */
+typedef struct rjp_geometry {
+  int32_t nx, ny, nz;
+  int32_t rotation_ccw;       /* 1 = "CCW", 0 = "CW" */
+  double csize;               /* [au] */
+  double inc, pa;             /* [deg] */
+  double w_0, r_0, mod_r_0, epsilon;
+  double R_1, R_2;            /* [au] */
+  double M_star;              /* [Msol] */
+  double v_lsr;               /* [km/s] */
+  double n_0, x_0, T_0, v_0;  /* axis values at the base */
+  double q_n, q_x, q_T, q_v;          /* power laws along r */
+  double qd_n, qd_x, qd_T, qd_v;      /* power laws across the jet */
+  double rb_frac;             /* mlr_rj / mlr_bj (classes.py:228-229, 895) */
+} rjp_geometry;
+
+/* d_vy / d_ts may be NULL to skip them; d_ff_raw / d_areas_raw (float64, optional) receive
+ * the un-packed fill factors / areas that JetModel.save pickles (classes.py:1704-1709). */
+int rjp_build_fields(rjp_ctx* ctx, const rjp_geometry* geom, int dtype,
+                     void* d_nd, void* d_xi, void* d_temp, void* d_pf, void* d_ts,
+                     void* d_vy, double* d_ff_raw, double* d_areas_raw, void* stream);
+
+/* ---- measurement harness: synthetic dense fields ---------------------
+ * Counter-based: u = splitmix64(seed ^ field_id<<60 ^ linear_cell_index) -> [0,1).
+ *   n = 10^(5+2.5u), x = 0.05+0.45u, T = 1e4 (temp_mode 0) or 5e3+1.5e4u (temp_mode 1),
+ *   pf = 0.5 w.p. 0.25 else 1, ts = 5u yr, red = i_z < n_z/2, vy = 6.2+60(u-0.5) km/s.
+ * Generates cells [cell0, cell0+n) of the flattened grid so a host restatement can
+ * regenerate any sub-block. */
+int rjp_synth_fields(rjp_ctx* ctx, uint64_t seed, int32_t temp_mode, int32_t nz,
+                     int64_t cell0, int64_t n, int dtype, void* d_nd, void* d_xi,
+                     void* d_temp, void* d_pf, void* d_ts, void* d_vy, void* stream);
+
+/* Device-time probe used by bench.py: average duration [ms] of `reps` back-to-back
+ * rjp_ff_scan launches measured with HIP events on `stream`. */
+int rjp_time_ff_scan(rjp_ctx* ctx, const rjp_fields* fields, const rjp_bursts* bursts,
+                     const double* h_epochs_s, int32_t n_epochs, int32_t gff_mode,
+                     double* d_sumA, double* d_em, double* d_tavg, void* d_work,
+                     size_t work_bytes, void* stream, int32_t reps, double* ms_avg);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RJPRT_H */

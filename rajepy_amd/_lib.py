@@ -1,0 +1,122 @@
+"""ctypes binding of librjprt.so (include/rjprt.h).
+
+There is NO CPU fallback: if the shared library is missing or a call fails this module
+raises.  Build the library with ``python -c "import __graft_entry__ as g; g.build()"`` or
+``rajepy_amd/csrc/build.sh`` (hipcc, --offload-arch=gfx950).
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "librjprt.so")
+
+RJP_F32, RJP_F64 = 4, 8
+RJP_GFF_SCALAR, RJP_GFF_POWERLAW = 0, 1
+RJP_MAX_BURSTS = 8
+RJP_MAX_EPOCH_TILE = 8
+RJP_OK = 0
+
+
+class RjprtError(RuntimeError):
+    """A librjprt call returned a negative status."""
+
+
+class Fields(C.Structure):
+    _fields_ = [("d_nd", C.c_void_p), ("d_xi", C.c_void_p), ("d_temp", C.c_void_p),
+                ("d_pf", C.c_void_p), ("d_ts", C.c_void_p), ("d_vy", C.c_void_p),
+                ("nx", C.c_int32), ("ny", C.c_int32), ("nz", C.c_int32),
+                ("dtype", C.c_int32), ("csize_au", C.c_double)]
+
+
+class Bursts(C.Structure):
+    _fields_ = [("n", C.c_int32 * 2),
+                ("t0", (C.c_double * RJP_MAX_BURSTS) * 2),
+                ("amp_rel", (C.c_double * RJP_MAX_BURSTS) * 2),
+                ("inv2s2", (C.c_double * RJP_MAX_BURSTS) * 2)]
+
+
+class Line(C.Structure):
+    _fields_ = [("nu_rest", C.c_double), ("kG", C.c_double), ("kL", C.c_double),
+                ("kappa0", C.c_double), ("en_over_k", C.c_double), ("h_over_k", C.c_double)]
+
+
+class Geometry(C.Structure):
+    _fields_ = [("nx", C.c_int32), ("ny", C.c_int32), ("nz", C.c_int32),
+                ("rotation_ccw", C.c_int32), ("csize", C.c_double),
+                ("inc", C.c_double), ("pa", C.c_double),
+                ("w_0", C.c_double), ("r_0", C.c_double), ("mod_r_0", C.c_double),
+                ("epsilon", C.c_double), ("R_1", C.c_double), ("R_2", C.c_double),
+                ("M_star", C.c_double), ("v_lsr", C.c_double),
+                ("n_0", C.c_double), ("x_0", C.c_double), ("T_0", C.c_double),
+                ("v_0", C.c_double),
+                ("q_n", C.c_double), ("q_x", C.c_double), ("q_T", C.c_double),
+                ("q_v", C.c_double),
+                ("qd_n", C.c_double), ("qd_x", C.c_double), ("qd_T", C.c_double),
+                ("qd_v", C.c_double), ("rb_frac", C.c_double)]
+
+
+_P = C.c_void_p
+_DP = C.POINTER(C.c_double)
+
+# name -> (restype, argtypes); every symbol include/rjprt.h declares
+SIGNATURES = {
+    "rjp_version": (C.c_int, []),
+    "rjp_device_count": (C.c_int, []),
+    "rjp_ctx_create": (C.c_int, [C.c_int, C.POINTER(_P)]),
+    "rjp_ctx_destroy": (C.c_int, [_P]),
+    "rjp_last_error": (C.c_char_p, [_P]),
+    "rjp_pack_field": (C.c_int, [_P, _P, _P, _P, _P, C.c_int64, C.c_int, _P]),
+    "rjp_ff_scan_workspace": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
+    "rjp_ff_scan": (C.c_int, [_P, C.POINTER(Fields), C.POINTER(Bursts), _DP, C.c_int32,
+                              C.c_int32, _P, _P, _P, _P, C.c_size_t, _P]),
+    "rjp_ff_maps_workspace": (C.c_size_t, [C.c_int64, C.c_int32, C.c_int32]),
+    "rjp_ff_maps": (C.c_int, [_P, _P, _P, C.c_int64, C.c_int32, _DP, _DP, C.c_int32,
+                              _P, _P, _P, _P, C.c_size_t, _P]),
+    "rjp_rrl_scan": (C.c_int, [_P, C.POINTER(Fields), C.POINTER(Bursts), C.c_double,
+                               C.POINTER(Line), _DP, C.c_int32, _P, _P]),
+    "rjp_rrl_maps": (C.c_int, [_P, _P, _P, _P, _P, C.c_int64, _DP, _DP, C.c_int32,
+                               _P, _P, _P, C.c_size_t, _P]),
+    "rjp_build_fields": (C.c_int, [_P, C.POINTER(Geometry), C.c_int, _P, _P, _P, _P, _P,
+                                   _P, _P, _P, _P]),
+    "rjp_synth_fields": (C.c_int, [_P, C.c_uint64, C.c_int32, C.c_int32, C.c_int64,
+                                   C.c_int64, C.c_int, _P, _P, _P, _P, _P, _P, _P]),
+    "rjp_time_ff_scan": (C.c_int, [_P, C.POINTER(Fields), C.POINTER(Bursts), _DP,
+                                   C.c_int32, C.c_int32, _P, _P, _P, _P, C.c_size_t, _P,
+                                   C.c_int32, _DP]),
+}
+
+_lib = None
+
+
+def load():
+    """Load librjprt.so (once) and declare every prototype.  Raises if it is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RjprtError(
+            "%s not found: the HIP library has not been built (rajepy_amd/csrc/build.sh). "
+            "rajepy_amd has no CPU fallback." % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if a declared symbol is missing
+        fn.restype = res
+        fn.argtypes = args
+    if lib.rjp_version() < 100:
+        raise RjprtError("librjprt.so is older than this binding")
+    _lib = lib
+    return lib
+
+
+def check(status, ctx=None, what=""):
+    if status != RJP_OK:
+        msg = load().rjp_last_error(ctx)
+        raise RjprtError("%s failed (status %d): %s"
+                         % (what or "librjprt call", status,
+                            msg.decode() if msg else "?"))
+
+
+def dbl_array(values):
+    """Host table of float64 as a ctypes array (kept alive by the caller)."""
+    vals = [float(v) for v in values]
+    return (C.c_double * len(vals))(*vals)

@@ -1,0 +1,922 @@
+"""Host-side mirror of RaJePy's `JetModel` / `ContinuumRun` / `RRLRun` / `Pipeline`
+(reference: classes.py) for the radiative-transfer path: same constructor arguments,
+method names, argument meaning, return shapes/dtypes, file names and error behaviour.
+
+What is different underneath: the 3-D grids live in HBM as five/six packed fields
+(`engine.DeviceFields`), are BUILT on the GPU (`rjp_build_fields`) and every line-of-sight
+reduction runs in librjprt's HIP kernels through the C-ABI of include/rjprt.h.  One grid pass
+serves every continuum channel of an epoch (the reference re-streams the grid per channel),
+and up to eight epochs share a pass.  There is no CPU fallback for any of it.
+"""
+import os
+import pickle
+import runpy
+import time as _time
+
+import numpy as np
+
+from . import _constants as con
+from . import _lib
+from . import fits as _fits
+from . import logger
+from .maths import geometry as mgeom
+from .maths import physics as mphys
+from .maths import rrls as mrrl
+from .miscellaneous import functions as miscf
+
+_STORAGE = {'f64': _lib.RJP_F64, 'f32': _lib.RJP_F32, 8: _lib.RJP_F64, 4: _lib.RJP_F32}
+
+
+def geometry_struct(params, nx, ny, nz):
+    """`rjp_geometry` (include/rjprt.h) from a model params dict with derived keys."""
+    g, t, pl, pr = (params['geometry'], params['target'], params['power_laws'],
+                    params['properties'])
+    s = _lib.Geometry()
+    s.nx, s.ny, s.nz = int(nx), int(ny), int(nz)
+    s.rotation_ccw = 1 if g["rotation"].lower() == 'ccw' else 0
+    s.csize = params['grid']['c_size']
+    s.inc, s.pa = g['inc'], g['pa']
+    s.w_0, s.r_0, s.mod_r_0, s.epsilon = g['w_0'], g['r_0'], g['mod_r_0'], g['epsilon']
+    s.R_1, s.R_2, s.M_star, s.v_lsr = t['R_1'], t['R_2'], t['M_star'], t['v_lsr']
+    s.n_0, s.x_0, s.T_0, s.v_0 = pr['n_0'], pr['x_0'], pr['T_0'], pr['v_0']
+    s.q_n, s.q_x, s.q_T, s.q_v = pl['q_n'], pl['q_x'], pl['q_T'], pl['q_v']
+    s.qd_n, s.qd_x, s.qd_T, s.qd_v = pl['q^d_n'], pl['q^d_x'], pl['q^d_T'], pl['q^d_v']
+    s.rb_frac = pr['mlr_rj'] / pr['mlr_bj']
+    return s
+
+
+def _load_params_file(py_file, checker):
+    if not os.path.exists(py_file):
+        raise FileNotFoundError(py_file + " does not exist")
+    params = runpy.run_path(py_file)["params"]
+    err = checker(params)
+    if err is not None:
+        raise err
+    return params
+
+
+class JetModel:
+    """Physical model of an ionised jet + its line-of-sight radiative transfer."""
+    _arr_indexing = 'ij'
+
+    # ------------------------------------------------------------------ construction ----
+    @classmethod
+    def load_model(cls, model_file, engine=None):
+        """Restore a model saved by `JetModel.save` (classes.py:48-88)."""
+        with open(os.path.expanduser(model_file), 'rb') as f:
+            loaded = pickle.load(f)
+        log = loaded.get('log')
+        if log is None:
+            log = logger.Log(os.path.expanduser('~') + os.sep + 'temp.log')
+        new = cls(loaded["params"], log=log, engine=engine,
+                  storage=loaded.get('storage', 'f64'))
+        new.time = loaded['time']
+        return new
+
+    @staticmethod
+    def lz_to_grid_dims(params):
+        """Grid dimensions from the requested jet length l_z [arcsec] (classes.py:90-122)."""
+        cs = params["grid"]["c_size"]
+        g = params["geometry"]
+        i_rads, pa_rads = np.radians(g["inc"]), np.radians(g["pa"])
+        l_xz = params['grid']['l_z'] * params['target']['dist']
+        xmax, ymax, zmax = (l_xz * np.sin(pa_rads), l_xz * np.tan(1.571 - i_rads),
+                            l_xz * np.cos(pa_rads))
+        rmax = mgeom.xyz_to_rwp(xmax, ymax, zmax, g["inc"], g["pa"])[0]
+        wmax = mgeom.w_r(rmax, g["w_0"], g["mod_r_0"], g["r_0"], g["epsilon"])
+        pad = 2 * int(np.ceil(np.abs(wmax / cs)))
+        dims = [int(np.ceil(np.abs(v / cs))) + pad for v in (xmax, ymax, zmax)]
+        return tuple(n if n % 2 == 0 else n + 1 for n in dims)
+
+    @staticmethod
+    def py_to_dict(py_file):
+        """Model parameter file -> dict (classes.py:124-142)."""
+        return _load_params_file(py_file, miscf.check_model_params)
+
+    def __init__(self, params, log=None, engine=None, storage='f64'):
+        if isinstance(params, dict):
+            self._params = params
+        elif isinstance(params, str):
+            self._params = JetModel.py_to_dict(params)
+        else:
+            raise TypeError("Supplied arg params must be dict or file path (str)")
+        if storage not in _STORAGE:
+            raise ValueError("storage must be 'f64' or 'f32'")
+        self._dtype = _STORAGE[storage]
+        p = self._params
+        self._name = p['target']['name']
+        self._csize = p['grid']['c_size']
+
+        # derived parameters, written back into the dict as the reference does
+        # (classes.py:169-180)
+        g, pl = p['geometry'], p['power_laws']
+        g["mod_r_0"] = mgeom.mod_r_0(g['opang'], g['epsilon'], g['w_0'])
+        pl["q_n"] = mphys.q_n(g["epsilon"], pl["q_v"])
+        pl["q_tau"] = mphys.q_tau(g["epsilon"], pl["q_x"], pl["q_n"], pl["q_T"])
+
+        if log is not None:
+            self._log = log
+        else:
+            self._log = logger.Log(os.path.expanduser('~') + os.sep + 'temp.log',
+                                   verbose=True)
+
+        if p['grid'].get('l_z') is not None:
+            nx, ny, nz = JetModel.lz_to_grid_dims(p)
+            self.log.add_entry(
+                "INFO", 'For a (bipolar) jet length of {:.1f}", cell size of {:.2f}au and '
+                        'distance of {:.0f}pc, a grid size of (n_x, n_y, n_z) = ({}, {}, {}) '
+                        'voxels is calculated'.format(p['grid']['l_z'], p["grid"]["c_size"],
+                                                      p["target"]["dist"], nx, ny, nz))
+        else:
+            nx, ny, nz = ((p['grid'][k] + 1) // 2 * 2 for k in ('n_x', 'n_y', 'n_z'))
+        p['grid']['n_x'], p['grid']['n_y'], p['grid']['n_z'] = nx, ny, nz
+        self._nx, self._ny, self._nz = int(nx), int(ny), int(nz)
+
+        pr = p["properties"]
+        self._ss_jml_rb_frac = pr["mlr_rj"] / pr["mlr_bj"]
+        self._ss_jml_bj = pr["mlr_bj"] * 1.989e30 / con.year          # classes.py:230-231
+        self._ss_jml_rj = self._ss_jml_bj * self._ss_jml_rb_frac
+        pr["n_0"] = mphys.n_0_from_mlr(pr["mlr_bj"], pr["v_0"], g["w_0"], pr["mu"],
+                                       pl["q^d_n"], pl["q^d_v"], p["target"]["R_1"],
+                                       p["target"]["R_2"])
+
+        self._ejections = {}
+        self._bursts = {'R': [], 'B': []}           # (t0 [s], amp_rel, sigma [s])
+        for idx, t0 in enumerate(p['ejection']['t_0']):
+            which = str(p['ejection']['which'][idx])
+            for jet, ss in (('R', self._ss_jml_rj), ('B', self._ss_jml_bj)):
+                if jet in which:
+                    self.add_ejection_event(t0 * con.year, ss * p['ejection']['chi'][idx],
+                                            p['ejection']['hl'][idx] * con.year, which=jet)
+        self._time = 0. * con.year
+
+        # device state (created lazily: constructing a model needs no GPU, using it does)
+        self._engine = engine
+        self._dev = None
+        self._version = 0            # bumped whenever a field or the burst list changes
+        self._scan_cache = {}        # time -> (sumA[P], em[P]) device tensors
+        self._tavg = None
+        self._host_ts = None
+
+    # ------------------------------------------------------------------ bookkeeping ----
+    def __str__(self):
+        """The parameter table the reference prints and embeds in every FITS header
+        (classes.py:268-361)."""
+        p = self.params
+        g, pl, pr, tg = p['geometry'], p['power_laws'], p['properties'], p['target']
+        rows = [('epsilon', format(g['epsilon'], '+.3f')),
+                ('opang', format(g['opang'], '+.0f') + ' deg'),
+                ('q_v', format(pl['q_v'], '+.3f')), ('q_T', format(pl['q_T'], '+.3f')),
+                ('q_x', format(pl['q_x'], '+.3f')), ('q_n', format(pl['q_n'], '+.3f')),
+                ('q^d_v', format(pl['q^d_v'], '+.3f')), ('q^d_T', format(pl['q^d_T'], '+.3f')),
+                ('q^d_x', format(pl['q^d_x'], '+.3f')), ('q^d_n', format(pl['q^d_n'], '+.3f')),
+                ('q_tau', format(pl['q_tau'], '+.3f')),
+                ('cell', format(p['grid']['c_size'], '.1f') + ' au'),
+                ('w_0', format(g['w_0'], '.2f') + ' au'),
+                ('r_0', format(g['r_0'], '.2f') + ' au'),
+                ('v_0', format(pr['v_0'], '.0f') + ' km/s'),
+                ('x_0', format(pr['x_0'], '.3f')),
+                ('n_0', format(pr['n_0'], '.3e') + ' cm^-3'),
+                ('T_0', format(pr['T_0'], '.0e') + ' K'),
+                ('f_R2B', format(self._ss_jml_rb_frac, '.2e')),
+                ('i', format(g['inc'], '+.1f') + ' deg'),
+                ('theta', format(g['pa'], '+.1f') + ' deg'),
+                ('D', format(tg['dist'], '+.0f') + ' pc'),
+                ('M*', format(tg['M_star'], '+.1f') + ' Msol'),
+                ('R_1', format(tg['R_1'], '+.1f') + ' au'),
+                ('R_2', format(tg['R_2'], '+.1f') + ' au')]
+        if len(p['ejection']['t_0']) > 0:
+            rows.append(('t_now', format(self.time / con.year, '+.3f') + ' yr'))
+        head = ('Parameter', 'Value')
+        w1 = max(len(head[0]), *(len(r[0]) for r in rows)) + 2
+        w2 = max(len(head[1]), *(len(r[1]) for r in rows)) + 2
+        width = w1 + w2 + 3
+        rule = '-' * width
+
+        def line(cells, widths):
+            return '|' + '|'.join(format(c, '^' + str(w)) for c, w in zip(cells, widths)) + '|\n'
+
+        s = rule + '\n' + '/' + format('JET MODEL', '^' + str(width - 2)) + '/\n' + rule + '\n'
+        s += line(head, (w1, w2)) + rule + '\n'
+        for r in rows:
+            s += line(r, (w1, w2))
+        s += rule + '\n'
+        s += '/' + format('BURSTS', '^' + str(width - 2)) + '/\n' + rule + '\n'
+        ej = p["ejection"]
+        if len(ej["t_0"]) == 0:
+            return s + '|' + format(' None ', '-^' + str(width - 2)) + '|\n' + rule + '\n'
+        base, extra = divmod(width - 4, 3)
+        bw = [base + (1 if extra > 0 else 0), base + (1 if extra == 2 else 0), base]
+        s += line(('t_0', 'FWHM', 'chi'), bw) + line(('[yr]', '[yr]', ''), bw) + rule + '\n'
+        for i, t in enumerate(ej["t_0"]):
+            s += line((format(t, '.2f'), format(ej["hl"][i], '.2f'),
+                       format(ej["chi"][i], '.2f')), bw)
+        return s + rule + '\n'
+
+    @property
+    def los_axis(self):
+        return 1 if self._arr_indexing == 'ij' else 0
+
+    @property
+    def time(self):
+        """Model time [s]."""
+        return self._time
+
+    @time.setter
+    def time(self, new_time):
+        self._time = new_time
+
+    @property
+    def log(self):
+        return self._log
+
+    @log.setter
+    def log(self, new_log):
+        self._log = new_log
+
+    csize = property(lambda self: self._csize)
+    nx = property(lambda self: self._nx)
+    ny = property(lambda self: self._ny)
+    nz = property(lambda self: self._nz)
+    params = property(lambda self: self._params)
+    name = property(lambda self: self._name)
+    ejections = property(lambda self: self._ejections)
+
+    def ss_jml(self, which):
+        if which == 'R':
+            return self._ss_jml_rj
+        if which == 'B':
+            return self._ss_jml_bj
+        if 'R' in which and 'B' in which:
+            return self._ss_jml_rj + self._ss_jml_bj
+        raise ValueError("which must be one of 'R', 'B', or 'RB'")
+
+    def add_ejection_event(self, t_0, peak_jml, half_life, which):
+        """Gaussian mass-loss burst (classes.py:399-463): t_0, half_life [s], peak [kg/s]."""
+        assert which in ('R', 'B')
+        ss = self._ss_jml_bj if which == 'B' else self._ss_jml_rj
+        sigma = half_life * 2. / (2. * np.sqrt(2. * np.log(2.)))
+        self._bursts[which].append((t_0, (peak_jml - ss) / ss, sigma))
+        self._ejections[str(len(self._ejections) + 1)] = {
+            't_0': t_0, 'peak_jml': peak_jml, 'half_life': half_life, 'which': which}
+        self._invalidate()
+
+    def jml_t(self, which):
+        """Callable mdot(t) [kg/s] of the red and/or blue jet (classes.py:383-397)."""
+        def mdot(t):
+            tot = 0.
+            for jet, ss in (('R', self._ss_jml_rj), ('B', self._ss_jml_bj)):
+                if jet in which:
+                    tot = tot + ss * self._chi_host(jet, t)
+            return tot
+        return mdot
+
+    def _chi_host(self, jet, t):
+        chi = 1.0
+        for t0, amp_rel, sigma in self._bursts[jet]:
+            chi = chi + amp_rel * np.exp(-(t - t0) ** 2. / (2. * sigma ** 2.))
+        return chi
+
+    # ------------------------------------------------------------------ device state ----
+    @property
+    def engine(self):
+        if self._engine is None:
+            from .engine import RTEngine
+            self._engine = RTEngine(int(os.environ.get("LOCAL_RANK", "0")))
+        return self._engine
+
+    def _invalidate(self):
+        self._version = getattr(self, "_version", 0) + 1
+        self._scan_cache = {}
+        self._tavg = None
+
+    @property
+    def gff_mode(self):
+        """classes.py:1388-1393: one Gaunt factor per channel iff q_T == 0."""
+        return _lib.RJP_GFF_SCALAR if self.params['power_laws']['q_T'] == 0. \
+            else _lib.RJP_GFF_POWERLAW
+
+    @property
+    def device_fields(self):
+        """The packed HBM state; built on the GPU on first use (K4)."""
+        if self._dev is None:
+            if self.log:
+                self.log.add_entry("INFO", "Calculating cells' fill factors/projected areas")
+            then = _time.time()
+            geom = geometry_struct(self.params, self.nx, self.ny, self.nz)
+            closed = self.params['power_laws']['q^d_v'] == 0.
+            self._dev = self.engine.build_fields(geom, self._dtype, want_ts=closed)
+            if not closed:
+                # launch times need 2F1: host evaluation as in the reference
+                # (maths/geometry.py:150-178), uploaded once
+                self.engine.replace_field(self._dev, "ts", self._host_launch_times())
+            self.engine.synchronize()
+            if self.log:
+                self.log.add_entry("INFO", _time.strftime(
+                    'Finished in %Hh%Mm%Ss', _time.gmtime(_time.time() - then)))
+        return self._dev
+
+    def _host_launch_times(self):
+        g = self.params['geometry']
+        ix, iy, iz = np.meshgrid(np.arange(self.nx), np.arange(self.ny), np.arange(self.nz),
+                                 indexing='ij')
+        c = self.csize
+        rr, ww, _ = mgeom.xyz_to_rwp(c * (ix - self.nx // 2) + c / 2., c * (iy - self.ny // 2) +
+                                     c / 2., c * (iz - self.nz // 2) + c / 2., g["inc"], g["pa"])
+        r = np.abs(rr)
+        r = np.where((r < g['r_0']) & ((r + c / 2.) >= g['r_0']), (g['r_0'] + r + c / 2.) / 2., r)
+        with np.errstate(all="ignore"):
+            return mgeom.t_rw(r, ww, self.params) * con.year
+
+    def _rjp_bursts(self):
+        from .engine import make_bursts
+        return make_bursts(self._bursts['R'], self._bursts['B'])
+
+    def _grid(self, tensor):
+        return tensor.cpu().numpy().astype(np.float64).reshape(self.nx, self.ny, self.nz)
+
+    # grids as host arrays (inspection / plotting / pickling; not on the RT path)
+    @property
+    def fill_factor(self):
+        return self._grid(self.device_fields.ff_raw) if self.device_fields.ff_raw is not None \
+            else self._grid(self.device_fields.pf)
+
+    @property
+    def areas(self):
+        d = self.device_fields
+        return self._grid(d.areas_raw) if d.areas_raw is not None else \
+            np.where(np.isnan(self._grid(d.pf)), np.nan, 1.0)
+
+    @property
+    def ts(self):
+        """Time since launch of the material in each cell [s] (classes.py:838-855)."""
+        return self.time - self._grid(self.device_fields.ts)
+
+    @ts.setter
+    def ts(self, new_ts):
+        self.engine.replace_field(self.device_fields, "ts", new_ts)
+        self._invalidate()
+
+    @property
+    def ion_fraction(self):
+        return self._grid(self.device_fields.xi)
+
+    @ion_fraction.setter
+    def ion_fraction(self, new_xis):
+        self.engine.replace_field(self.device_fields, "xi", new_xis)
+        self._invalidate()
+
+    @property
+    def temperature(self):
+        return self._grid(self.device_fields.temp)
+
+    @temperature.setter
+    def temperature(self, new_ts):
+        self.engine.replace_field(self.device_fields, "temp", new_ts)
+        self._invalidate()
+
+    @property
+    def chi_xyz(self):
+        """Burst factor per cell (classes.py:861-870)."""
+        red = np.signbit(self._grid(self.device_fields.nd))
+        tl = self.ts
+        return np.where(red, self._chi_host('R', tl), self._chi_host('B', tl))
+
+    @property
+    def number_density(self):
+        return np.abs(self._grid(self.device_fields.nd)) * self.chi_xyz
+
+    @property
+    def vel(self):
+        """(None, v_y + v_lsr, None) [km/s]: only the line-of-sight component feeds the RT
+        path (classes.py:1160-1161); the transverse components are not built."""
+        return None, self._grid(self.device_fields.vy), None
+
+    # ------------------------------------------------------------------ K1 cache ----
+    def prefetch_epochs(self, times_s):
+        """Scan the grid for several model times at once (eight epochs share one pass over
+        HBM); later RT calls at those times reuse the base maps."""
+        todo = [t for t in dict.fromkeys(float(t) for t in times_s)
+                if t not in self._scan_cache]
+        if not todo:
+            return
+        dev = self.device_fields
+        sumA, em, tavg = self.engine.ff_scan(dev, self._rjp_bursts(), todo, self.gff_mode)
+        for i, t in enumerate(todo):
+            self._scan_cache[t] = (sumA[i:i + 1], em[i:i + 1])
+        self._tavg = tavg
+
+    def _base_maps(self):
+        t = float(self.time)
+        if t not in self._scan_cache:
+            self.prefetch_epochs([t])
+        return self._scan_cache[t] + (self._tavg,)
+
+    def _map(self, tensor, lead=()):
+        return tensor.cpu().numpy().reshape(*lead, self.nx, self.nz)
+
+    def _ff_products(self, freq, tau=False, flux=False, intensity=False, device=False):
+        from . import engine as E
+        scalar = np.isscalar(freq)
+        freqs = np.atleast_1d(np.asarray(freq, dtype=np.float64))
+        sumA, _, tavg = self._base_maps()
+        gv = None
+        if self.gff_mode == _lib.RJP_GFF_SCALAR:
+            gv = [mphys.gff(nu, self.params['properties']['T_0']) for nu in freqs]
+        ctau, cflux = E.ff_channel_coeffs(freqs, self.csize, self.params["target"]["dist"],
+                                          self.gff_mode, gv)
+        if intensity:        # W m^-2 Hz^-1 sr^-1 (classes.py:1475, 1488)
+            cflux = 2. * freqs ** 2. * con.k / con.c ** 2.
+        t, s, _ = self.engine.ff_maps(sumA, tavg, ctau, cflux, want_tau=tau,
+                                      want_flux=flux or intensity, want_ftot=False)
+        out = t if tau else s
+        if device:
+            return out.reshape(len(freqs), self.nx, self.nz)
+        arr = self._map(out, (len(freqs),))
+        return arr[0] if scalar else arr
+
+    # ------------------------------------------------------------------ RT methods ----
+    def emission_measure(self, savefits=False):
+        """Emission measure along y [pc cm^-6] (classes.py:1101-1128)."""
+        _, em, _ = self._base_maps()
+        ems = self._map(em)
+        if savefits:
+            self.save_fits(miscf.reorder_axes(ems, ra_axis=0, dec_axis=1), savefits, 'em')
+        return ems
+
+    def optical_depth_ff(self, freq, savefits=False, collapse=True):
+        """Free-free optical depth along y (classes.py:1353-1447)."""
+        if not collapse:
+            raise NotImplementedError("collapse=False (the 3-D per-cell optical depths) is "
+                                      "not produced by the line-of-sight scan kernels")
+        tff = self._ff_products(freq, tau=True)
+        self._save_cube(tff, savefits, 'tau', freq)
+        return tff
+
+    def intensity_ff(self, freq, savefits=False):
+        """Radio intensity [W m^-2 Hz^-1 sr^-1] (classes.py:1449-1496)."""
+        ints = self._ff_products(freq, intensity=True)
+        self._save_cube(ints, savefits, 'intensity', freq)
+        return ints
+
+    def flux_ff(self, freq, savefits=False):
+        """Flux density [Jy/pixel] (classes.py:1498-1541)."""
+        fluxes = self._ff_products(freq, flux=True)
+        self._save_cube(fluxes, savefits, 'flux', freq)
+        return fluxes
+
+    def _rrl_tau_device(self, rrl, freqs):
+        line = _lib.Line(**mrrl.line_constants(rrl))
+        return self.engine.rrl_scan(self.device_fields, self._rjp_bursts(), float(self.time),
+                                    line, freqs)
+
+    def optical_depth_rrl(self, rrl, freq, lte=True, savefits=False, collapse=True):
+        """RRL optical depth along y (classes.py:1130-1229)."""
+        if not collapse:
+            raise NotImplementedError("collapse=False (the 3-D per-cell optical depths) is "
+                                      "not produced by the line-of-sight scan kernels")
+        scalar = np.isscalar(freq)
+        freqs = np.atleast_1d(np.asarray(freq, dtype=np.float64))
+        tau = self._map(self._rrl_tau_device(rrl, freqs), (len(freqs),))
+        tau = tau[0] if scalar else tau
+        self._save_cube(tau, savefits, 'tau', freq)
+        return tau
+
+    def _rrl_flux(self, rrl, freq, lte, contsub, intensity=False):
+        from . import engine as E
+        if not lte:
+            raise ValueError("Non-LTE RRL calculations not yet supported")   # classes.py:1261
+        scalar = np.isscalar(freq)
+        freqs = np.atleast_1d(np.asarray(freq, dtype=np.float64))
+        F, P = len(freqs), self.nx * self.nz
+        tau_rrl = self._rrl_tau_device(rrl, freqs)
+        tau_ff = self._ff_products(freqs, tau=True, device=True).reshape(F, P)
+        flux_ff = None
+        if not contsub:
+            flux_ff = self._ff_products(freqs, flux=True, device=True).reshape(F, P)
+        cfl, hnu = E.rrl_channel_coeffs(freqs, self.csize, self.params["target"]["dist"])
+        if intensity:
+            cfl = cfl / (E.solid_angle(self.csize, self.params["target"]["dist"]) / 1e-26)
+        flux, _ = self.engine.rrl_maps(tau_rrl, tau_ff, self._tavg, flux_ff, cfl, hnu,
+                                       want_ftot=False)
+        out = self._map(flux, (F,))
+        return out[0] if scalar else out
+
+    def intensity_rrl(self, rrl, freq, lte=True, savefits=False):
+        """RRL intensity [W m^-2 Hz^-1 sr^-1] (classes.py:1231-1290).  Arrays of
+        frequencies are handled channel by channel; the reference's own array branch raises
+        (it passes the whole array where a scalar is meant, classes.py:1266-1271)."""
+        ints = self._rrl_flux(rrl, freq, lte, contsub=True, intensity=True)
+        self._save_cube(ints, savefits, 'intensity', freq)
+        return ints
+
+    def flux_rrl(self, rrl, freq, lte=True, contsub=True, savefits=False):
+        """RRL flux [Jy/pixel], continuum-subtracted unless contsub=False
+        (classes.py:1292-1351)."""
+        fluxes = self._rrl_flux(rrl, freq, lte, contsub)
+        self._save_cube(fluxes, savefits, 'flux', freq)
+        return fluxes
+
+    # ------------------------------------------------------------------ products ----
+    def _save_cube(self, data, savefits, image_type, freq):
+        if not savefits:
+            return
+        if np.ndim(data) == 3:
+            arr = miscf.reorder_axes(data, ra_axis=1, dec_axis=2, axis3=0, axis3_type='freq')
+        else:
+            arr = miscf.reorder_axes(data, ra_axis=0, dec_axis=1)
+        self.save_fits(arr, savefits, image_type, freq)
+
+    def save_fits(self, data, filename, image_type, freq=None):
+        """Write a map/cube with the reference's header (classes.py:1543-1652)."""
+        if image_type not in ('flux', 'tau', 'em', 'intensity'):
+            raise ValueError("arg image_type must be one of 'flux', 'tau' or 'em'")
+        ndims = len(np.shape(data))
+        if ndims not in (2, 3):
+            raise ValueError(f"Unexpected number of data dimensions ({ndims})")
+        tg = self.params['target']
+        _, dec_deg = miscf.sexagesimal_to_deg(tg['ra'], tg['dec'])
+        # astropy's hourangle -> degree scale factor is (15 pi/180)/(pi/180), not a literal 15
+        ra_deg = miscf.parse_sexagesimal(tg['ra']) * ((15. * (np.pi / 180.)) / (np.pi / 180.))
+        csize_deg = np.degrees(np.arctan(self.csize * con.au / (tg['dist'] * con.parsec)))
+        h = _fits.Header()
+        h.set('AUTHOR', 'S.J.D.Purser')
+        h.set('OBJECT', tg['name'])
+        h.set('CTYPE1', 'RA---TAN', 'x-coord type is RA Tan Gnomonic projection')
+        h.set('CTYPE2', 'DEC--TAN', 'y-coord type is DEC Tan Gnomonic projection')
+        h.set('EQUINOX', 2000., 'Equinox of coordinates')
+        h.set('CRPIX1', self.nx / 2 + 0.5, 'Reference pixel in RA')
+        h.set('CRPIX2', self.nz / 2 + 0.5, 'Reference pixel in DEC')
+        h.set('CRVAL1', ra_deg, 'Reference pixel value in RA (deg)')
+        h.set('CRVAL2', dec_deg, 'Reference pixel value in DEC (deg)')
+        h.set('CDELT1', -csize_deg, 'Pixel increment in RA (deg)')
+        h.set('CDELT2', csize_deg, 'Pixel size in DEC (deg)')
+        if image_type in ('flux', 'tau', 'intensity'):
+            if ndims == 3:
+                nchan = len(freq)
+                chan_width = float(freq[1] - freq[0]) if nchan != 1 else 1.
+                h.set('CTYPE3', 'FREQ', 'Spectral axis (frequency)')
+                h.set('CRPIX3', nchan / 2. + 0.5, 'Reference frequency (channel number)')
+                h.set('CRVAL3', float(freq[len(freq) // 2 - 1] + chan_width / 2),
+                      'Reference frequency (Hz)')
+                h.set('CDELT3', chan_width, 'Frequency increment (Hz)')
+            else:
+                f0 = float(freq[0]) if not np.isscalar(freq) else float(freq)
+                h.set('CDELT3', 1., 'Frequency increment (Hz)')
+                h.set('CRPIX3', 0.5, 'Reference frequency (channel number)')
+                h.set('CRVAL3', f0, 'Reference frequency (Hz)')
+        h.set('BUNIT', {'flux': 'Jy pixel^-1', 'intensity': 'W m^-2 Hz^-1 sr^-1',
+                        'em': 'pc cm^-6', 'tau': 'dimensionless'}[image_type])
+        lines = self.__str__().split('\n')
+        h.add_history((' ' * (72 - len(lines[0]))).join(lines))
+        _fits.writeto(filename, data, h)
+
+    def save(self, filename):
+        """Pickle the model state (classes.py:1704-1713).  The grids themselves are not
+        stored: they are rebuilt on the GPU in milliseconds."""
+        ps = {'params': self._params, 'areas': None, 'ffs': None, 'time': self.time,
+              'log': self.log, 'storage': 'f64' if self._dtype == _lib.RJP_F64 else 'f32'}
+        self.log.add_entry("INFO", "Saving physical model to {}".format(filename))
+        with open(filename, "wb") as f:
+            pickle.dump(ps, f)
+
+
+class ContinuumRun:
+    """One (epoch, frequency band) radiative-transfer run (classes.py:1716-1900)."""
+
+    def __init__(self, dcy, year, freq=None, bandwidth=None, chanwidth=None, t_obs=None,
+                 t_int=None, tscop=None):
+        self._year, self._dcy, self._obs_type = year, dcy, 'continuum'
+        self._freq, self._t_obs, self._t_int, self._tscop = freq, t_obs, t_int, tscop
+        self._products, self._results = {}, {}
+        self._bandwidth = bandwidth if bandwidth is not None else 1.
+        self._chanwidth = chanwidth if chanwidth is not None else 1.
+        self.completed = False
+        self.radiative_transfer = freq is not None
+        self.simobserve = all(v is not None for v in (tscop, bandwidth, chanwidth, t_obs,
+                                                      t_int))
+
+    line = None
+
+    def _row(self):
+        val = [self._year, self._obs_type.capitalize(), self._tscop, self._t_obs, self._t_int,
+               self.line, self._freq, self._bandwidth, self._chanwidth,
+               self.radiative_transfer, self.simobserve, self.completed]
+        return ['-' if v is None else v for v in val]
+
+    def __str__(self):
+        return _run_table([self._row()], "grid")
+
+    @property
+    def results(self):
+        return self._results
+
+    @results.setter
+    def results(self, new_results):
+        if not isinstance(new_results, dict):
+            raise TypeError("setter method for results attribute requires dict")
+        self._results = new_results
+
+    @property
+    def products(self):
+        return self._products
+
+    @products.setter
+    def products(self, new_products):
+        if not isinstance(new_products, dict):
+            raise TypeError("setter method for products attribute requires dict")
+        self._products = new_products
+
+    obs_type = property(lambda self: self._obs_type)
+    year = property(lambda self: self._year)
+    freq = property(lambda self: self._freq)
+    bandwidth = property(lambda self: self._bandwidth)
+    chanwidth = property(lambda self: self._chanwidth)
+    t_obs = property(lambda self: self._t_obs)
+    t_int = property(lambda self: self._t_int)
+    tscop = property(lambda self: self._tscop)
+
+    @property
+    def dcy(self):
+        return self._dcy
+
+    @dcy.setter
+    def dcy(self, path):
+        self._dcy = path
+
+    @property
+    def day(self):
+        return int(self.year * 365.)
+
+    @property
+    def model_dcy(self):
+        return os.sep.join([self.dcy, f'Day{self.day}'])
+
+    def _tag(self):
+        return miscf.freq_str(self.freq)
+
+    @property
+    def rt_dcy(self):
+        if not self.radiative_transfer:
+            return None
+        return os.sep.join([self.model_dcy, self._tag()])
+
+    def _fits(self, kind):
+        return self.rt_dcy + os.sep + '_'.join([kind, 'Day' + str(self.day),
+                                                self._tag()]) + '.fits'
+
+    fits_flux = property(lambda self: self._fits('Flux'))
+    fits_tau = property(lambda self: self._fits('Tau'))
+    fits_em = property(lambda self: self._fits('EM'))
+
+    @property
+    def nchan(self):
+        return int(self.bandwidth / self.chanwidth)
+
+    @property
+    def chan_freqs(self):
+        chan1 = self.freq - self.bandwidth / 2. + self.chanwidth / 2.
+        return chan1 + np.arange(self.nchan) * self.chanwidth
+
+
+class RRLRun(ContinuumRun):
+    """One (epoch, recombination line) run (classes.py:1903-1967)."""
+
+    def __init__(self, dcy, year, line=None, bandwidth=None, chanwidth=None, t_obs=None,
+                 t_int=None, tscp=None):
+        freq = mrrl.rrl_nu_0(*mrrl.rrl_parser(line))
+        super().__init__(dcy, year, freq, bandwidth, chanwidth, t_obs, t_int, tscp)
+        self.line = line
+        self._obs_type = 'rrl'
+
+    def _tag(self):
+        return self.line
+
+
+_RUN_HDR = ['Year', 'Type', 'Telescope', 't_obs', 't_int', 'Line', 'Frequency', 'Bandwidth',
+            'Channel width', 'Radiative Transfer?', 'Synthetic Obs.?', 'Completed?']
+_RUN_UNITS = ['yr', '', '', 's', 's', '', 'Hz', 'Hz', 'Hz', '', '', '']
+_RUN_FMT = ['.2f', '', '', '.0f', '.0f', '', '.3e', '.3e', '.3e', '', '', '']
+
+
+def _run_table(rows, tablefmt, **kw):
+    import tabulate
+    head = [h + ('\n[' + u + ']' if u else '') for h, u in zip(_RUN_HDR, _RUN_UNITS)]
+    return tabulate.tabulate(rows, head, tablefmt=tablefmt, floatfmt=_RUN_FMT, **kw)
+
+
+class Pipeline:
+    """Runs the radiative transfer of every (epoch x band/line) of a pipeline-params file
+    and writes the reference's products (classes.py:1970-2868, RT section 2386-2479).
+    The CASA synthetic-observation section is outside this core."""
+
+    @classmethod
+    def load_pipeline(cls, load_file):
+        home = os.path.expanduser('~')
+        with open(os.path.expanduser(load_file), 'rb') as f:
+            loaded = pickle.load(f)
+        for run in loaded['runs']:
+            run.dcy = run.dcy.replace('~', home)
+        loaded['model_file'] = loaded['model_file'].replace('~', home)
+        loaded['params']['dcys']['model_dcy'] = \
+            loaded['params']['dcys']['model_dcy'].replace('~', home)
+        jm = JetModel.load_model(loaded["model_file"])
+        new = cls(jm, loaded["params"], log=loaded.get('log'))
+        new.runs = loaded["runs"]
+        return new
+
+    @staticmethod
+    def py_to_dict(py_file):
+        return _load_params_file(py_file, miscf.check_pline_params)
+
+    def __init__(self, jetmodel, params, log=None):
+        if not isinstance(jetmodel, JetModel):
+            raise TypeError("Supplied arg jetmodel must be JetModel instance not {}"
+                            "".format(type(jetmodel)))
+        self.model = jetmodel
+        if isinstance(params, dict):
+            err = miscf.check_pline_params(params)
+            if err:
+                raise err
+            self._params = params
+        elif isinstance(params, str):
+            self._params = Pipeline.py_to_dict(params)
+        else:
+            raise TypeError("Supplied arg params must be dict or full path (str)")
+
+        self.dcy = self.params['dcys']['model_dcy'].rstrip(os.sep)
+        self.model_file = self.dcy + os.sep + "jetmodel.save"
+        self.save_file = self.dcy + os.sep + "pipeline.save"
+        log_name = "Pipeline_{}.log".format(_time.strftime("%Y%m%d%H-%M-%S",
+                                                           _time.localtime()))
+        created = not os.path.exists(self.dcy)
+        if created:
+            os.mkdir(self.dcy)
+        self._log = log if log is not None else logger.Log(os.sep.join([self.dcy, log_name]))
+        if created:
+            self.log.add_entry("INFO", f"Creating pipeline directory, {self.dcy}")
+        if self.model.log is None:
+            self.model.log = self.log
+        elif self.model.log is not self.log:
+            merged = logger.Log.combine_logs(self.log, self.model.log, self.log.filename,
+                                             delete_old_logs=True)
+            self.log = self.model.log = merged
+
+        for band in ('continuum', 'rrls'):
+            if self.params[band]['times'] is not None:
+                self.params[band]['times'].sort()
+            else:
+                self.params[band]['times'] = np.array([])
+
+        def pick(v, i):
+            return v[i] if miscf.is_iter(v) else v
+
+        runs = []
+        c = self.params['continuum']
+        self.log.add_entry("INFO", "Reading continuum runs into pipeline")
+        for t in c['times']:
+            for i, freq in enumerate(c['freqs']):
+                runs.append(ContinuumRun(self.dcy, t, freq, pick(c['bws'], i),
+                                         pick(c['chanws'], i), pick(c['t_obs'], i),
+                                         pick(c['t_ints'], i), pick(c['tscps'], i)))
+        if not runs:
+            self.log.add_entry("WARNING", "No continuum runs found", timestamp=True)
+        r = self.params['rrls']
+        self.log.add_entry("INFO", "Reading radio recombination line runs into pipeline")
+        n0 = len(runs)
+        for t in r['times']:
+            for i, line in enumerate(r['lines']):
+                runs.append(RRLRun(self.dcy, t, str(line), pick(r['bws'], i),
+                                   pick(r['chanws'], i), pick(r['t_obs'], i),
+                                   pick(r['t_ints'], i), pick(r['tscps'], i)))
+        if len(runs) == n0:
+            self.log.add_entry("WARNING", "No RRL runs found", timestamp=True)
+        self._runs = runs
+        self.log.add_entry("INFO", self.__str__(), timestamp=True)
+
+    def __str__(self):
+        return _run_table([run._row() for run in self.runs], "psql", numalign='center',
+                          stralign='center')
+
+    params = property(lambda self: self._params)
+
+    @property
+    def runs(self):
+        return self._runs
+
+    @runs.setter
+    def runs(self, new_runs):
+        self._runs = new_runs
+
+    @property
+    def log(self):
+        return self._log
+
+    @log.setter
+    def log(self, new_log):
+        self._log = new_log
+
+    def save(self, save_file, absolute_directories=False):
+        """Pickle the pipeline state (classes.py:2215-2258)."""
+        home = os.path.expanduser('~')
+        mf = self.model_file
+        if not absolute_directories:
+            for run in self.runs:
+                run.dcy = run.dcy.replace(home, '~')
+            self._params['dcys']['model_dcy'] = \
+                self._params['dcys']['model_dcy'].replace(home, '~')
+            mf = mf.replace(home, '~')
+        self.log.add_entry("INFO", "Saving pipeline to " + save_file)
+        with open(save_file, 'wb') as f:
+            pickle.dump({"runs": self.runs, "params": self._params, "model_file": mf,
+                         'log': self.log}, f)
+
+    def execute(self, simobserve=True, verbose=True, dryrun=False, resume=True, clobber=False):
+        """Radiative transfer for every run; writes EM/Tau/Flux FITS products, records
+        `results['flux']`, pickles model and pipeline state (classes.py:2296-2479)."""
+        self.log.add_entry("INFO", "Beginning pipeline execution")
+        if verbose != self.log.verbose:
+            self.log.verbose = verbose
+        if simobserve:
+            self.log.add_entry("WARNING", "CASA synthetic observations are outside the "
+                                          "radiative-transfer core and are skipped")
+        if resume and os.path.exists(self.model_file):
+            self.model = JetModel.load_model(self.model_file, engine=self.model._engine)
+
+        if not dryrun:
+            # one pass over HBM serves up to eight epochs
+            pending = [r.year * con.year for r in self.runs if r.radiative_transfer and
+                       not (r.completed and resume and not clobber)]
+            if pending:
+                self.model.prefetch_epochs(pending)
+
+        for idx, run in enumerate(self.runs):
+            self.model.time = run.year * con.year
+            self.log.add_entry("INFO", "Executing run #{} -> Details:\n{}"
+                                       "".format(idx + 1, run.__str__()))
+            if run.completed and resume and not clobber:
+                self.log.add_entry("INFO", "Run #{} previously completed, skipping"
+                                           "".format(idx + 1), timestamp=False)
+                continue
+            try:
+                if not os.path.exists(run.rt_dcy):
+                    self.log.add_entry("INFO", "{} doesn't exist, creating"
+                                               "".format(run.rt_dcy), timestamp=False)
+                    os.makedirs(run.rt_dcy)
+                if not dryrun and run.radiative_transfer:
+                    self._radiative_transfer(idx, run, clobber)
+            except KeyboardInterrupt:
+                self.log.add_entry("ERROR", "Pipeline interrupted by user, saving state")
+                self.save(self.save_file)
+                self.model.save(self.model_file)
+                raise KeyboardInterrupt("Pipeline interrupted by user")
+            run.completed = True                                   # classes.py:2853
+        self.save(self.save_file)
+        self.model.save(self.model_file)
+
+    def _radiative_transfer(self, idx, run, clobber):
+        m = self.model
+        self.log.add_entry("INFO", "Conducting radiative transfer at "
+                                   f"{run.freq / 1e9:.1f}GHz for a model time of "
+                                   f"{run.year:.1f}yr")
+        if not os.path.exists(run.fits_em) or clobber:
+            self.log.add_entry("INFO", f"Emission measures saved to {run.fits_em}")
+            m.emission_measure(savefits=run.fits_em)
+        else:
+            self.log.add_entry("INFO", f"Emission measures already exist -> {run.fits_em}",
+                               timestamp=False)
+        rrl = run.obs_type != 'continuum'
+        if not os.path.exists(run.fits_tau) or clobber:
+            self.log.add_entry("INFO", f"Computing optical depths and saving to {run.fits_tau}")
+            if rrl:
+                m.optical_depth_rrl(run.line, run.chan_freqs, savefits=run.fits_tau)
+            else:
+                m.optical_depth_ff(run.chan_freqs, savefits=run.fits_tau)
+        else:
+            self.log.add_entry("INFO", f"Optical depths already exist -> {run.fits_tau}",
+                               timestamp=False)
+        if not os.path.exists(run.fits_flux) or clobber:
+            self.log.add_entry("INFO", f"Calculating fluxes and saving to {run.fits_flux}")
+            if rrl:
+                fluxes = m.flux_rrl(run.line, run.chan_freqs, contsub=False,
+                                    savefits=run.fits_flux)
+            else:
+                fluxes = m.flux_ff(run.chan_freqs, savefits=run.fits_flux)
+        else:
+            self.log.add_entry("INFO", f"Fluxes already exist -> {run.fits_flux}",
+                               timestamp=False)
+            fluxes = _fits.read(run.fits_flux)[0]
+        import warnings
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            if not rrl:
+                # classes.py:2461-2467: total of the channel-averaged map
+                flux = np.nansum(np.nanmean(fluxes, axis=0))
+                self.log.add_entry("INFO", f"Total, average, channel flux of {flux:.2e}Jy "
+                                           "calculated")
+            else:
+                flux = np.nansum(np.nansum(fluxes, axis=1), axis=1)     # classes.py:2471
+        self.runs[idx].results['flux'] = flux
+        if not os.path.exists(self.model_file):
+            m.save(self.model_file)
+        self.save(self.save_file, absolute_directories=True)

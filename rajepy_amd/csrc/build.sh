@@ -1,0 +1,32 @@
+#!/bin/bash
+# Builds librjprt.so for gfx950 in-tree (rajepy_amd/librjprt.so).  hipcc cross-compiles
+# without a GPU.  Usage: build.sh [--report]  (--report prints per-kernel register use)
+set -euo pipefail
+here="$(cd "$(dirname "${BASH_SOURCE[0]}")" && pwd)"
+out="$here/../librjprt.so"
+flags=(--offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -Wall -Wno-unused-function)
+if [[ "${1:-}" == "--report" ]]; then
+  hipcc "${flags[@]}" -Rpass-analysis=kernel-resource-usage -o "$out" "$here/rjprt.hip" 2> "$here/../../gpurun_out/resource_usage.txt" || { cat "$here/../../gpurun_out/resource_usage.txt"; exit 1; }
+  python3 - "$here/../../gpurun_out/resource_usage.txt" <<'PY'
+import re, sys, subprocess
+txt = open(sys.argv[1]).read()
+rows = []
+cur = None
+for line in txt.splitlines():
+    m = re.search(r"remark: +(Function Name|VGPRs|AGPRs|TotalSGPRs|ScratchSize \[bytes/lane\]|Occupancy \[waves/SIMD\]|LDS Size \[bytes/block\]): (.*?) \[-R", line)
+    if not m: continue
+    k, v = m.group(1), m.group(2)
+    if k == "Function Name":
+        cur = {"name": v}; rows.append(cur)
+    elif cur is not None:
+        cur[k.split(" [")[0]] = v
+names = subprocess.run(["c++filt"] + [r["name"] for r in rows], capture_output=True, text=True).stdout.splitlines()
+print("%-6s %-6s %-8s %-4s %-6s %s" % ("VGPR", "SGPR", "scratch", "occ", "LDS", "kernel"))
+for r, n in zip(rows, names):
+    n = re.sub(r"\(.*", "", n).replace("void rjp::", "")
+    print("%-6s %-6s %-8s %-4s %-6s %s" % (r.get("VGPRs"), r.get("TotalSGPRs"), r.get("ScratchSize"), r.get("Occupancy"), r.get("LDS Size"), n))
+PY
+else
+  hipcc "${flags[@]}" -o "$out" "$here/rjprt.hip"
+fi
+echo "built $out"

@@ -1,0 +1,398 @@
+// K1 (free-free / emission-measure line-of-sight scan) and K2 (per-channel map stage).
+//
+// K1 replaces the three y-reductions the reference performs per channel with ~15 full-grid
+// NumPy temporaries each (classes.py:1116-1120, 1375-1432, 1471-1472) by ONE streaming pass
+// over the five device-resident fields: one lane owns VEC adjacent (x,z) sightlines (16 B of
+// every field per load, 1 KiB per wave-instruction, lanes adjacent along the contiguous
+// z-axis), walks y serially with UNROLL rows of loads in flight, evaluates the burst factor
+// chi(t) for up to 8 epochs in registers and keeps FP64 accumulators.  The y-range is split
+// over gridDim.y so small maps still fill 256 CUs; partial sums go to a workspace and a tiny
+// second kernel reduces them in a fixed order (bitwise reproducible, no atomics).
+// HBM-bound: algorithmic bytes = 5 fields * sizeof(T) per cell per epoch tile.
+#include <algorithm>
+
+#include "rjp_device.h"
+
+namespace rjp {
+
+template <typename T>
+struct FieldPtrs {
+  const T* nd;
+  const T* xi;
+  const T* temp;
+  const T* pf;
+  const T* ts;
+};
+
+template <int ET>
+struct EpochTile { double t[ET]; };
+
+constexpr int kBlock = 256;
+// y-rows of loads kept in flight per lane; fewer when many accumulators are live so the
+// kernel stays inside the 256-VGPR budget without scratch
+__host__ __device__ constexpr int unroll_for(int vec, int et) {
+  return vec * et >= 16 ? 1 : (vec * et >= 8 ? 2 : 4);
+}
+
+// number of accumulator planes a tile of ET epochs writes per y-split
+__host__ __device__ constexpr int nacc(int et) { return 2 * et + 2; }
+
+template <typename T, int VEC, int ET, int MODE, bool BURSTS>
+__global__ __launch_bounds__(kBlock) void ff_scan_kernel(
+    FieldPtrs<T> f, int ny, int nz, int64_t nchunks, int64_t npix, int ylen, BurstsDev b,
+    EpochTile<ET> ep, double* __restrict__ ws) {
+  constexpr int kUnroll = unroll_for(VEC, ET);
+  const int64_t c = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (c >= nchunks) return;
+  const int64_t p0 = c * VEC;              // first sightline (pixel) of this lane
+  const int64_t x = p0 / nz;
+  const int z = (int)(p0 - x * nz);
+  const int y0 = blockIdx.y * ylen;
+  const int y1 = min(ny, y0 + ylen);
+
+  double accA[ET][VEC], accE[ET][VEC], accT[VEC], cnt[VEC];
+#pragma unroll
+  for (int v = 0; v < VEC; ++v) {
+    accT[v] = 0.0; cnt[v] = 0.0;
+#pragma unroll
+    for (int e = 0; e < ET; ++e) { accA[e][v] = 0.0; accE[e][v] = 0.0; }
+  }
+
+  int64_t off = (x * ny + y0) * (int64_t)nz + z;
+  const int64_t stride = nz;
+
+  auto cell = [&](const double (&nd)[VEC], const double (&xi)[VEC], const double (&tp)[VEC],
+                  const double (&pf)[VEC], const double (&ts)[VEC]) {
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) {
+      const double Tk = tp[v];
+      // temperature power: T^-1.5 (scalar Gaunt) or T^-1.35 = T^-1.5 * T^0.15 (power law)
+      double tpow = pow_m1p5(Tk);
+      if (MODE == RJP_GFF_POWERLAW) tpow *= pow(Tk, 0.15);
+      const double n0 = fabs(nd[v]) * xi[v];       // steady-state electron density
+      const double g = n0 * n0 * pf[v];            // (n x)^2 * ff/areas at chi = 1
+      const double a = g * tpow;
+      if (Tk > 0.0) { accT[v] += Tk; cnt[v] += 1.0; }
+      if (BURSTS) {
+        const bool red = signbit_d(nd[v]);
+#pragma unroll
+        for (int e = 0; e < ET; ++e) {
+          const double chi = chi_cell(b, red, ep.t[e] - ts[v]);
+          const double c2 = chi * chi;
+          const double ge = g * c2, ae = a * c2;
+          if (ge == ge) accE[e][v] += ge;          // nansum: skip NaN only (inf propagates)
+          if (ae == ae) accA[e][v] += ae;
+        }
+      } else {
+        if (g == g) accE[0][v] += g;
+        if (a == a) accA[0][v] += a;
+      }
+    }
+  };
+
+  int y = y0;
+  for (; y + kUnroll <= y1; y += kUnroll) {
+    double nd[kUnroll][VEC], xi[kUnroll][VEC], tp[kUnroll][VEC], pf[kUnroll][VEC],
+        ts[kUnroll][VEC];
+#pragma unroll
+    for (int u = 0; u < kUnroll; ++u) {
+      const int64_t o = off + u * stride;
+      load_vec(f.nd + o, nd[u]);
+      load_vec(f.xi + o, xi[u]);
+      load_vec(f.temp + o, tp[u]);
+      load_vec(f.pf + o, pf[u]);
+      if (BURSTS) load_vec(f.ts + o, ts[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < kUnroll; ++u) cell(nd[u], xi[u], tp[u], pf[u], ts[u]);
+    off += kUnroll * stride;
+  }
+  for (; y < y1; ++y) {
+    double nd[VEC], xi[VEC], tp[VEC], pf[VEC], ts[VEC];
+    load_vec(f.nd + off, nd);
+    load_vec(f.xi + off, xi);
+    load_vec(f.temp + off, tp);
+    load_vec(f.pf + off, pf);
+    if (BURSTS) load_vec(f.ts + off, ts);
+    cell(nd, xi, tp, pf, ts);
+    off += stride;
+  }
+
+  // partial sums: ws[split][plane][pixel]
+  double* w = ws + (int64_t)blockIdx.y * nacc(ET) * npix + p0;
+#pragma unroll
+  for (int e = 0; e < ET; ++e) {
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) {
+      w[(int64_t)e * npix + v] = accA[e][v];
+      w[(int64_t)(ET + e) * npix + v] = accE[e][v];
+    }
+  }
+#pragma unroll
+  for (int v = 0; v < VEC; ++v) {
+    w[(int64_t)(2 * ET) * npix + v] = accT[v];
+    w[(int64_t)(2 * ET + 1) * npix + v] = cnt[v];
+  }
+}
+
+// Fixed-order reduction over the y-splits; writes the base maps of epochs [e0, e0+et).
+__global__ __launch_bounds__(kBlock) void ff_reduce_kernel(
+    const double* __restrict__ ws, int nsplit, int et, int64_t npix, int e0, double em_scale,
+    double* __restrict__ sumA, double* __restrict__ em, double* __restrict__ tavg) {
+  const int64_t p = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (p >= npix) return;
+  const int na = nacc(et);
+  for (int e = 0; e < et; ++e) {
+    double a = 0.0, g = 0.0;
+    for (int s = 0; s < nsplit; ++s) {
+      a += ws[((int64_t)s * na + e) * npix + p];
+      g += ws[((int64_t)s * na + et + e) * npix + p];
+    }
+    sumA[(int64_t)(e0 + e) * npix + p] = a;
+    if (em) em[(int64_t)(e0 + e) * npix + p] = g * em_scale;
+  }
+  if (tavg && e0 == 0) {
+    double t = 0.0, n = 0.0;
+    for (int s = 0; s < nsplit; ++s) {
+      t += ws[((int64_t)s * na + 2 * et) * npix + p];
+      n += ws[((int64_t)s * na + 2 * et + 1) * npix + p];
+    }
+    tavg[p] = t / n;            // 0/0 = NaN on empty sightlines = nanmean of all-NaN
+  }
+}
+
+// ---- K2 ------------------------------------------------------------------------------
+// One thread per pixel, serial over the channels of its slice: every store instruction is a
+// coalesced row segment of one (epoch, channel) map.  Write-bound: 16 B per voxel-channel.
+__global__ __launch_bounds__(kBlock) void ff_maps_kernel(
+    const double* __restrict__ sumA, const double* __restrict__ tavg, int64_t npix,
+    const double* __restrict__ ctau, const double* __restrict__ cflux, int nchan, int fchunk,
+    double* __restrict__ tau, double* __restrict__ flux, double* __restrict__ part) {
+  const int64_t p = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  const int e = blockIdx.y;
+  const int f0 = blockIdx.z * fchunk;
+  const int f1 = min(nchan, f0 + fchunk);
+  const bool live = p < npix;
+  const double A = live ? sumA[(int64_t)e * npix + p] : 0.0;
+  const double ta = live ? tavg[p] : 0.0;
+  __shared__ double red[kBlock / RJP_WAVE];
+  for (int f = f0; f < f1; ++f) {
+    const double t = ctau[f] * A;
+    const double s = cflux[f] * (ta * (1.0 - exp(-t)));
+    const int64_t o = ((int64_t)e * nchan + f) * npix + p;
+    if (live) {
+      if (tau) tau[o] = t;
+      if (flux) flux[o] = s;
+    }
+    if (part) {
+      double v = (live && s == s) ? s : 0.0;        // nansum
+#pragma unroll
+      for (int d = RJP_WAVE / 2; d > 0; d >>= 1) v += __shfl_down(v, d, RJP_WAVE);
+      if ((threadIdx.x & (RJP_WAVE - 1)) == 0) red[threadIdx.x / RJP_WAVE] = v;
+      __syncthreads();
+      if (threadIdx.x == 0) {
+        double tot = 0.0;
+#pragma unroll
+        for (int w = 0; w < kBlock / RJP_WAVE; ++w) tot += red[w];
+        part[((int64_t)e * nchan + f) * gridDim.x + blockIdx.x] = tot;
+      }
+      __syncthreads();
+    }
+  }
+}
+
+// sums the per-block partials of one (epoch, channel) in a fixed order
+__global__ __launch_bounds__(kBlock) void sum_partials_kernel(const double* __restrict__ part,
+                                                              int nblk,
+                                                              double* __restrict__ out) {
+  const int64_t row = blockIdx.x;
+  double v = 0.0;
+  for (int i = threadIdx.x; i < nblk; i += kBlock) v += part[row * nblk + i];
+  __shared__ double red[kBlock / RJP_WAVE];
+#pragma unroll
+  for (int d = RJP_WAVE / 2; d > 0; d >>= 1) v += __shfl_down(v, d, RJP_WAVE);
+  if ((threadIdx.x & (RJP_WAVE - 1)) == 0) red[threadIdx.x / RJP_WAVE] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double tot = 0.0;
+    for (int w = 0; w < kBlock / RJP_WAVE; ++w) tot += red[w];
+    out[row] = tot;
+  }
+}
+
+// ---- launch helpers ---------------------------------------------------------------------
+static int choose_ysplit(int64_t nchunks, int ny) {
+  static int forced = -1;
+  if (forced < 0) {
+    const char* s = getenv("RJP_YSPLIT");
+    forced = s ? atoi(s) : 0;
+  }
+  if (forced > 0) return std::min(forced, ny);
+  const int64_t waves = (nchunks + RJP_WAVE - 1) / RJP_WAVE;
+  const int64_t target = 256 * 24;                 // ~6 waves per SIMD chip-wide
+  int64_t s = (target + waves - 1) / waves;
+  const int64_t smax = std::max(1, ny / 16);
+  if (s > smax) s = smax;
+  if (s < 1) s = 1;
+  return (int)s;
+}
+
+int ff_scan_vec(const rjp_fields* fl) {
+  const int full = fl->dtype == RJP_F64 ? 2 : 4;
+  const size_t esz = (size_t)fl->dtype;
+  bool ok = (fl->nz % full) == 0;
+  const void* ptrs[5] = {fl->d_nd, fl->d_xi, fl->d_temp, fl->d_pf, fl->d_ts};
+  for (const void* p : ptrs)
+    if (p && ((uintptr_t)p % 16) != 0) ok = false;
+  (void)esz;
+  return ok ? full : 1;
+}
+
+size_t ff_scan_workspace_bytes(int nx, int ny, int nz, int n_epochs) {
+  const int64_t npix = (int64_t)nx * nz;
+  const int et = n_epochs < RJP_MAX_EPOCH_TILE ? (n_epochs < 1 ? 1 : n_epochs)
+                                               : RJP_MAX_EPOCH_TILE;
+  // worst case split count is bounded by choose_ysplit's target / (npix/4/64) and ny/16
+  int64_t smax = std::max(1, ny / 16);
+  const int64_t waves_min = std::max<int64_t>(1, (npix / 4 + RJP_WAVE - 1) / RJP_WAVE);
+  int64_t s = (256 * 24 + waves_min - 1) / waves_min;
+  if (const char* f = getenv("RJP_YSPLIT")) s = std::max<int64_t>(s, atoi(f));
+  s = std::min(s, smax);
+  s = std::max<int64_t>(s, 1);
+  return (size_t)s * nacc(et > 8 ? 8 : et) * npix * sizeof(double) + 256;
+}
+
+template <typename T, int VEC, int ET, int MODE, bool BURSTS>
+static hipError_t launch_tile(const rjp_fields* fl, const BurstsDev& b, const double* t,
+                              int nsplit, int ylen, double* ws, hipStream_t st) {
+  FieldPtrs<T> f{(const T*)fl->d_nd, (const T*)fl->d_xi, (const T*)fl->d_temp,
+                 (const T*)fl->d_pf, (const T*)fl->d_ts};
+  EpochTile<ET> ep;
+  for (int e = 0; e < ET; ++e) ep.t[e] = t[e];
+  const int64_t npix = (int64_t)fl->nx * fl->nz;
+  const int64_t nchunks = npix / VEC;
+  dim3 grid((unsigned)((nchunks + kBlock - 1) / kBlock), (unsigned)nsplit);
+  hipLaunchKernelGGL((ff_scan_kernel<T, VEC, ET, MODE, BURSTS>), grid, dim3(kBlock), 0, st, f,
+                     fl->ny, fl->nz, nchunks, npix, ylen, b, ep, ws);
+  return hipGetLastError();
+}
+
+template <typename T, int VEC, int MODE>
+static hipError_t dispatch_et(const rjp_fields* fl, const BurstsDev& b, bool bursts,
+                              const double* t, int et, int nsplit, int ylen, double* ws,
+                              hipStream_t st) {
+  if (!bursts) return launch_tile<T, VEC, 1, MODE, false>(fl, b, t, nsplit, ylen, ws, st);
+  switch (et) {
+    case 1: return launch_tile<T, VEC, 1, MODE, true>(fl, b, t, nsplit, ylen, ws, st);
+    case 2: return launch_tile<T, VEC, 2, MODE, true>(fl, b, t, nsplit, ylen, ws, st);
+    case 4: return launch_tile<T, VEC, 4, MODE, true>(fl, b, t, nsplit, ylen, ws, st);
+    case 8:
+      // 4 sightlines x 8 epochs x 2 sums does not fit 256 VGPRs: the launcher caps the
+      // epoch tile at 4 for 4-wide (f32) lanes
+      if constexpr (VEC == 4) return hipErrorInvalidValue;
+      else return launch_tile<T, VEC, 8, MODE, true>(fl, b, t, nsplit, ylen, ws, st);
+  }
+  return hipErrorInvalidValue;
+}
+
+template <typename T, int VEC>
+static hipError_t dispatch_mode(const rjp_fields* fl, const BurstsDev& b, bool bursts,
+                                int mode, const double* t, int et, int nsplit, int ylen,
+                                double* ws, hipStream_t st) {
+  if (mode == RJP_GFF_SCALAR)
+    return dispatch_et<T, VEC, RJP_GFF_SCALAR>(fl, b, bursts, t, et, nsplit, ylen, ws, st);
+  return dispatch_et<T, VEC, RJP_GFF_POWERLAW>(fl, b, bursts, t, et, nsplit, ylen, ws, st);
+}
+
+// Enqueue the whole scan for n_epochs epochs.  Returns hipSuccess or the first error.
+hipError_t ff_scan_launch(const rjp_fields* fl, const rjp_bursts* hb, const double* epochs,
+                          int n_epochs, int mode, double* sumA, double* em, double* tavg,
+                          double* ws, hipStream_t st) {
+  BurstsDev b;
+  bool bursts = false;
+  for (int j = 0; j < 2; ++j) {
+    b.n[j] = hb ? hb->n[j] : 0;
+    if (b.n[j] > 0) bursts = true;
+    for (int i = 0; i < RJP_MAX_BURSTS; ++i) {
+      b.t0[j][i] = hb ? hb->t0[j][i] : 0.0;
+      b.amp_rel[j][i] = hb ? hb->amp_rel[j][i] : 0.0;
+      b.inv2s2[j][i] = hb ? hb->inv2s2[j][i] : 0.0;
+    }
+  }
+  if (bursts && !fl->d_ts) return hipErrorInvalidValue;
+  const int64_t npix = (int64_t)fl->nx * fl->nz;
+  const int vec = ff_scan_vec(fl);
+  const int nsplit = choose_ysplit(npix / vec, fl->ny);
+  const int ylen = (fl->ny + nsplit - 1) / nsplit;
+  // em = sum (n x)^2 * csize*au/pc * pf  (classes.py:1116-1118)
+  const double em_scale = fl->csize_au * 149597870700.0 / 3.085677581491367e+16;
+  const unsigned rblocks = (unsigned)((npix + kBlock - 1) / kBlock);
+
+  int e0 = 0;
+  while (e0 < n_epochs) {
+    int et = 1;
+    if (bursts) {
+      const int left = n_epochs - e0;
+      et = (left >= 8 && vec != 4) ? 8 : left >= 4 ? 4 : left >= 2 ? 2 : 1;
+    }
+    hipError_t err;
+    const double* t = epochs + e0;
+    if (fl->dtype == RJP_F64) {
+      err = vec == 2 ? dispatch_mode<double, 2>(fl, b, bursts, mode, t, et, nsplit, ylen, ws, st)
+                     : dispatch_mode<double, 1>(fl, b, bursts, mode, t, et, nsplit, ylen, ws, st);
+    } else {
+      err = vec == 4 ? dispatch_mode<float, 4>(fl, b, bursts, mode, t, et, nsplit, ylen, ws, st)
+                     : dispatch_mode<float, 1>(fl, b, bursts, mode, t, et, nsplit, ylen, ws, st);
+    }
+    if (err != hipSuccess) return err;
+    hipLaunchKernelGGL(ff_reduce_kernel, dim3(rblocks), dim3(kBlock), 0, st, ws, nsplit, et,
+                       npix, e0, em_scale, sumA, em, tavg);
+    err = hipGetLastError();
+    if (err != hipSuccess) return err;
+    if (!bursts) {
+      // chi == 1 at every epoch: replicate epoch 0
+      for (int e = 1; e < n_epochs; ++e) {
+        err = hipMemcpyAsync(sumA + (int64_t)e * npix, sumA, npix * sizeof(double),
+                             hipMemcpyDeviceToDevice, st);
+        if (err != hipSuccess) return err;
+        if (em) {
+          err = hipMemcpyAsync(em + (int64_t)e * npix, em, npix * sizeof(double),
+                               hipMemcpyDeviceToDevice, st);
+          if (err != hipSuccess) return err;
+        }
+      }
+      break;
+    }
+    e0 += et;
+  }
+  return hipSuccess;
+}
+
+size_t ff_maps_workspace_bytes(int64_t npix, int n_epochs, int n_chan) {
+  const int64_t nblk = (npix + kBlock - 1) / kBlock;
+  return (size_t)nblk * n_epochs * n_chan * sizeof(double) + 256;
+}
+
+hipError_t ff_maps_launch(const double* sumA, const double* tavg, int64_t npix, int n_epochs,
+                          const double* d_ctau, const double* d_cflux, int n_chan, double* tau,
+                          double* flux, double* ftot, double* part, hipStream_t st) {
+  const unsigned nblk = (unsigned)((npix + kBlock - 1) / kBlock);
+  // split channels over gridDim.z so that small maps still expose >= ~2048 blocks
+  int fsplit = 1;
+  while ((int64_t)nblk * n_epochs * fsplit < 2048 && fsplit < n_chan) fsplit *= 2;
+  const int fchunk = (n_chan + fsplit - 1) / fsplit;
+  fsplit = (n_chan + fchunk - 1) / fchunk;
+  dim3 grid(nblk, (unsigned)n_epochs, (unsigned)fsplit);
+  hipLaunchKernelGGL(ff_maps_kernel, grid, dim3(kBlock), 0, st, sumA, tavg, npix, d_ctau,
+                     d_cflux, n_chan, fchunk, tau, flux, ftot ? part : nullptr);
+  hipError_t err = hipGetLastError();
+  if (err != hipSuccess) return err;
+  if (ftot) {
+    hipLaunchKernelGGL(sum_partials_kernel, dim3((unsigned)(n_epochs * n_chan)), dim3(kBlock),
+                       0, st, part, (int)nblk, ftot);
+    err = hipGetLastError();
+  }
+  return err;
+}
+
+}  // namespace rjp

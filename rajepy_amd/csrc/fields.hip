@@ -1,0 +1,220 @@
+// Field layout kernels: upload packing, K4 (geometry -> fields on the device) and the
+// synthetic dense-field generator of the measurement harness.
+#include <algorithm>
+
+#include "rjp_device.h"
+
+namespace rjp {
+
+constexpr int kFB = 256;
+
+template <typename T>
+__device__ __forceinline__ void store_as(void* dst, int64_t i, double v) {
+  reinterpret_cast<T*>(dst)[i] = (T)v;
+}
+
+__device__ __forceinline__ double with_sign(double mag, bool neg) {
+  long long bits = __double_as_longlong(mag) & 0x7FFFFFFFFFFFFFFFll;
+  if (neg) bits |= (long long)0x8000000000000000ull;
+  return __longlong_as_double(bits);
+}
+
+// ---- upload packing ---------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(kFB) void pack_field_kernel(const double* __restrict__ src,
+                                                         const double* __restrict__ den,
+                                                         const uint8_t* __restrict__ red,
+                                                         T* __restrict__ dst, int64_t n) {
+  int64_t i = (int64_t)blockIdx.x * kFB + threadIdx.x;
+  const int64_t step = (int64_t)gridDim.x * kFB;
+  for (; i < n; i += step) {
+    double v = src[i];
+    if (den) v = v / den[i];
+    if (red) v = with_sign(v, red[i] != 0);
+    dst[i] = (T)v;     // a float cast keeps the sign bit, NaN stays NaN
+  }
+}
+
+hipError_t pack_field_launch(const double* src, const double* den, const uint8_t* red,
+                             void* dst, int64_t n, int dtype, hipStream_t st) {
+  const unsigned blocks = (unsigned)std::min<int64_t>((n + kFB - 1) / kFB, 256 * 16);
+  if (dtype == RJP_F64)
+    hipLaunchKernelGGL(pack_field_kernel<double>, dim3(blocks), dim3(kFB), 0, st, src, den,
+                       red, (double*)dst, n);
+  else
+    hipLaunchKernelGGL(pack_field_kernel<float>, dim3(blocks), dim3(kFB), 0, st, src, den,
+                       red, (float*)dst, n);
+  return hipGetLastError();
+}
+
+// ---- synthetic dense fields --------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(kFB) void synth_kernel(uint64_t seed, int temp_mode, int nz,
+                                                    int64_t cell0, int64_t n, T* nd, T* xi,
+                                                    T* temp, T* pf, T* ts, T* vy) {
+  int64_t i = (int64_t)blockIdx.x * kFB + threadIdx.x;
+  const int64_t step = (int64_t)gridDim.x * kFB;
+  for (; i < n; i += step) {
+    const uint64_t cell = (uint64_t)(cell0 + i);
+    const int iz = (int)(cell % (uint64_t)nz);
+    const bool red = iz < nz / 2;
+    const double un = hash_u01(seed, 1, cell), ux = hash_u01(seed, 2, cell),
+                 ut = hash_u01(seed, 3, cell), up = hash_u01(seed, 4, cell),
+                 us = hash_u01(seed, 5, cell), uv = hash_u01(seed, 6, cell);
+    const double n0 = exp10(5.0 + 2.5 * un);
+    if (nd) nd[i] = (T)with_sign(n0, red);
+    if (xi) xi[i] = (T)(0.05 + 0.45 * ux);
+    if (temp) temp[i] = (T)(temp_mode == 0 ? 1e4 : 5e3 + 1.5e4 * ut);
+    if (pf) pf[i] = (T)(up < 0.25 ? 0.5 : 1.0);
+    if (ts) ts[i] = (T)(5.0 * us * 31536000.0);
+    if (vy) vy[i] = (T)(6.2 + 60.0 * (uv - 0.5));
+  }
+}
+
+hipError_t synth_launch(uint64_t seed, int temp_mode, int nz, int64_t cell0, int64_t n,
+                        int dtype, void* nd, void* xi, void* temp, void* pf, void* ts, void* vy,
+                        hipStream_t st) {
+  const unsigned blocks = (unsigned)std::min<int64_t>((n + kFB - 1) / kFB, 256 * 32);
+  if (dtype == RJP_F64)
+    hipLaunchKernelGGL(synth_kernel<double>, dim3(blocks), dim3(kFB), 0, st, seed, temp_mode, nz,
+                       cell0, n, (double*)nd, (double*)xi, (double*)temp, (double*)pf,
+                       (double*)ts, (double*)vy);
+  else
+    hipLaunchKernelGGL(synth_kernel<float>, dim3(blocks), dim3(kFB), 0, st, seed, temp_mode, nz,
+                       cell0, n, (float*)nd, (float*)xi, (float*)temp, (float*)pf, (float*)ts,
+                       (float*)vy);
+  return hipGetLastError();
+}
+
+// ---- K4: geometry -> fields ---------------------------------------------------------------
+// One thread per cell.  Follows the reference's floating-point ORDER (no FMA contraction)
+// for everything that feeds a comparison (the 8-vertex inside test, classes.py:657-669), so
+// that the jet mask comes out identical; the rotation sines/cosines are computed on the host
+// (NumPy) and passed in, as the reference does (maths/geometry.py:249-253).
+struct GeomDev {
+  int nx, ny, nz, ccw;
+  double cs;
+  double ca, sa, cb, sb;          // derotation: alpha = inc - 90 (about x), beta = pa (about y)
+  double ca2, sa2, cb2, sb2;      // velocity rotation: alpha = 90 - inc, beta = -pa
+  double w_0, r_0, mr0, eps, R_1, R_2;
+  double gm;                      // G * M_star * MSOL [SI]
+  double v_lsr;
+  double n_0, x_0, T_0, v_0;
+  double q_n, q_x, q_T, q_v, qd_n, qd_x, qd_T, qd_v;
+  double rb_frac;
+  double ts_const, ts_pow, ts_base;   // ts = ts_const * (rad^ts_pow - ts_base)  [q^d_v == 0]
+  int ts_closed_form;
+};
+
+#pragma clang fp contract(off)
+__device__ __forceinline__ void xyz_to_rw(const GeomDev& g, double x, double y, double z,
+                                          double& r, double& w, double& x2, double& y2) {
+  // geometry.py:206 xyz_rotate(order='yx'): y-rotation first, then x-rotation
+  const double x1 = g.cb * x + g.sb * z;
+  const double y1 = y;
+  const double z1 = g.cb * z - g.sb * x;
+  x2 = x1;
+  y2 = g.ca * y1 - g.sa * z1;
+  r = g.sa * y1 + g.ca * z1;
+  w = sqrt(x2 * x2 + y2 * y2);      // x ** 2. is an exact square in NumPy too
+}
+
+__device__ __forceinline__ double rho_mod(const GeomDev& g, double r) {
+  return (fabs(r) + g.mr0 - g.r_0) / g.mr0;          // geometry.py:58-59
+}
+
+__device__ __forceinline__ double powerlaw(double zero, double rho_, double reff, double r1,
+                                           double q, double qd) {
+  // geometry.py:92; x ** 0. == 1 in NumPy, pow() agrees
+  double v = zero * pow(rho_, q) * pow(reff / r1, qd);
+  if (v == 0.0 || isinf(v)) v = __builtin_nan("");  // classes.py:892, 897
+  return v;
+}
+
+template <typename T>
+__global__ __launch_bounds__(kFB) void build_fields_kernel(GeomDev g, T* nd, T* xi, T* temp,
+                                                           T* pf, T* ts, T* vy,
+                                                           double* ff_raw, double* areas_raw) {
+  const int64_t n = (int64_t)g.nx * g.ny * g.nz;
+  const int64_t i = (int64_t)blockIdx.x * kFB + threadIdx.x;
+  if (i >= n) return;
+  const int iz = (int)(i % g.nz);
+  const int iy = (int)((i / g.nz) % g.ny);
+  const int ix = (int)(i / ((int64_t)g.nz * g.ny));
+  // classes.py:497-499: bottom-left-front corner
+  const double x0 = g.cs * (ix - g.nx / 2), y0 = g.cs * (iy - g.ny / 2),
+               z0 = g.cs * (iz - g.nz / 2);
+
+  int n_in = 0;
+#pragma unroll
+  for (int v = 0; v < 8; ++v) {
+    const double dx = (v & 1) ? g.cs : 0.0, dy = (v & 2) ? g.cs : 0.0,
+                 dz = (v & 4) ? g.cs : 0.0;
+    double r, w, xa, ya;
+    xyz_to_rw(g, x0 + dx, y0 + dy, z0 + dz, r, w, xa, ya);
+    const double wr = g.w_0 * pow(rho_mod(g, r), g.eps);            // geometry.py:118
+    if (wr >= w && fabs(r) >= g.r_0) ++n_in;                       // classes.py:665
+  }
+  const double nan = __builtin_nan("");
+  const double ff = n_in == 8 ? 1.0 : (n_in > 0 ? 0.5 : nan);
+  const double ar = n_in > 0 ? 1.0 : nan;
+  if (ff_raw) ff_raw[i] = ff;
+  if (areas_raw) areas_raw[i] = ar;
+  const bool jet = n_in > 0;
+
+  // centroid coordinates (classes.py:521-525)
+  const double h = g.cs / 2.0;
+  double rr, ww, xa, ya;
+  xyz_to_rw(g, x0 + h, y0 + h, z0 + h, rr, ww, xa, ya);
+  const double ar_ = fabs(rr);
+  // classes.py:884-886 (same clamp in ion_fraction / vel / ts)
+  const double rc = (ar_ < g.r_0 && (ar_ + h) >= g.r_0) ? (g.r_0 + ar_ + h) / 2.0 : ar_;
+  // classes.py:549-555: r_eff uses |rr| (unclamped)
+  const double reff = g.R_1 + ((g.R_2 - g.R_1) * ww) / (g.w_0 * pow(rho_mod(g, ar_), g.eps));
+  const double rho_c = rho_mod(g, rc);
+
+  if (nd) {
+    double v = jet ? powerlaw(g.n_0, rho_c, reff, g.R_1, g.q_n, g.qd_n) : nan;
+    if (rr < 0) v = v * g.rb_frac;                                 // classes.py:895
+    nd[i] = (T)with_sign(v, rr < 0);
+  }
+  if (xi) xi[i] = (T)(jet ? powerlaw(g.x_0, rho_c, reff, g.R_1, g.q_x, g.qd_x) : nan);
+  if (temp) {
+    // classes.py:957-962: r converted to cm BEFORE the r_0 [au] comparison and rho()
+    const double rcm = ar_ * 149597870700.0 * 1e2;
+    const double rt = (rcm < g.r_0 && (rcm + h) >= g.r_0) ? (g.r_0 + rcm + h) / 2.0 : rcm;
+    temp[i] = (T)(jet ? powerlaw(g.T_0, rho_mod(g, rt), reff, g.R_1, g.q_T, g.qd_T) : nan);
+  }
+  if (pf) pf[i] = (T)(ff / ar);
+  if (ts && g.ts_closed_form) {
+    // geometry.py:150-178 with q^d_v == 0 (p2 = p3 = p4 = 1), in seconds
+    const double au = 149597870700.0;
+    const double rad = rc * au + g.mr0 * au - g.r_0 * au;
+    const double t_yr = (g.ts_const * pow(rad, g.ts_pow) - g.ts_base) / 31536000.0;
+    ts[i] = (T)(t_yr * 31536000.0);
+  }
+  if (vy) {
+    double out = nan;
+    if (jet) {
+      // classes.py:1056-1093
+      double vz = powerlaw(g.v_0, rho_c, reff, g.R_1, g.q_v, g.qd_v);
+      vz = vz * (rr > 0 ? 1.0 : (rr < 0 ? -1.0 : 0.0));
+      // physics.py:90 with rho(self.rr) (unclamped)
+      const double vr = sqrt(g.gm / (reff * 149597870700.0)) * pow(rho_mod(g, rr), -g.eps) / 1e3;
+      // geometry.py:292-296: phi = arcsin(y/rho), mirrored for x < 0
+      double phi = asin(ya / ww);
+      if (xa < 0) phi = -phi + 3.141592653589793;
+      const double sgn = g.ccw ? 1.0 : -1.0;
+      const double vx0 = -vr * sin(phi) * sgn;
+      const double vy0 = vr * cos(phi) * sgn;
+      // xyz_rotate(order='xy') with (90 - inc, -pa): x-rotation then y-rotation; the
+      // y-component after both is the x-rotated one
+      out = (g.ca2 * vy0 - g.sa2 * vz) + g.v_lsr;
+      (void)vx0;
+    }
+    vy[i] = (T)out;
+  }
+}
+#pragma clang fp contract(fast)
+
+}  // namespace rjp

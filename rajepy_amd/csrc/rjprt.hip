@@ -1,0 +1,354 @@
+// librjprt.so -- C-ABI entry points (include/rjprt.h) over the gfx950 kernels.
+// Single translation unit: the kernel sources are included below.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+
+#include "ff_scan.hip"
+#include "fields.hip"
+#include "rrl_scan.hip"
+
+struct rjp_ctx {
+  int device = -1;
+  std::string err;
+  // small per-call tables (channel coefficients, frequencies): a ring of pinned host
+  // staging buffers + device copies, grown on demand; the copies are ordered on the
+  // caller's stream and a slot is reused only after its readers have finished.
+  static constexpr int kSlots = 8;
+  struct Slot {
+    double* h = nullptr;
+    double* d = nullptr;
+    size_t cap = 0;               // doubles
+    hipEvent_t free_ev = nullptr; // recorded after the last kernel that reads `d`
+  } slot[kSlots];
+  int next_slot = 0;
+  int cur_slot = 0;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+};
+
+static std::string g_create_err;
+
+static int fail(rjp_ctx* ctx, int code, const char* what, hipError_t e = hipSuccess) {
+  std::string m = what;
+  if (e != hipSuccess) {
+    m += ": ";
+    m += hipGetErrorString(e);
+  }
+  if (ctx) ctx->err = m; else g_create_err = m;
+  return code;
+}
+
+#define RJP_HIP(ctx, call)                                              \
+  do {                                                                  \
+    hipError_t _e = (call);                                             \
+    if (_e != hipSuccess) return fail((ctx), RJP_ERR_HIP, #call, _e);   \
+  } while (0)
+
+static int bind(rjp_ctx* ctx) {
+  if (!ctx) return fail(nullptr, RJP_ERR_ARG, "null context");
+  hipError_t e = hipSetDevice(ctx->device);
+  if (e != hipSuccess) return fail(ctx, RJP_ERR_HIP, "hipSetDevice", e);
+  return RJP_OK;
+}
+
+// Stage up to four small host tables into one slot of the context's table ring and return
+// device pointers.  The caller records `release_tables()` after enqueueing the readers.
+static int stage_tables(rjp_ctx* ctx, hipStream_t st, const double* const* src,
+                        const size_t* len, int ntab, double** dev_out) {
+  size_t tot = 0;
+  for (int i = 0; i < ntab; ++i) tot += len[i];
+  rjp_ctx::Slot& sl = ctx->slot[ctx->next_slot];
+  ctx->cur_slot = ctx->next_slot;
+  ctx->next_slot = (ctx->next_slot + 1) % rjp_ctx::kSlots;
+  RJP_HIP(ctx, hipEventSynchronize(sl.free_ev));     // no-op unless the ring wrapped
+  if (tot > sl.cap) {
+    if (sl.h) RJP_HIP(ctx, hipHostFree(sl.h));
+    if (sl.d) RJP_HIP(ctx, hipFree(sl.d));
+    sl.h = nullptr; sl.d = nullptr; sl.cap = 0;
+    const size_t cap = tot < 4096 ? 4096 : tot * 2;
+    RJP_HIP(ctx, hipHostMalloc((void**)&sl.h, cap * sizeof(double), hipHostMallocDefault));
+    RJP_HIP(ctx, hipMalloc((void**)&sl.d, cap * sizeof(double)));
+    sl.cap = cap;
+  }
+  size_t off = 0;
+  for (int i = 0; i < ntab; ++i) {
+    if (len[i]) memcpy(sl.h + off, src[i], len[i] * sizeof(double));
+    dev_out[i] = sl.d + off;
+    off += len[i];
+  }
+  RJP_HIP(ctx, hipMemcpyAsync(sl.d, sl.h, tot * sizeof(double), hipMemcpyHostToDevice, st));
+  return RJP_OK;
+}
+
+static int release_tables(rjp_ctx* ctx, hipStream_t st) {
+  RJP_HIP(ctx, hipEventRecord(ctx->slot[ctx->cur_slot].free_ev, st));
+  return RJP_OK;
+}
+
+static int check_fields(rjp_ctx* ctx, const rjp_fields* f, bool need_vy) {
+  if (!f) return fail(ctx, RJP_ERR_ARG, "fields is NULL");
+  if (f->dtype != RJP_F32 && f->dtype != RJP_F64)
+    return fail(ctx, RJP_ERR_ARG, "fields.dtype must be RJP_F32 (4) or RJP_F64 (8)");
+  if (f->nx <= 0 || f->ny <= 0 || f->nz <= 0)
+    return fail(ctx, RJP_ERR_ARG, "grid dimensions must be positive");
+  if (!f->d_nd || !f->d_xi || !f->d_temp || !f->d_pf)
+    return fail(ctx, RJP_ERR_ARG, "fields nd/xi/temp/pf must be device pointers");
+  if (need_vy && !f->d_vy) return fail(ctx, RJP_ERR_ARG, "fields.d_vy required for RRL");
+  if (!(f->csize_au > 0.0)) return fail(ctx, RJP_ERR_ARG, "fields.csize_au must be > 0");
+  return RJP_OK;
+}
+
+static int check_bursts(rjp_ctx* ctx, const rjp_bursts* b, const rjp_fields* f) {
+  if (!b) return RJP_OK;
+  for (int j = 0; j < 2; ++j) {
+    if (b->n[j] < 0 || b->n[j] > RJP_MAX_BURSTS)
+      return fail(ctx, RJP_ERR_ARG, "bursts.n out of range [0, RJP_MAX_BURSTS]");
+    if (b->n[j] > 0 && !f->d_ts)
+      return fail(ctx, RJP_ERR_ARG, "fields.d_ts required when bursts are present");
+  }
+  return RJP_OK;
+}
+
+extern "C" {
+
+int rjp_version(void) { return RJP_VERSION; }
+
+int rjp_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+int rjp_ctx_create(int device, rjp_ctx** out) {
+  if (!out) return fail(nullptr, RJP_ERR_ARG, "out is NULL");
+  *out = nullptr;
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n <= 0)
+    return fail(nullptr, RJP_ERR_NODEVICE, "no HIP device visible", e);
+  if (device < 0 || device >= n) return fail(nullptr, RJP_ERR_ARG, "device index out of range");
+  hipDeviceProp_t prop;
+  e = hipGetDeviceProperties(&prop, device);
+  if (e != hipSuccess) return fail(nullptr, RJP_ERR_HIP, "hipGetDeviceProperties", e);
+  if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+    std::string m = std::string("librjprt is built for gfx950 only; device is ") + prop.gcnArchName;
+    return fail(nullptr, RJP_ERR_NODEVICE, m.c_str());
+  }
+  e = hipSetDevice(device);
+  if (e != hipSuccess) return fail(nullptr, RJP_ERR_HIP, "hipSetDevice", e);
+  rjp_ctx* c = new rjp_ctx();
+  c->device = device;
+  bool ok = hipEventCreate(&c->ev0) == hipSuccess && hipEventCreate(&c->ev1) == hipSuccess;
+  for (int i = 0; ok && i < rjp_ctx::kSlots; ++i)
+    ok = hipEventCreateWithFlags(&c->slot[i].free_ev, hipEventDisableTiming) == hipSuccess;
+  if (!ok) {
+    delete c;
+    return fail(nullptr, RJP_ERR_HIP, "hipEventCreate failed");
+  }
+  *out = c;
+  return RJP_OK;
+}
+
+int rjp_ctx_destroy(rjp_ctx* ctx) {
+  if (!ctx) return RJP_OK;
+  (void)hipSetDevice(ctx->device);
+  (void)hipDeviceSynchronize();
+  for (auto& sl : ctx->slot) {
+    if (sl.h) (void)hipHostFree(sl.h);
+    if (sl.d) (void)hipFree(sl.d);
+    if (sl.free_ev) (void)hipEventDestroy(sl.free_ev);
+  }
+  if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
+  if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+  delete ctx;
+  return RJP_OK;
+}
+
+const char* rjp_last_error(const rjp_ctx* ctx) {
+  return ctx ? ctx->err.c_str() : g_create_err.c_str();
+}
+
+int rjp_pack_field(rjp_ctx* ctx, const double* d_src, const double* d_den,
+                   const uint8_t* d_red, void* d_dst, int64_t n, int dtype, void* stream) {
+  if (int r = bind(ctx)) return r;
+  if (!d_src || !d_dst || n <= 0) return fail(ctx, RJP_ERR_ARG, "rjp_pack_field: bad pointers/size");
+  if (dtype != RJP_F32 && dtype != RJP_F64) return fail(ctx, RJP_ERR_ARG, "bad dtype tag");
+  RJP_HIP(ctx, rjp::pack_field_launch(d_src, d_den, d_red, d_dst, n, dtype, (hipStream_t)stream));
+  return RJP_OK;
+}
+
+size_t rjp_ff_scan_workspace(int32_t nx, int32_t ny, int32_t nz, int32_t n_epochs) {
+  if (nx <= 0 || ny <= 0 || nz <= 0) return 0;
+  return rjp::ff_scan_workspace_bytes(nx, ny, nz, n_epochs);
+}
+
+int rjp_ff_scan(rjp_ctx* ctx, const rjp_fields* fields, const rjp_bursts* bursts,
+                const double* h_epochs_s, int32_t n_epochs, int32_t gff_mode, double* d_sumA,
+                double* d_em, double* d_tavg, void* d_work, size_t work_bytes, void* stream) {
+  if (int r = bind(ctx)) return r;
+  if (int r = check_fields(ctx, fields, false)) return r;
+  if (int r = check_bursts(ctx, bursts, fields)) return r;
+  if (!h_epochs_s || n_epochs < 1) return fail(ctx, RJP_ERR_ARG, "need >= 1 epoch");
+  if (gff_mode != RJP_GFF_SCALAR && gff_mode != RJP_GFF_POWERLAW)
+    return fail(ctx, RJP_ERR_ARG, "bad gff_mode");
+  if (!d_sumA || !d_work) return fail(ctx, RJP_ERR_ARG, "d_sumA / d_work is NULL");
+  if (work_bytes < rjp::ff_scan_workspace_bytes(fields->nx, fields->ny, fields->nz, n_epochs))
+    return fail(ctx, RJP_ERR_WORKSPACE, "rjp_ff_scan: workspace smaller than rjp_ff_scan_workspace()");
+  RJP_HIP(ctx, rjp::ff_scan_launch(fields, bursts, h_epochs_s, n_epochs, gff_mode, d_sumA, d_em,
+                                   d_tavg, (double*)d_work, (hipStream_t)stream));
+  return RJP_OK;
+}
+
+int rjp_time_ff_scan(rjp_ctx* ctx, const rjp_fields* fields, const rjp_bursts* bursts,
+                     const double* h_epochs_s, int32_t n_epochs, int32_t gff_mode,
+                     double* d_sumA, double* d_em, double* d_tavg, void* d_work,
+                     size_t work_bytes, void* stream, int32_t reps, double* ms_avg) {
+  if (!ms_avg || reps < 1) return fail(ctx, RJP_ERR_ARG, "rjp_time_ff_scan: bad reps/ms_avg");
+  if (int r = bind(ctx)) return r;
+  hipStream_t st = (hipStream_t)stream;
+  RJP_HIP(ctx, hipEventRecord(ctx->ev0, st));
+  for (int i = 0; i < reps; ++i) {
+    int r = rjp_ff_scan(ctx, fields, bursts, h_epochs_s, n_epochs, gff_mode, d_sumA, d_em,
+                        d_tavg, d_work, work_bytes, stream);
+    if (r != RJP_OK) return r;
+  }
+  RJP_HIP(ctx, hipEventRecord(ctx->ev1, st));
+  RJP_HIP(ctx, hipEventSynchronize(ctx->ev1));
+  float ms = 0.f;
+  RJP_HIP(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+  *ms_avg = (double)ms / reps;
+  return RJP_OK;
+}
+
+size_t rjp_ff_maps_workspace(int64_t n_pix, int32_t n_epochs, int32_t n_chan) {
+  if (n_pix <= 0 || n_epochs <= 0 || n_chan <= 0) return 0;
+  return rjp::ff_maps_workspace_bytes(n_pix, n_epochs, n_chan);
+}
+
+int rjp_ff_maps(rjp_ctx* ctx, const double* d_sumA, const double* d_tavg, int64_t n_pix,
+                int32_t n_epochs, const double* h_ctau, const double* h_cflux, int32_t n_chan,
+                double* d_tau, double* d_flux, double* d_ftot, void* d_work, size_t work_bytes,
+                void* stream) {
+  if (int r = bind(ctx)) return r;
+  if (!d_sumA || !d_tavg || !h_ctau || !h_cflux)
+    return fail(ctx, RJP_ERR_ARG, "rjp_ff_maps: NULL input");
+  if (n_pix <= 0 || n_epochs <= 0 || n_chan <= 0)
+    return fail(ctx, RJP_ERR_ARG, "rjp_ff_maps: sizes must be positive");
+  if (d_ftot && (!d_work || work_bytes < rjp::ff_maps_workspace_bytes(n_pix, n_epochs, n_chan)))
+    return fail(ctx, RJP_ERR_WORKSPACE, "rjp_ff_maps: workspace smaller than rjp_ff_maps_workspace()");
+  hipStream_t st = (hipStream_t)stream;
+  const double* src[2] = {h_ctau, h_cflux};
+  const size_t len[2] = {(size_t)n_chan, (size_t)n_chan};
+  double* dev[2];
+  if (int r = stage_tables(ctx, st, src, len, 2, dev)) return r;
+  RJP_HIP(ctx, rjp::ff_maps_launch(d_sumA, d_tavg, n_pix, n_epochs, dev[0], dev[1], n_chan, d_tau,
+                                   d_flux, d_ftot, (double*)d_work, st));
+  return release_tables(ctx, st);
+}
+
+int rjp_rrl_scan(rjp_ctx* ctx, const rjp_fields* fields, const rjp_bursts* bursts,
+                 double time_s, const rjp_line* line, const double* h_nu, int32_t n_chan,
+                 double* d_tau_rrl, void* stream) {
+  if (int r = bind(ctx)) return r;
+  if (int r = check_fields(ctx, fields, true)) return r;
+  if (int r = check_bursts(ctx, bursts, fields)) return r;
+  if (!line || !h_nu || n_chan < 1 || !d_tau_rrl)
+    return fail(ctx, RJP_ERR_ARG, "rjp_rrl_scan: NULL line / nu / output or n_chan < 1");
+  hipStream_t st = (hipStream_t)stream;
+  const double* src[1] = {h_nu};
+  const size_t len[1] = {(size_t)n_chan};
+  double* dev[1];
+  if (int r = stage_tables(ctx, st, src, len, 1, dev)) return r;
+  RJP_HIP(ctx, rjp::rrl_scan_launch(fields, bursts, time_s, line, h_nu, dev[0], n_chan,
+                                    d_tau_rrl, st));
+  return release_tables(ctx, st);
+}
+
+int rjp_rrl_maps(rjp_ctx* ctx, const double* d_tau_rrl, const double* d_tau_ff,
+                 const double* d_tavg, const double* d_flux_ff, int64_t n_pix,
+                 const double* h_cflux_rrl, const double* h_hnu_k, int32_t n_chan,
+                 double* d_flux, double* d_ftot, void* d_work, size_t work_bytes, void* stream) {
+  if (int r = bind(ctx)) return r;
+  if (!d_tau_rrl || !d_tau_ff || !d_tavg || !h_cflux_rrl || !h_hnu_k)
+    return fail(ctx, RJP_ERR_ARG, "rjp_rrl_maps: NULL input");
+  if (n_pix <= 0 || n_chan <= 0) return fail(ctx, RJP_ERR_ARG, "rjp_rrl_maps: sizes must be positive");
+  if (d_ftot && (!d_work || work_bytes < rjp::ff_maps_workspace_bytes(n_pix, 1, n_chan)))
+    return fail(ctx, RJP_ERR_WORKSPACE, "rjp_rrl_maps: workspace too small");
+  hipStream_t st = (hipStream_t)stream;
+  const double* src[2] = {h_cflux_rrl, h_hnu_k};
+  const size_t len[2] = {(size_t)n_chan, (size_t)n_chan};
+  double* dev[2];
+  if (int r = stage_tables(ctx, st, src, len, 2, dev)) return r;
+  RJP_HIP(ctx, rjp::rrl_maps_launch(d_tau_rrl, d_tau_ff, d_tavg, d_flux_ff, n_pix, dev[0], dev[1],
+                                    n_chan, d_flux, d_ftot, (double*)d_work, st));
+  return release_tables(ctx, st);
+}
+
+int rjp_build_fields(rjp_ctx* ctx, const rjp_geometry* gm, int dtype, void* d_nd, void* d_xi,
+                     void* d_temp, void* d_pf, void* d_ts, void* d_vy, double* d_ff_raw,
+                     double* d_areas_raw, void* stream) {
+  if (int r = bind(ctx)) return r;
+  if (!gm) return fail(ctx, RJP_ERR_ARG, "geometry is NULL");
+  if (dtype != RJP_F32 && dtype != RJP_F64) return fail(ctx, RJP_ERR_ARG, "bad dtype tag");
+  if (gm->nx <= 0 || gm->ny <= 0 || gm->nz <= 0 || !(gm->csize > 0))
+    return fail(ctx, RJP_ERR_ARG, "bad grid in geometry");
+  if (d_ts && gm->qd_v != 0.0)
+    return fail(ctx, RJP_ERR_ARG,
+                "rjp_build_fields: launch times need 2F1 when q^d_v != 0; pass d_ts = NULL "
+                "and upload ts computed by the host (rajepy_amd.maths.geometry.t_rw)");
+  const double au = 149597870700.0, d2r = M_PI / 180.0;
+  rjp::GeomDev g;
+  g.nx = gm->nx; g.ny = gm->ny; g.nz = gm->nz; g.ccw = gm->rotation_ccw;
+  g.cs = gm->csize;
+  // numpy.radians(x) = x * (pi/180); cos/sin in libm double, as maths/geometry.py:249-253
+  const double a = (gm->inc - 90.) * d2r, b = gm->pa * d2r;
+  g.ca = cos(a); g.sa = sin(a); g.cb = cos(b); g.sb = sin(b);
+  const double a2 = (90. - gm->inc) * d2r, b2 = -gm->pa * d2r;
+  g.ca2 = cos(a2); g.sa2 = sin(a2); g.cb2 = cos(b2); g.sb2 = sin(b2);
+  g.w_0 = gm->w_0; g.r_0 = gm->r_0; g.mr0 = gm->mod_r_0; g.eps = gm->epsilon;
+  g.R_1 = gm->R_1; g.R_2 = gm->R_2;
+  g.gm = 6.6743e-11 * gm->M_star * 1.98847e30;
+  g.v_lsr = gm->v_lsr;
+  g.n_0 = gm->n_0; g.x_0 = gm->x_0; g.T_0 = gm->T_0; g.v_0 = gm->v_0;
+  g.q_n = gm->q_n; g.q_x = gm->q_x; g.q_T = gm->q_T; g.q_v = gm->q_v;
+  g.qd_n = gm->qd_n; g.qd_x = gm->qd_x; g.qd_T = gm->qd_T; g.qd_v = gm->qd_v;
+  g.rb_frac = gm->rb_frac;
+  g.ts_closed_form = d_ts != nullptr;
+  {
+    // geometry.py:150-156 with q^d_v = 0
+    const double mr0 = gm->mod_r_0 * au, r0 = gm->r_0 * au, v0 = gm->v_0 * 1e3;
+    g.ts_pow = 1. - gm->q_v;
+    g.ts_const = pow(mr0, gm->q_v) / (v0 * (1. - gm->q_v + gm->epsilon * 0.0));
+    g.ts_base = g.ts_const * pow(r0 + mr0 - r0, g.ts_pow);
+  }
+  const int64_t n = (int64_t)g.nx * g.ny * g.nz;
+  const unsigned blocks = (unsigned)((n + rjp::kFB - 1) / rjp::kFB);
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == RJP_F64)
+    hipLaunchKernelGGL(rjp::build_fields_kernel<double>, dim3(blocks), dim3(rjp::kFB), 0, st, g,
+                       (double*)d_nd, (double*)d_xi, (double*)d_temp, (double*)d_pf,
+                       (double*)d_ts, (double*)d_vy, d_ff_raw, d_areas_raw);
+  else
+    hipLaunchKernelGGL(rjp::build_fields_kernel<float>, dim3(blocks), dim3(rjp::kFB), 0, st, g,
+                       (float*)d_nd, (float*)d_xi, (float*)d_temp, (float*)d_pf, (float*)d_ts,
+                       (float*)d_vy, d_ff_raw, d_areas_raw);
+  RJP_HIP(ctx, hipGetLastError());
+  return RJP_OK;
+}
+
+int rjp_synth_fields(rjp_ctx* ctx, uint64_t seed, int32_t temp_mode, int32_t nz, int64_t cell0,
+                     int64_t n, int dtype, void* d_nd, void* d_xi, void* d_temp, void* d_pf,
+                     void* d_ts, void* d_vy, void* stream) {
+  if (int r = bind(ctx)) return r;
+  if (n <= 0 || nz <= 0 || cell0 < 0) return fail(ctx, RJP_ERR_ARG, "rjp_synth_fields: bad range");
+  if (dtype != RJP_F32 && dtype != RJP_F64) return fail(ctx, RJP_ERR_ARG, "bad dtype tag");
+  RJP_HIP(ctx, rjp::synth_launch(seed, temp_mode, nz, cell0, n, dtype, d_nd, d_xi, d_temp, d_pf,
+                                 d_ts, d_vy, (hipStream_t)stream));
+  return RJP_OK;
+}
+
+}  // extern "C"

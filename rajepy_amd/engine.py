@@ -1,0 +1,320 @@
+"""Device engine: owns the librjprt context of one GPU and the device-resident model fields.
+
+PyTorch (ROCm) is used for device memory, streams and (elsewhere) torch.distributed only; all
+arithmetic on the RT path happens inside librjprt's HIP kernels.  Nothing here falls back to
+the CPU: without a GPU or without the built library, construction raises.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _constants as con
+from . import _lib
+from ._lib import RJP_F32, RJP_F64, RJP_GFF_POWERLAW, RJP_GFF_SCALAR  # noqa: F401
+
+
+def _torch():
+    import torch
+    return torch
+
+
+class DeviceFields:
+    """The packed per-cell state in HBM (include/rjprt.h `rjp_fields`)."""
+
+    def __init__(self, shape, dtype, csize_au, nd, xi, temp, pf, ts=None, vy=None,
+                 ff_raw=None, areas_raw=None):
+        self.shape = tuple(int(s) for s in shape)
+        self.dtype = int(dtype)
+        self.csize_au = float(csize_au)
+        self.nd, self.xi, self.temp, self.pf, self.ts, self.vy = nd, xi, temp, pf, ts, vy
+        self.ff_raw, self.areas_raw = ff_raw, areas_raw
+
+    @property
+    def ncells(self):
+        return self.shape[0] * self.shape[1] * self.shape[2]
+
+    @property
+    def npix(self):
+        return self.shape[0] * self.shape[2]
+
+    def struct(self):
+        f = _lib.Fields()
+        f.d_nd, f.d_xi, f.d_temp, f.d_pf = (t.data_ptr() for t in
+                                            (self.nd, self.xi, self.temp, self.pf))
+        f.d_ts = self.ts.data_ptr() if self.ts is not None else None
+        f.d_vy = self.vy.data_ptr() if self.vy is not None else None
+        f.nx, f.ny, f.nz = self.shape
+        f.dtype = self.dtype
+        f.csize_au = self.csize_au
+        return f
+
+    def nbytes(self, rrl=False):
+        n = 5 + (1 if rrl else 0)
+        return n * self.ncells * self.dtype
+
+
+def make_bursts(red, blue):
+    """Build an rjp_bursts from per-jet lists of (t0_s, amp_rel, sigma_s)
+    (classes.py:442-448: sigma = half_life * 2 / (2 sqrt(2 ln 2)))."""
+    b = _lib.Bursts()
+    for j, lst in enumerate((red, blue)):
+        if len(lst) > _lib.RJP_MAX_BURSTS:
+            raise ValueError("at most %d bursts per jet are supported" % _lib.RJP_MAX_BURSTS)
+        b.n[j] = len(lst)
+        for i, (t0, amp_rel, sigma) in enumerate(lst):
+            b.t0[j][i] = float(t0)
+            b.amp_rel[j][i] = float(amp_rel)
+            b.inv2s2[j][i] = 1.0 / (2.0 * float(sigma) ** 2.0)
+    return b
+
+
+class RTEngine:
+    """One per process/rank: binds to `cuda:<device>`."""
+
+    def __init__(self, device=0):
+        torch = _torch()
+        self.lib = _lib.load()
+        if not torch.cuda.is_available():
+            raise _lib.RjprtError("no GPU visible to PyTorch: rajepy_amd needs an MI355X "
+                                  "(there is no CPU fallback)")
+        self.device_index = int(device)
+        self.device = torch.device("cuda", self.device_index)
+        torch.cuda.set_device(self.device)
+        ctx = C.c_void_p()
+        _lib.check(self.lib.rjp_ctx_create(self.device_index, C.byref(ctx)), None,
+                   "rjp_ctx_create")
+        self.ctx = ctx
+        self._work = None
+
+    def close(self):
+        if getattr(self, "ctx", None):
+            self.lib.rjp_ctx_destroy(self.ctx)
+            self.ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- helpers ---------------------------------------------------------------------------
+    def _stream(self):
+        return C.c_void_p(_torch().cuda.current_stream(self.device).cuda_stream)
+
+    def _empty(self, n, dtype):
+        torch = _torch()
+        td = {RJP_F32: torch.float32, RJP_F64: torch.float64}[dtype]
+        return torch.empty(int(n), dtype=td, device=self.device)
+
+    def _f64(self, *shape):
+        torch = _torch()
+        return torch.empty(*shape, dtype=torch.float64, device=self.device)
+
+    def _workspace(self, nbytes):
+        torch = _torch()
+        if self._work is None or self._work.numel() < nbytes:
+            self._work = torch.empty(int(nbytes), dtype=torch.uint8, device=self.device)
+        return self._work
+
+    def synchronize(self):
+        _torch().cuda.synchronize(self.device)
+
+    # -- field producers ---------------------------------------------------------------------
+    def upload_fields(self, nd, xi, temp, ff, areas, ts, red, vy=None, csize_au=1.0,
+                      dtype=RJP_F64):
+        """Host float64 grids (reference layout, classes.py:216-227) -> packed device state.
+        `red` is a boolean grid (rr < 0)."""
+        torch = _torch()
+        shape = np.shape(nd)
+        n = int(np.prod(shape))
+        st = self._stream()
+
+        def up(a):
+            return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64).ravel()).to(
+                self.device)
+
+        def pack(src, den=None, redt=None):
+            dst = self._empty(n, dtype)
+            _lib.check(self.lib.rjp_pack_field(
+                self.ctx, src.data_ptr(), den.data_ptr() if den is not None else None,
+                redt.data_ptr() if redt is not None else None, dst.data_ptr(), n, dtype, st),
+                self.ctx, "rjp_pack_field")
+            return dst
+
+        red_t = torch.from_numpy(np.ascontiguousarray(red, dtype=np.uint8).ravel()).to(
+            self.device)
+        d_nd = pack(up(nd), None, red_t)
+        d_xi = pack(up(xi))
+        d_t = pack(up(temp))
+        d_pf = pack(up(ff), up(areas))
+        d_ts = pack(up(ts)) if ts is not None else None
+        d_vy = pack(up(vy)) if vy is not None else None
+        self.synchronize()
+        return DeviceFields(shape, dtype, csize_au, d_nd, d_xi, d_t, d_pf, d_ts, d_vy)
+
+    def replace_field(self, fields, name, host_array):
+        """Re-upload one plain field (the reference's public setters: ts, ion_fraction,
+        temperature; classes.py:857-859, 938-940, 998-1000)."""
+        torch = _torch()
+        assert name in ("xi", "temp", "ts", "vy")
+        src = torch.from_numpy(np.ascontiguousarray(host_array, dtype=np.float64).ravel()).to(
+            self.device)
+        if src.numel() != fields.ncells:
+            raise ValueError("grid shape mismatch")
+        dst = self._empty(fields.ncells, fields.dtype)
+        _lib.check(self.lib.rjp_pack_field(self.ctx, src.data_ptr(), None, None,
+                                           dst.data_ptr(), fields.ncells, fields.dtype,
+                                           self._stream()), self.ctx, "rjp_pack_field")
+        self.synchronize()
+        setattr(fields, name, dst)
+
+    def build_fields(self, geom, dtype=RJP_F64, want_ts=True, want_vy=True, want_raw=True):
+        """K4: geometry -> packed fields on the device (`geom` is a _lib.Geometry)."""
+        n = geom.nx * geom.ny * geom.nz
+        nd, xi, temp, pf = (self._empty(n, dtype) for _ in range(4))
+        ts = self._empty(n, dtype) if want_ts else None
+        vy = self._empty(n, dtype) if want_vy else None
+        ffr = self._f64(n) if want_raw else None
+        arr = self._f64(n) if want_raw else None
+        _lib.check(self.lib.rjp_build_fields(
+            self.ctx, C.byref(geom), dtype, nd.data_ptr(), xi.data_ptr(), temp.data_ptr(),
+            pf.data_ptr(), ts.data_ptr() if want_ts else None,
+            vy.data_ptr() if want_vy else None, ffr.data_ptr() if want_raw else None,
+            arr.data_ptr() if want_raw else None, self._stream()), self.ctx,
+            "rjp_build_fields")
+        return DeviceFields((geom.nx, geom.ny, geom.nz), dtype, geom.csize, nd, xi, temp, pf,
+                            ts, vy, ffr, arr)
+
+    def synth_fields(self, shape, seed, temp_mode=0, dtype=RJP_F64, csize_au=0.5,
+                     with_vy=False, cell0=0):
+        """Measurement harness: dense synthetic fields generated on the device
+        (SURVEY.md 8(d)); `shape` may be a sub-block starting at flat cell `cell0` of a
+        grid whose z-extent is shape[2]."""
+        nx, ny, nz = shape
+        n = nx * ny * nz
+        nd, xi, temp, pf, ts = (self._empty(n, dtype) for _ in range(5))
+        vy = self._empty(n, dtype) if with_vy else None
+        _lib.check(self.lib.rjp_synth_fields(
+            self.ctx, int(seed), int(temp_mode), int(nz), int(cell0), int(n), dtype,
+            nd.data_ptr(), xi.data_ptr(), temp.data_ptr(), pf.data_ptr(), ts.data_ptr(),
+            vy.data_ptr() if with_vy else None, self._stream()), self.ctx,
+            "rjp_synth_fields")
+        return DeviceFields(shape, dtype, csize_au, nd, xi, temp, pf, ts, vy)
+
+    # -- K1 / K2 -----------------------------------------------------------------------------
+    def ff_scan(self, fields, bursts, epochs_s, gff_mode, want_em=True, out=None):
+        """-> (sumA[E,P], em[E,P] or None, tavg[P]) device tensors (float64)."""
+        E = len(epochs_s)
+        P = fields.npix
+        nx, ny, nz = fields.shape
+        if out is None:
+            sumA = self._f64(E, P)
+            em = self._f64(E, P) if want_em else None
+            tavg = self._f64(P)
+        else:
+            sumA, em, tavg = out
+        wb = self.lib.rjp_ff_scan_workspace(nx, ny, nz, E)
+        work = self._workspace(wb)
+        fs = fields.struct()
+        ep = _lib.dbl_array(epochs_s)
+        _lib.check(self.lib.rjp_ff_scan(
+            self.ctx, C.byref(fs), C.byref(bursts) if bursts is not None else None, ep, E,
+            int(gff_mode), sumA.data_ptr(), em.data_ptr() if em is not None else None,
+            tavg.data_ptr(), work.data_ptr(), work.numel(), self._stream()), self.ctx,
+            "rjp_ff_scan")
+        return sumA, em, tavg
+
+    def time_ff_scan(self, fields, bursts, epochs_s, gff_mode, reps=5):
+        """Average device time [ms] of one rjp_ff_scan (HIP events on the launch stream)."""
+        E = len(epochs_s)
+        P = fields.npix
+        nx, ny, nz = fields.shape
+        sumA, em, tavg = self._f64(E, P), self._f64(E, P), self._f64(P)
+        wb = self.lib.rjp_ff_scan_workspace(nx, ny, nz, E)
+        work = self._workspace(wb)
+        fs = fields.struct()
+        ep = _lib.dbl_array(epochs_s)
+        ms = C.c_double()
+        _lib.check(self.lib.rjp_time_ff_scan(
+            self.ctx, C.byref(fs), C.byref(bursts) if bursts is not None else None, ep, E,
+            int(gff_mode), sumA.data_ptr(), em.data_ptr(), tavg.data_ptr(), work.data_ptr(),
+            work.numel(), self._stream(), int(reps), C.byref(ms)), self.ctx,
+            "rjp_time_ff_scan")
+        return ms.value
+
+    def ff_maps(self, sumA, tavg, ctau, cflux, want_tau=True, want_flux=True,
+                want_ftot=True, out=None):
+        """-> (tau[E,F,P], flux[E,F,P], ftot[E,F]) device tensors (None where not wanted)."""
+        E, P = sumA.shape
+        F = len(ctau)
+        if out is None:
+            tau = self._f64(E, F, P) if want_tau else None
+            flux = self._f64(E, F, P) if want_flux else None
+            ftot = self._f64(E, F) if want_ftot else None
+        else:
+            tau, flux, ftot = out
+        wb = self.lib.rjp_ff_maps_workspace(P, E, F)
+        work = self._workspace(wb) if ftot is not None else None
+        a, b = _lib.dbl_array(ctau), _lib.dbl_array(cflux)
+        ptr = lambda t: t.data_ptr() if t is not None else None
+        _lib.check(self.lib.rjp_ff_maps(
+            self.ctx, sumA.data_ptr(), tavg.data_ptr(), P, E, a, b, F, ptr(tau), ptr(flux),
+            ptr(ftot), ptr(work), work.numel() if work is not None else 0, self._stream()),
+            self.ctx, "rjp_ff_maps")
+        return tau, flux, ftot
+
+    # -- K3 ------------------------------------------------------------------------------------
+    def rrl_scan(self, fields, bursts, time_s, line, nus):
+        """-> tau_rrl[F,P] device tensor."""
+        F = len(nus)
+        tau = self._f64(F, fields.npix)
+        fs = fields.struct()
+        nu = _lib.dbl_array(nus)
+        _lib.check(self.lib.rjp_rrl_scan(
+            self.ctx, C.byref(fs), C.byref(bursts) if bursts is not None else None,
+            float(time_s), C.byref(line), nu, F, tau.data_ptr(), self._stream()), self.ctx,
+            "rjp_rrl_scan")
+        return tau
+
+    def rrl_maps(self, tau_rrl, tau_ff, tavg, flux_ff, cflux_rrl, hnu_k, want_ftot=True):
+        """-> (flux[F,P], ftot[F])."""
+        F, P = tau_rrl.shape
+        flux = self._f64(F, P)
+        ftot = self._f64(F) if want_ftot else None
+        wb = self.lib.rjp_ff_maps_workspace(P, 1, F)
+        work = self._workspace(wb) if want_ftot else None
+        a, b = _lib.dbl_array(cflux_rrl), _lib.dbl_array(hnu_k)
+        ptr = lambda t: t.data_ptr() if t is not None else None
+        _lib.check(self.lib.rjp_rrl_maps(
+            self.ctx, tau_rrl.data_ptr(), tau_ff.data_ptr(), tavg.data_ptr(), ptr(flux_ff), P,
+            a, b, F, flux.data_ptr(), ptr(ftot), ptr(work),
+            work.numel() if work is not None else 0, self._stream()), self.ctx,
+            "rjp_rrl_maps")
+        return flux, ftot
+
+
+# -- host-side per-channel coefficients (scalars; classes.py:1395-1397, 1473-1475, 1519-1521) --
+def solid_angle(csize_au, dist_pc):
+    return np.arctan((csize_au * con.au) / (dist_pc * con.parsec)) ** 2.
+
+
+def ff_channel_coeffs(freqs, csize_au, dist_pc, gff_mode, gff_values=None):
+    """ctau[f], cflux[f] of include/rjprt.h `rjp_ff_maps`."""
+    freqs = np.atleast_1d(np.asarray(freqs, dtype=np.float64))
+    path0 = csize_au * con.au * 1e2
+    if gff_mode == RJP_GFF_SCALAR:
+        g = np.asarray(gff_values, dtype=np.float64)
+        ctau = 0.018 * freqs ** -2. * path0 * g
+    else:
+        ctau = 0.018 * freqs ** -2. * path0 * (11.95 * freqs ** -0.1)
+    cflux = 2. * freqs ** 2. * con.k / con.c ** 2. * solid_angle(csize_au, dist_pc) / 1e-26
+    return ctau, cflux
+
+
+def rrl_channel_coeffs(freqs, csize_au, dist_pc):
+    """cflux_rrl[f], hnu_k[f] of `rjp_rrl_maps` (physics.py:571-574; rrls.py:444-449)."""
+    freqs = np.atleast_1d(np.asarray(freqs, dtype=np.float64))
+    p1 = 2. * con.h * 1e7 * freqs ** 3. / (con.c * 1e2) ** 2.
+    cflux = p1 * 1e-7 * 1e4 * solid_angle(csize_au, dist_pc) / 1e-26
+    hnu_k = con.h * 1e7 * freqs / (con.k * 1e7)
+    return cflux, hnu_k

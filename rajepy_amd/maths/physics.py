@@ -1,0 +1,117 @@
+"""Scalar physics helpers (reference: maths/physics.py).  Host side only -- one value per
+channel or per model, never per cell."""
+import functools
+import os
+import warnings
+
+import numpy as np
+
+from .. import _constants as con
+
+_FILES = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "files")
+
+
+def q_n(epsilon, q_v):
+    """Density index along the jet from mass conservation (physics.py:17-36)."""
+    return -q_v - 2.0 * epsilon
+
+
+def q_tau(epsilon, q_x, q_n_, q_T):
+    """Optical-depth index along the jet (physics.py:39-63)."""
+    return epsilon + 2.0 * q_x + 2.0 * q_n_ - 1.35 * q_T
+
+
+def atomic_mass(atom):
+    """Mass [kg] of the isotope the reference uses for `atom` (physics.py:607-624)."""
+    return con.ATOMIC_MASS_MICRO_U[atom] * (1e-6 * con.u)
+
+
+def z_number(atom):
+    """physics.py:523-532."""
+    return con.NZ[atom][0]
+
+
+def rydberg_constant(atom):
+    """Finite-mass Rydberg constant [1/m] (physics.py:535-544)."""
+    m = atomic_mass(atom)
+    return con.Rydberg * (m / (m + con.m_e))
+
+
+def doppler_shift(nu_0, v_lsr):
+    """physics.py:547-558; v in km/s."""
+    return nu_0 * (1. - v_lsr * 1000. / con.c)
+
+
+def blackbody_nu(freq, temp):
+    """Planck function in cgs (physics.py:561-574)."""
+    x = con.h * 1e7 * freq / (con.k * 1e7 * temp)
+    return (2. * con.h * 1e7 * freq ** 3. / (con.c * 1e2) ** 2.) / (np.exp(x) - 1.)
+
+
+def _mlr_shape(q_nd, q_nv, R_1, R_2):
+    a = q_nd + q_nv
+    if a == -1. or a == -2.:
+        a *= 1. + 1e-12                      # physics.py:442-444, 507-509
+    r1, r2 = R_1 * con.au, R_2 * con.au
+    return ((r1 ** 2. + r2 * (r2 * (a + 1.) - r1 * (a + 2.)) * (r2 / r1) ** a) /
+            ((r2 - r1) ** 2. * (a + 1.) * (a + 2.)))
+
+
+def n_0_from_mlr(mlr, v_0, w_0, mu, q_nd, q_nv, R_1, R_2):
+    """Axis density at the jet base [cm^-3] for a mass-loss rate [Msol/yr]
+    (physics.py:474-517)."""
+    k = 2. * np.pi * (mu * atomic_mass('H')) * (v_0 * 1e3) * (w_0 * con.au) ** 2.
+    return mlr * con.MSOL / con.year / k / _mlr_shape(q_nd, q_nv, R_1, R_2) / 1e6
+
+
+def mlr_from_n_0(n_0, v_0, w_0, mu, q_nd, q_nv, R_1, R_2):
+    """Inverse of n_0_from_mlr (physics.py:413-471)."""
+    k = 2. * np.pi * (mu * atomic_mass('H')) * (n_0 * 1e6) * (v_0 * 1e3) * \
+        (w_0 * con.au) ** 2.
+    return k * _mlr_shape(q_nd, q_nv, R_1, R_2) / con.MSOL * con.year
+
+
+@functools.lru_cache(maxsize=1)
+def import_vanHoof2014():
+    """van Hoof et al. (2014) thermally averaged Gaunt factors: (log gamma^2 axis,
+    log u axis, table[146, 81]).  Parsed once (the reference re-reads the file per call,
+    physics.py:626-663)."""
+    with open(os.path.join(_FILES, "vanHoofetal2014.data"), "rt") as f:
+        lines = f.readlines()
+    lg2_0 = float(lines[30].split('#')[0])
+    lu_0 = float(lines[31].split('#')[0])
+    step = float(lines[32].split('#')[0])
+    table = np.array([[float(v) for v in ln.split()] for ln in lines[42:188]])
+    n_u, n_g = table.shape
+    lus = np.linspace(np.round(lu_0, 1), np.round(lu_0 + step * (n_u - 1), 1), n_u)
+    lg2s = np.linspace(np.round(lg2_0, 1), np.round(lg2_0 + step * (n_g - 1), 1), n_g)
+    return lg2s, lus, table
+
+
+def gff(freq, temp, z=1.):
+    """Free-free Gaunt factor at one (frequency, temperature) (physics.py:666-698).
+
+    The reference interpolates the 5x5 table window nearest to (log gamma^2, log u) with
+    scipy's interp2d(kind='cubic') on scattered points, i.e. FITPACK surfit through
+    bisplrep(kx=ky=3, s=0) + bisplev; the same two FITPACK calls are made here.  The row
+    clamp deliberately reproduces physics.py:687-690 (it clamps against 81, not 146)."""
+    from scipy.interpolate import bisplev, bisplrep
+    ry = con.m_e * con.e ** 4. / (8 * con.epsilon_0 ** 2. * con.h ** 2.)
+    lg2 = np.log10(z ** 2. * ry / (con.k * temp))
+    lu = np.log10(con.h * freq / (con.k * temp))
+    lg2s, lus, table = import_vanHoof2014()
+    col = int(np.argmin(np.abs(lg2s - lg2)))
+    row = int(np.argmin(np.abs(lus - lu)))
+    col = min(max(col, 2), len(lg2s) - 3)
+    row = min(max(row, 2), len(lg2s) - 3)
+    gx, gy = np.meshgrid(lg2s[col - 2:col + 3], lus[row - 2:row + 3])
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        tck = bisplrep(gx.ravel(), gy.ravel(), table[row - 2:row + 3, col - 2:col + 3].ravel(),
+                       kx=3, ky=3, s=0.0)
+    return float(bisplev(lg2, lu, tck))
+
+
+def v_rot(r, reff, rho, epsilon, m_star):
+    """Rotation speed [km/s] (physics.py:66-90)."""
+    return np.sqrt(con.G * m_star * con.MSOL / (reff * con.au)) * rho ** -epsilon / 1e3

@@ -1,0 +1,172 @@
+"""Multi-GPU sharding of the RT sweep: one process per GPU, `torch.distributed` over RCCL
+(backend "nccl" on ROCm) for the single gather at the end; no collective on the data path.
+
+The path shards along three independent axes with no halo:
+  * epochs    -- every epoch is a genuine pass over the grid (chi(t) enters as n^2); the grid
+                 is replicated (built per rank on its own GPU), only flux-vs-time vectors or
+                 map blocks are gathered.  This is the axis that carries real work.
+  * channels  -- the north star's "frequency-sharded sweep".  Continuum channels share one
+                 grid pass, so channel sharding splits only the map stage (K2); RRL channels
+                 are real per-channel work (K3) and do scale.
+  * x-slabs   -- sightlines are independent: each rank scans n_x/N of the grid.
+
+The planners are pure Python; the gathers work with any backend (tests run them under
+`gloo` on CPU tensors with world_size 2).
+"""
+import numpy as np
+
+
+def _split(n, world):
+    """Contiguous near-equal split of range(n): list of (start, stop)."""
+    base, extra = divmod(n, world)
+    out, s = [], 0
+    for r in range(world):
+        e = s + base + (1 if r < extra else 0)
+        out.append((s, e))
+        s = e
+    return out
+
+
+class Shards:
+    """Contiguous block partition of a 1-D list of work items over `world` ranks."""
+
+    def __init__(self, items, world):
+        self.items = np.asarray(items)
+        self.world = int(world)
+        if self.world < 1:
+            raise ValueError("world must be >= 1")
+        self.bounds = _split(len(self.items), self.world)
+
+    def __len__(self):
+        return len(self.items)
+
+    def slice(self, rank):
+        s, e = self.bounds[rank]
+        return slice(s, e)
+
+    def local(self, rank):
+        return self.items[self.slice(rank)]
+
+    def counts(self):
+        return [e - s for s, e in self.bounds]
+
+
+class EpochShards(Shards):
+    """Model times [s] split over ranks."""
+
+    @property
+    def n_epochs(self):
+        return len(self.items)
+
+
+class ChannelShards(Shards):
+    """Channel frequencies [Hz] split over ranks."""
+
+
+class SlabShards(Shards):
+    """x-rows of the grid split over ranks (each rank scans rows [x0, x1))."""
+
+    def __init__(self, nx, world):
+        super().__init__(np.arange(nx), world)
+
+
+def _dist():
+    import torch.distributed as dist
+    return dist
+
+
+def all_gather_blocks(local, shards, rank, axis=0, group=None):
+    """Gather per-rank blocks of unequal leading size along `axis` to every rank.
+
+    `local` has size shards.counts()[rank] along `axis`.  Blocks are padded to the largest
+    count so a single fixed-size all_gather suffices (one collective per sweep)."""
+    import torch
+    dist = _dist()
+    counts = shards.counts()
+    if local.shape[axis] != counts[rank]:
+        raise ValueError("local block has %d items on axis %d, plan says %d"
+                         % (local.shape[axis], axis, counts[rank]))
+    if shards.world == 1:
+        return local
+    loc = local.movedim(axis, 0).contiguous()
+    cmax = max(counts)
+    if loc.shape[0] < cmax:
+        pad = torch.zeros((cmax - loc.shape[0],) + tuple(loc.shape[1:]), dtype=loc.dtype,
+                          device=loc.device)
+        loc = torch.cat([loc, pad], dim=0)
+    out = [torch.empty_like(loc) for _ in range(shards.world)]
+    dist.all_gather(out, loc, group=group)
+    full = torch.cat([o[:c] for o, c in zip(out, counts)], dim=0)
+    return full.movedim(0, axis)
+
+
+def gather_flux_vs_time(ftot_local, shards, rank, group=None):
+    """[E_local, F] per-channel total fluxes of this rank's epochs -> [E_total, F] on every
+    rank (2 KB-scale messages: latency-bound, one all_gather)."""
+    return all_gather_blocks(ftot_local, shards, rank, axis=0, group=group)
+
+
+def gather_to_root(local, shards, rank, axis=0, root=0, group=None):
+    """Gather map blocks (channel blocks or x-slabs) onto `root` only; other ranks get None.
+    The root ingests (world-1)/world of the product over its xGMI links."""
+    import torch
+    dist = _dist()
+    counts = shards.counts()
+    if shards.world == 1:
+        return local
+    loc = local.movedim(axis, 0).contiguous()
+    cmax = max(counts)
+    if loc.shape[0] < cmax:
+        pad = torch.zeros((cmax - loc.shape[0],) + tuple(loc.shape[1:]), dtype=loc.dtype,
+                          device=loc.device)
+        loc = torch.cat([loc, pad], dim=0)
+    bufs = [torch.empty_like(loc) for _ in range(shards.world)] if rank == root else None
+    dist.gather(loc, bufs, dst=root, group=group)
+    if rank != root:
+        return None
+    full = torch.cat([b[:c] for b, c in zip(bufs, counts)], dim=0)
+    return full.movedim(0, axis)
+
+
+def sweep_flux_vs_time(model, epochs_s, freqs, rank=0, world=1, group=None):
+    """Epoch-sharded continuum sweep through the JetModel API: every rank scans its epochs
+    (eight per pass over HBM), reduces each (epoch, channel) map to its total flux on the
+    device and the [E, F] light curves are all_gathered.  Returns a host array [E, F] [Jy]."""
+    from . import engine as E
+    from .maths import physics as mphys
+    shards = EpochShards(epochs_s, world)
+    mine = [float(t) for t in shards.local(rank)]
+    freqs = np.atleast_1d(np.asarray(freqs, dtype=np.float64))
+    eng = model.engine
+    dev = model.device_fields
+    gv = None
+    if model.gff_mode == E.RJP_GFF_SCALAR:
+        gv = [mphys.gff(nu, model.params['properties']['T_0']) for nu in freqs]
+    ctau, cflux = E.ff_channel_coeffs(freqs, model.csize, model.params["target"]["dist"],
+                                      model.gff_mode, gv)
+    if mine:
+        sumA, _, tavg = eng.ff_scan(dev, model._rjp_bursts(), mine, model.gff_mode,
+                                    want_em=False)
+        _, _, ftot = eng.ff_maps(sumA, tavg, ctau, cflux, want_tau=False, want_flux=False,
+                                 want_ftot=True)
+    else:
+        ftot = eng._f64(0, len(freqs))
+    full = gather_flux_vs_time(ftot, shards, rank, group=group)
+    return full.cpu().numpy()
+
+
+def sweep_channel_sharded(model, freqs, rank=0, world=1, root=0, group=None, kind="flux"):
+    """The north star's frequency-sharded continuum sweep at the model's current time: every
+    rank performs the (shared) grid scan and the map stage for ITS channels; channel blocks
+    are gathered on `root`.  Returns (F, n_x, n_z) on root, None elsewhere."""
+    shards = ChannelShards(np.atleast_1d(np.asarray(freqs, dtype=np.float64)), world)
+    mine = shards.local(rank)
+    import torch
+    if len(mine):
+        block = model._ff_products(mine, tau=(kind == "tau"), flux=(kind == "flux"),
+                                   device=True)
+    else:
+        block = torch.empty((0, model.nx, model.nz), dtype=torch.float64,
+                            device=model.engine.device)
+    full = gather_to_root(block, shards, rank, axis=0, root=root, group=group)
+    return None if full is None else full.cpu().numpy()

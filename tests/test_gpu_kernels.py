@@ -1,0 +1,216 @@
+"""GPU parity tests proper: every librjprt kernel, called through the C-ABI, against the CPU
+oracle and the committed golden vectors.  Run with `pytest -m gpu` on an MI355X."""
+import copy
+
+import numpy as np
+import pytest
+
+from tests import gpu_util as U
+from oracle import rt_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-5          # north-star parity bar; most checks below are far tighter
+
+
+@pytest.fixture(scope="module")
+def eng():
+    from rajepy_amd.engine import RTEngine
+    e = RTEngine(0)
+    yield e
+    e.close()
+
+
+def _upload(eng, g, csize, dtype):
+    return eng.upload_fields(g["nd"], g["xi"], g["temp"], g["ff"], g["areas"], g["ts"],
+                             g["rr"] < 0, g["vy"], csize_au=csize, dtype=dtype)
+
+
+def _run_ff(eng, fields, bursts, jet, years, freqs):
+    from rajepy_amd import engine as E
+    from rajepy_amd.maths import physics as ph
+    p = jet.params
+    mode = E.RJP_GFF_SCALAR if p["power_laws"]["q_T"] == 0. else E.RJP_GFF_POWERLAW
+    g = [ph.gff(nu, p["properties"]["T_0"]) for nu in freqs] if mode == E.RJP_GFF_SCALAR else None
+    ctau, cflux = E.ff_channel_coeffs(freqs, jet.csize, p["target"]["dist"], mode, g)
+    sumA, em, tavg = eng.ff_scan(fields, bursts, [y * orc.YEAR for y in years], mode)
+    tau, flux, ftot = eng.ff_maps(sumA, tavg, ctau, cflux)
+    eng.synchronize()
+    shp = (len(years), len(freqs), jet.nx, jet.nz)
+    return (em.cpu().numpy().reshape(len(years), jet.nx, jet.nz),
+            tau.cpu().numpy().reshape(shp), flux.cpu().numpy().reshape(shp),
+            ftot.cpu().numpy(), tavg.cpu().numpy().reshape(jet.nx, jet.nz))
+
+
+@pytest.mark.parametrize("tag", ["cfg1_example", "tilted"])
+@pytest.mark.parametrize("dtype", [8, 4])
+def test_ff_against_reference_golden(eng, tag, dtype):
+    """K1+K2 on the reference's own fields vs the reference's own maps (tau, flux, EM) at
+    every golden epoch and frequency."""
+    z, meta, p, g, jet = U.golden_dense(tag)
+    fields = _upload(eng, g, jet.csize, dtype)
+    em, tau, flux, ftot, _ = _run_ff(eng, fields, U.bursts_from_oracle(jet), jet,
+                                     z["years"], z["freqs"])
+    tol = 1e-11 if dtype == 8 else RTOL
+    np.testing.assert_allclose(em, z["em"], rtol=tol)
+    np.testing.assert_allclose(tau, z["tau_ff"], rtol=tol)
+    assert np.array_equal(np.isnan(flux), np.isnan(z["flux_ff"]))       # NaN pattern
+    assert np.array_equal(tau == 0.0, z["tau_ff"] == 0.0)               # empty sightlines
+    np.testing.assert_allclose(flux, z["flux_ff"], rtol=max(tol, 1e-10))
+    np.testing.assert_allclose(ftot, np.nansum(z["flux_ff"], axis=(2, 3)), rtol=max(tol, 1e-10))
+
+
+@pytest.mark.parametrize("temp_mode", [0, 1])
+@pytest.mark.parametrize("dtype", [8, 4])
+@pytest.mark.parametrize("shape", [(6, 37, 10), (4, 64, 128), (3, 50, 7)])
+def test_ff_dense_synthetic_vs_oracle(eng, shape, dtype, temp_mode):
+    """Dense synthetic fields (device generator) vs the oracle on the host restatement of the
+    same hash; exercises odd n_y tails, the scalar (VEC=1) path (n_z=7) and y-splitting."""
+    seed = 20240501
+    fields = eng.synth_fields(shape, seed, temp_mode, dtype, csize_au=0.5, with_vy=True)
+    g = U.synth_host(shape, seed, temp_mode)
+    if dtype == 8:    # generator itself must be bit-identical to the host restatement
+        eng.synchronize()
+        for name, ref in (("xi", g["xi"]), ("temp", g["temp"]), ("pf", g["ff"]),
+                          ("vy", g["vy"]), ("ts", g["ts"])):
+            got = getattr(fields, name).cpu().numpy().reshape(shape)
+            np.testing.assert_allclose(got, ref, rtol=1e-15, err_msg=name)
+        nd = fields.nd.cpu().numpy().reshape(shape)
+        np.testing.assert_allclose(np.abs(nd), g["nd"], rtol=1e-13)
+        assert np.array_equal(np.signbit(nd), g["rr"] < 0)
+    p = copy.deepcopy(U.load_golden("cfg1_example")[2])
+    p["ejection"] = U.example_bursts_params()
+    p["power_laws"]["q_T"] = 0. if temp_mode == 0 else -0.5
+    p["grid"].update(n_x=shape[0], n_y=shape[1], n_z=shape[2])
+    jet = orc.OracleJet.from_fields(p, g["nd"], g["xi"], g["temp"], g["ff"], g["areas"],
+                                    g["ts"], g["rr"], g["vy"])
+    years, freqs = [0., 0.6, 1.1, 2.0, 2.7], [1e9, 5e9, 5e10]
+    em, tau, flux, ftot, tavg = _run_ff(eng, fields, U.bursts_from_oracle(jet), jet, years,
+                                        freqs)
+    tol = 1e-11 if dtype == 8 else RTOL
+    for e, yr in enumerate(years):
+        jet.time = yr * orc.YEAR
+        np.testing.assert_allclose(em[e], jet.emission_measure(), rtol=tol)
+        np.testing.assert_allclose(tau[e], jet.optical_depth_ff(np.array(freqs)), rtol=tol)
+        np.testing.assert_allclose(flux[e], jet.flux_ff(np.array(freqs)), rtol=max(tol, 1e-10))
+
+
+def test_ff_nan_semantics(eng):
+    """NumPy's per-product NaN masks: tau skips a cell if ANY of
+    n, x, T, ff, areas is NaN; EM ignores T; T_avg counts a cell iff T > 0."""
+    rng = np.random.default_rng(7)
+    shape = (4, 23, 8)
+    g = U.synth_host(shape, 99, 1)
+    for k in ("nd", "xi", "temp", "ff", "areas"):
+        m = rng.random(shape) < 0.15
+        g[k] = np.where(m, np.nan, g[k])
+    g["temp"][rng.random(shape) < 0.05] = -5.0          # not counted by T > 0, tau -> NaN term
+    g["nd"][0, :, 0] = np.nan                           # an empty sightline
+    g["temp"][1, :, 1] = np.nan                         # EM finite, tau = 0, flux NaN
+    p = copy.deepcopy(U.load_golden("cfg1_example")[2])
+    p["power_laws"]["q_T"] = -0.5
+    p["grid"].update(n_x=shape[0], n_y=shape[1], n_z=shape[2])
+    jet = orc.OracleJet.from_fields(p, g["nd"], g["xi"], g["temp"], g["ff"], g["areas"],
+                                    g["ts"], g["rr"], g["vy"])
+    fields = _upload(eng, g, jet.csize, 8)
+    em, tau, flux, ftot, tavg = _run_ff(eng, fields, U.bursts_from_oracle(jet), jet, [0.7],
+                                        [5e9])
+    jet.time = 0.7 * orc.YEAR
+    np.testing.assert_allclose(em[0], jet.emission_measure(), rtol=1e-11)
+    ref_tau = jet.optical_depth_ff(5e9)
+    np.testing.assert_allclose(tau[0, 0], ref_tau, rtol=1e-11)
+    ref_flux = jet.flux_ff(5e9)
+    assert np.array_equal(np.isnan(flux[0, 0]), np.isnan(ref_flux))
+    np.testing.assert_allclose(flux[0, 0], ref_flux, rtol=1e-10)
+    assert tau[0, 0][0, 0] == 0.0 and em[0][0, 0] == 0.0 and np.isnan(flux[0, 0][0, 0])
+    assert tau[0, 0][1, 1] == 0.0 and em[0][1, 1] > 0.0 and np.isnan(flux[0, 0][1, 1])
+
+
+@pytest.mark.parametrize("tag", ["cfg1_example", "tilted"])
+@pytest.mark.parametrize("dtype", [8, 4])
+def test_rrl_against_reference_golden(eng, tag, dtype):
+    """K3 + map stage vs the reference's RRL optical depths and fluxes (scipy wofz)."""
+    from rajepy_amd import _lib, engine as E
+    from rajepy_amd.maths import physics as ph, rrls
+    z, meta, p, g, jet = U.golden_dense(tag)
+    fields = _upload(eng, g, jet.csize, dtype)
+    bursts = U.bursts_from_oracle(jet)
+    rf = z["rrl_freqs"]
+    line = _lib.Line(**rrls.line_constants(meta["rrl"]))
+    t0 = z["years"][0] * orc.YEAR
+    tau_rrl = eng.rrl_scan(fields, bursts, t0, line, rf)
+    mode = E.RJP_GFF_SCALAR if p["power_laws"]["q_T"] == 0. else E.RJP_GFF_POWERLAW
+    gv = [ph.gff(nu, p["properties"]["T_0"]) for nu in rf] if mode == E.RJP_GFF_SCALAR else None
+    ctau, cflux = E.ff_channel_coeffs(rf, jet.csize, p["target"]["dist"], mode, gv)
+    sumA, em, tavg = eng.ff_scan(fields, bursts, [t0], mode)
+    tau_ff, flux_ff, _ = eng.ff_maps(sumA, tavg, ctau, cflux)
+    cfl, hnu = E.rrl_channel_coeffs(rf, jet.csize, p["target"]["dist"])
+    F = len(rf)
+    P = jet.nx * jet.nz
+    f_sub, _ = eng.rrl_maps(tau_rrl, tau_ff.reshape(F, P), tavg, None, cfl, hnu)
+    f_tot, ftot = eng.rrl_maps(tau_rrl, tau_ff.reshape(F, P), tavg, flux_ff.reshape(F, P), cfl, hnu)
+    eng.synchronize()
+    shp = (F, jet.nx, jet.nz)
+    tol = 1e-9 if dtype == 8 else RTOL
+    np.testing.assert_allclose(tau_rrl.cpu().numpy().reshape(shp), z["tau_rrl"], rtol=tol)
+    got = f_sub.cpu().numpy().reshape(shp)
+    assert np.array_equal(np.isnan(got), np.isnan(z["flux_rrl_contsub"]))
+    np.testing.assert_allclose(got, z["flux_rrl_contsub"], rtol=tol)
+    np.testing.assert_allclose(f_tot.cpu().numpy().reshape(shp), z["flux_rrl_total"], rtol=tol)
+    np.testing.assert_allclose(ftot.cpu().numpy(), np.nansum(z["flux_rrl_total"], axis=(1, 2)),
+                               rtol=tol)
+
+
+@pytest.mark.parametrize("nchan", [1, 5, 40, 300])
+def test_rrl_dense_synthetic_vs_oracle(eng, nchan):
+    """Dense synthetic cells, every channel-lane layout (16/64/256 lanes, >1 channel block),
+    wide band so the far-field continued fraction, the core and the pole term are all hit."""
+    from rajepy_amd import _lib
+    from rajepy_amd.maths import rrls
+    shape = (2, 19, 21)
+    seed = 20240503
+    fields = eng.synth_fields(shape, seed, 1, 8, csize_au=0.5, with_vy=True)
+    g = U.synth_host(shape, seed, 1)
+    p = copy.deepcopy(U.load_golden("cfg1_example")[2])
+    p["ejection"] = U.example_bursts_params()
+    p["power_laws"]["q_T"] = -0.5
+    p["grid"].update(n_x=shape[0], n_y=shape[1], n_z=shape[2])
+    jet = orc.OracleJet.from_fields(p, g["nd"], g["xi"], g["temp"], g["ff"], g["areas"],
+                                    g["ts"], g["rr"], g["vy"])
+    jet.time = 1.3 * orc.YEAR
+    nu0 = rrls.rrl_nu_0("H", 66, 1)
+    rf = orc.chan_freqs(nu0, nchan * 1.5e5 if nchan > 1 else 1.0, 1.5e5 if nchan > 1 else 1.0)
+    assert len(rf) == nchan
+    line = _lib.Line(**rrls.line_constants("H66a"))
+    tau = eng.rrl_scan(fields, U.bursts_from_oracle(jet), jet.time, line, rf)
+    eng.synchronize()
+    ref = jet.optical_depth_rrl("H66a", np.asarray(rf))
+    np.testing.assert_allclose(tau.cpu().numpy().reshape(ref.shape), ref, rtol=1e-9)
+
+
+@pytest.mark.parametrize("tag", ["cfg1_example", "tilted"])
+def test_field_builder_vs_reference(eng, tag):
+    """K4: geometry -> fields on the device vs the reference's own grids."""
+    from rajepy_amd.classes import geometry_struct
+    z, meta, p = U.load_golden(tag)
+    jet = orc.OracleJet(p)                      # derived params (mod_r_0, q_n, n_0 ...)
+    geom = geometry_struct(jet.params, jet.nx, jet.ny, jet.nz)
+    closed = jet.params["power_laws"]["q^d_v"] == 0.
+    f = eng.build_fields(geom, 8, want_ts=closed)
+    eng.synchronize()
+    idx = z["f_idx"]
+    ff = f.ff_raw.cpu().numpy()
+    assert np.array_equal(np.flatnonzero(np.isfinite(ff)), idx)          # identical jet mask
+    assert np.array_equal(ff[idx], z["f_ff"])
+    assert np.array_equal(f.areas_raw.cpu().numpy()[idx], z["f_areas"])
+    nd = f.nd.cpu().numpy()
+    np.testing.assert_allclose(np.abs(nd[idx]), z["f_nd"], rtol=1e-12)
+    assert np.array_equal(np.signbit(nd[idx]), z["f_rr"] < 0)
+    assert not np.isfinite(np.delete(nd, idx)).any()
+    for name, key in (("xi", "xi"), ("temp", "temp"), ("vy", "vy")):
+        got = getattr(f, name).cpu().numpy()
+        np.testing.assert_allclose(got[idx], z["f_" + key], rtol=1e-11, atol=1e-12, err_msg=name)
+        assert not np.isfinite(np.delete(got, idx)).any()
+    np.testing.assert_allclose(f.pf.cpu().numpy()[idx], z["f_ff"] / z["f_areas"], rtol=0)
+    if closed:
+        np.testing.assert_allclose(f.ts.cpu().numpy()[idx], z["f_ts0"], rtol=1e-11, atol=1e-3)
