@@ -33,10 +33,13 @@ HBM_PEAK_GBS = 8000.0            # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 YEAR = 31536000.0
 
 CONFIGS = {
-    # name: (shape, n_chan) -- BASELINE.json configs[1] and configs[3]
-    "cfg4": ((512, 4096, 512), 256),
-    "cfg2": ((256, 1024, 256), 32),
-    "tiny": ((16, 64, 64), 8),
+    # name: (shape, n_chan, n_epochs_total or None, kind) -- BASELINE.json configs[1..4]
+    "cfg4": ((512, 4096, 512), 256, None, "continuum"),   # headline: metric's configuration
+    "cfg2": ((256, 1024, 256), 32, None, "continuum"),
+    "cfg5": ((512, 4096, 512), 64, 32, "continuum"),      # 64 ch x 32 epochs, epoch-fused passes
+    "cfg3": ((512, 2048, 512), 256, None, "rrl"),         # H66a cube, LTE
+    "tiny": ((16, 64, 64), 8, None, "continuum"),
+    "tiny_rrl": ((8, 64, 64), 40, None, "rrl"),
 }
 
 
@@ -54,37 +57,52 @@ def parse():
     return ap.parse_args()
 
 
-def cpu_baseline(shape, freqs, seed, target_s):
-    """The CPU oracle (oracle/rt_oracle.py, a literal NumPy restatement of the reference's
-    per-channel re-streaming path) timed on a y-truncated block with the same n_x, n_z and a
-    subset of the same channels: what Pipeline.execute issues per run, optical_depth_ff +
-    flux_ff (classes.py:2411, 2423).  Single process: NumPy elementwise work uses one core."""
+def _oracle_jet(sub, seed):
     from oracle import rt_oracle as orc
     from tests import gpu_util as U
-    nx, ny, nz = shape
-    nyb = 8
-    nch = 4
-    # ~0.2-0.35 us per cell-channel for the tau+flux pair on one core
-    while nx * nyb * 2 * nz * nch * 0.3e-6 < target_s and nyb * 2 <= ny:
-        nyb *= 2
-    sub = (nx, nyb, nz)
     g = U.synth_host(sub, seed, 0)
     p = U.load_golden("cfg1_example")[2]
     p["ejection"] = U.example_bursts_params()
-    p["grid"].update(n_x=nx, n_y=nyb, n_z=nz)
+    p["grid"].update(n_x=sub[0], n_y=sub[1], n_z=sub[2])
     jet = orc.OracleJet.from_fields(p, g["nd"], g["xi"], g["temp"], g["ff"], g["areas"],
                                     g["ts"], g["rr"], g["vy"])
     jet.time = 1.0 * YEAR
+    return jet
+
+
+def cpu_baseline(shape, freqs, seed, target_s, rrl=None):
+    """The CPU oracle (oracle/rt_oracle.py, a literal NumPy restatement of the reference's
+    per-channel re-streaming path) timed on a y-truncated block with the same n_x, n_z and a
+    subset of the same channels: what Pipeline.execute issues per run -- optical_depth_ff +
+    flux_ff (classes.py:2411, 2423), or optical_depth_rrl + flux_rrl(contsub=False)
+    (classes.py:2437, 2450).  Single process: NumPy elementwise work uses one core.  The
+    block is sized from a short calibration run so the sample costs about `target_s`."""
+    nx, ny, nz = shape
+    nch = 4
     sel = np.asarray(freqs)[np.linspace(0, len(freqs) - 1, nch).astype(int)]
-    t0 = time.perf_counter()
-    jet.optical_depth_ff(sel)
-    jet.flux_ff(sel)
-    dt = time.perf_counter() - t0
+
+    def run(jet):
+        t0 = time.perf_counter()
+        if rrl:
+            jet.optical_depth_rrl(rrl, sel)
+            jet.flux_rrl(rrl, sel, contsub=False)
+        else:
+            jet.optical_depth_ff(sel)
+            jet.flux_ff(sel)
+        return time.perf_counter() - t0
+
+    nyb, dt = 2, 0.0
+    for _ in range(4):                       # grow the block until it costs ~target_s
+        dt = run(_oracle_jet((nx, nyb, nz), seed))
+        if dt >= 0.6 * target_s or nyb >= ny:
+            break
+        nyb = int(min(ny, max(nyb + 1, nyb * min(target_s / dt, 64.0))))
     ncell = nx * nyb * nz
+    what = "optical_depth_rrl+flux_rrl(contsub=False)" if rrl else "optical_depth_ff+flux_ff"
     return {"value": ncell * nch / dt / 1e6, "unit": "Mvoxel-freq/s", "cores": 1,
             "kind": "port",
-            "sample": "oracle optical_depth_ff+flux_ff on a %dx%dx%d y-truncated block of the "
-                      "same synthetic grid x %d of the channels (%.1f s)" % (nx, nyb, nz, nch, dt)}
+            "sample": "oracle %s on a %dx%dx%d y-truncated block of the same synthetic grid x "
+                      "%d of the channels (%.1f s)" % (what, nx, nyb, nz, nch, dt)}
 
 
 def main():
@@ -100,8 +118,8 @@ def main():
 
     import torch
     import torch.distributed as dist
-    from rajepy_amd import engine as E
-    from rajepy_amd.maths import physics as ph
+    from rajepy_amd import _lib, engine as E
+    from rajepy_amd.maths import physics as ph, rrls
     from rajepy_amd.parallel import EpochShards, gather_flux_vs_time
     from tests import gpu_util as U            # burst parameters of the example model
 
@@ -111,44 +129,63 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world,
                                 device_id=torch.device("cuda", local))
     eng = E.RTEngine(local)
-    shape, nchan = CONFIGS[args.config]
+    shape, nchan, n_ep_cfg, kind = CONFIGS[args.config]
     dtype = E.RJP_F64 if args.storage == "f64" else E.RJP_F32
     seed = 20240504
     ncell = shape[0] * shape[1] * shape[2]
     P = shape[0] * shape[2]
+    rrl = kind == "rrl"
 
-    fields = eng.synth_fields(shape, seed, 0, dtype, csize_au=0.5)
+    fields = eng.synth_fields(shape, seed, 0, dtype, csize_au=0.5, with_vy=rrl)
     ej = U.example_bursts_params()
-    ss = 1.0
     red, blue = [], []
     for t0, hl, chi, which in zip(ej["t_0"], ej["hl"], ej["chi"], ej["which"]):
         sig = hl * YEAR * 2. / (2. * np.sqrt(2. * np.log(2.)))
         for jet, lst in (("R", red), ("B", blue)):
             if jet in str(which):
-                lst.append((t0 * YEAR, (ss * chi - ss) / ss, sig))
+                lst.append((t0 * YEAR, chi - 1., sig))
     bursts = E.make_bursts(red, blue)
 
-    freqs = np.geomspace(1e9, 5e10, nchan)
+    if rrl:
+        line_c = rrls.line_constants("H66a")
+        line = _lib.Line(**line_c)
+        freqs = line_c["nu_rest"] - nchan * 1e5 / 2. + 1e5 / 2. + np.arange(nchan) * 1e5
+        cfl_rrl, hnu_k = E.rrl_channel_coeffs(freqs, 0.5, 120.)
+    else:
+        freqs = np.geomspace(1e9, 5e10, nchan)
     gv = [ph.gff(nu, 1e4) for nu in freqs]
     ctau, cflux = E.ff_channel_coeffs(freqs, 0.5, 120., E.RJP_GFF_SCALAR, gv)
 
-    # epochs: one per rank per step (weak scaling over the burst-time sweep)
-    epochs = np.linspace(0., 5., world) * YEAR if world > 1 else np.array([1.0 * YEAR])
+    # epochs: cfg5 = its 32 epochs split over the ranks; otherwise one epoch per rank per
+    # step (weak scaling over the burst-time sweep)
+    if n_ep_cfg:
+        epochs = np.linspace(0., 5., n_ep_cfg) * YEAR
+    else:
+        epochs = np.linspace(0., 5., world) * YEAR if world > 1 else np.array([1.0 * YEAR])
     shards = EpochShards(epochs, world)
-    my_epochs = shards.local(rank)
+    my_epochs = [float(t) for t in shards.local(rank)]
     E_loc = len(my_epochs)
 
     sumA = eng._f64(E_loc, P)
     em = eng._f64(E_loc, P)
     tavg = eng._f64(P)
-    tau = eng._f64(E_loc, nchan, P)
-    flux = eng._f64(E_loc, nchan, P)
     ftot = eng._f64(E_loc, nchan)
+    if n_ep_cfg:
+        tau = flux = None                   # flux-vs-time output: maps reduced on the device
+    else:
+        tau = eng._f64(E_loc, nchan, P)
+        flux = eng._f64(E_loc, nchan, P)
 
     def step():
         eng.ff_scan(fields, bursts, my_epochs, E.RJP_GFF_SCALAR, out=(sumA, em, tavg))
         eng.ff_maps(sumA, tavg, ctau, cflux, out=(tau, flux, ftot))
-        return gather_flux_vs_time(ftot, shards, rank) if world > 1 else ftot
+        res = ftot
+        if rrl:
+            tau_rrl = eng.rrl_scan(fields, bursts, my_epochs[0], line, freqs)
+            _, res = eng.rrl_maps(tau_rrl, tau.reshape(nchan, P), tavg, flux.reshape(nchan, P),
+                                  cfl_rrl, hnu_k)
+            res = res.reshape(1, nchan)
+        return gather_flux_vs_time(res, shards, rank) if world > 1 else res
 
     def fence():
         if world > 1:
@@ -171,37 +208,57 @@ def main():
     total_epochs = shards.n_epochs
     value = ncell * nchan * total_epochs / (ms_step * 1e-3) / 1e6
 
-    # dominant kernel: K1 (ff_scan).  Live HIP-event timing on the launch stream.
-    k1_ms = eng.time_ff_scan(fields, bursts, my_epochs, E.RJP_GFF_SCALAR, reps=5)
-    alg_bytes = 5 * ncell * int(dtype) * 1 + E_loc * P * 2 * 8      # fields in, base maps out
-    achieved = alg_bytes / (k1_ms * 1e-3) / 1e9
+    # dominant kernel, timed live with HIP events on the launch stream
+    if rrl:
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
+        for _ in range(2):
+            eng.rrl_scan(fields, bursts, my_epochs[0], line, freqs)
+        ev1.record()
+        torch.cuda.synchronize()
+        k_ms = ev0.elapsed_time(ev1) / 2
+        # K3 is vector-ALU bound by construction (SURVEY.md finding 3): report its HBM rate
+        # against the HBM peak anyway and the Voigt-evaluation rate beside it
+        alg_bytes = 6 * ncell * int(dtype) + nchan * P * 8
+        kname, extra = "rrl_scan_kernel", {"voigt_evals_per_s": ncell * nchan / (k_ms * 1e-3)}
+    else:
+        k_ms = eng.time_ff_scan(fields, bursts, my_epochs, E.RJP_GFF_SCALAR, reps=5)
+        npass = -(-E_loc // 8) if E_loc > 1 else 1        # epoch tiles of <= 8 share a pass
+        alg_bytes = npass * 5 * ncell * int(dtype) + E_loc * P * 2 * 8
+        kname, extra = "ff_scan_kernel", {"grid_passes_per_launch": npass}
+    achieved = alg_bytes / (k_ms * 1e-3) / 1e9
     traffic = None
-    pmc = os.path.join(ROOT, "profiles", "r01_ff_scan_pmc.json")
+    pmc = os.path.join(ROOT, "profiles", "r01_%s_%s_pmc.json" % (args.config, args.storage))
     if os.path.exists(pmc):
         try:
-            rec = json.load(open(pmc))
-            if rec.get("config") == args.config and rec.get("storage") == args.storage:
-                traffic = rec.get("hbm_bytes_per_launch")
+            traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
         except Exception:
             traffic = None
-    roofline = {"bound": "hbm", "kernel": "ff_scan_kernel", "achieved": achieved,
+    roofline = {"bound": "hbm", "kernel": kname, "achieved": achieved,
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                "traffic": traffic, "ms_per_launch": k1_ms, "algorithmic_bytes": alg_bytes}
+                "traffic": traffic, "ms_per_launch": k_ms, "algorithmic_bytes": alg_bytes}
+    roofline.update(extra)
 
     result = {
         "metric": "Mvoxel-freq/s", "value": value, "unit": "Mvoxel-freq/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": ms_step, "higher_is_better": True, "scaling": "weak",
+        "ms_per_step": ms_step, "higher_is_better": True,
+        "scaling": "strong" if n_ep_cfg else "weak",
         "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-        "config": {"workload": "%s: %dx%dx%d grid x %d continuum channels 1-50 GHz, %d epoch(s) "
-                               "per step (one per GPU), K1 scan + K2 tau/flux cubes"
-                               % ((args.config,) + shape + (nchan, total_epochs)),
+        "config": {"workload": "%s: %dx%dx%d grid x %d %s, %d epoch(s) per step, %s"
+                               % ((args.config,) + shape + (
+                                   nchan, "H66a channels of 100 kHz" if rrl else
+                                   "continuum channels 1-50 GHz", total_epochs,
+                                   "K3 RRL scan + K1/K2 continuum + line flux cube" if rrl else
+                                   "K1 scan + K2 flux-vs-time" if n_ep_cfg else
+                                   "K1 scan + K2 tau/flux cubes")),
                    "storage": args.storage, "sharding": "epochs" if world > 1 else "none",
                    "gather": "all_gather of flux-vs-time [E,F]" if world > 1 else "none"},
         "roofline": roofline,
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        result["cpu_baseline"] = cpu_baseline(shape, freqs, seed, args.cpu_seconds)
+        result["cpu_baseline"] = cpu_baseline(shape, freqs, seed, args.cpu_seconds,
+                                              rrl="H66a" if rrl else None)
     if rank == 0:
         chk = float(out.sum().item())
         result["checksum_flux_total_jy"] = chk

@@ -8,7 +8,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "librjprt.so")
+# RJP_LIB overrides the library path (A/B runs of experimental builds; never a CPU path)
+LIB_PATH = os.environ.get("RJP_LIB") or os.path.join(_HERE, "librjprt.so")
 
 RJP_F32, RJP_F64 = 4, 8
 RJP_GFF_SCALAR, RJP_GFF_POWERLAW = 0, 1

@@ -37,6 +37,73 @@ __host__ __device__ constexpr int unroll_for(int vec, int et) {
 // number of accumulator planes a tile of ET epochs writes per y-split
 __host__ __device__ constexpr int nacc(int et) { return 2 * et + 2; }
 
+// U rows x VEC sightlines of one lane: loads first (U*5 independent 16-B loads in flight),
+// then the burst factors of all U*VEC*ET (cell, epoch) pairs as ONE batch so their exp()
+// polynomial chains interleave (FP64 FMA latency is what limits a single chain), then the
+// accumulation.
+template <typename T, int VEC, int ET, int MODE, bool BURSTS, int U>
+__device__ __forceinline__ void scan_rows(const FieldPtrs<T>& f, int64_t off, int64_t stride,
+                                          const BurstsDev& b, const EpochTile<ET>& ep,
+                                          double (&accA)[ET][VEC], double (&accE)[ET][VEC],
+                                          double (&accT)[VEC], double (&cnt)[VEC]) {
+  double nd[U][VEC], xi[U][VEC], tp[U][VEC], pf[U][VEC], ts[U][VEC];
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const int64_t o = off + u * stride;
+    load_vec(f.nd + o, nd[u]);
+    load_vec(f.xi + o, xi[u]);
+    load_vec(f.temp + o, tp[u]);
+    load_vec(f.pf + o, pf[u]);
+    if (BURSTS) load_vec(f.ts + o, ts[u]);
+  }
+
+  constexpr int NB = ET * U * VEC;
+  double chi[NB];
+  if (BURSTS) {
+    double tl[NB];
+    bool red[NB];
+#pragma unroll
+    for (int e = 0; e < ET; ++e)
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) {
+          const int k = (e * U + u) * VEC + v;
+          tl[k] = ep.t[e] - ts[u][v];
+          red[k] = signbit_d(nd[u][v]);
+        }
+    chi_batch<NB>(b, red, tl, chi);
+  }
+
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) {
+      const double Tk = tp[u][v];
+      // temperature power: T^-1.5 (scalar Gaunt) or T^-1.35 = T^-1.5 * T^0.15 (power law)
+      double tpow = pow_m1p5(Tk);
+      if (MODE == RJP_GFF_POWERLAW) tpow *= pow(Tk, 0.15);
+      const double n0 = fabs(nd[u][v]) * xi[u][v];   // steady-state electron density
+      const double g = n0 * n0 * pf[u][v];           // (n x)^2 * ff/areas at chi = 1
+      const double a = g * tpow;
+      if (Tk > 0.0) { accT[v] += Tk; cnt[v] += 1.0; }
+      if (BURSTS) {
+#pragma unroll
+        for (int e = 0; e < ET; ++e) {
+          const double c = chi[(e * U + u) * VEC + v];
+          const double c2 = c * c;
+          const double ge = g * c2, ae = a * c2;
+          if (ge == ge) accE[e][v] += ge;            // nansum: skip NaN only (inf propagates)
+          if (ae == ae) accA[e][v] += ae;
+        }
+      } else {
+        if (g == g) accE[0][v] += g;
+        if (a == a) accA[0][v] += a;
+      }
+    }
+  }
+}
+
 template <typename T, int VEC, int ET, int MODE, bool BURSTS>
 __global__ __launch_bounds__(kBlock) void ff_scan_kernel(
     FieldPtrs<T> f, int ny, int nz, int64_t nchunks, int64_t npix, int ylen, BurstsDev b,
@@ -61,60 +128,13 @@ __global__ __launch_bounds__(kBlock) void ff_scan_kernel(
   int64_t off = (x * ny + y0) * (int64_t)nz + z;
   const int64_t stride = nz;
 
-  auto cell = [&](const double (&nd)[VEC], const double (&xi)[VEC], const double (&tp)[VEC],
-                  const double (&pf)[VEC], const double (&ts)[VEC]) {
-#pragma unroll
-    for (int v = 0; v < VEC; ++v) {
-      const double Tk = tp[v];
-      // temperature power: T^-1.5 (scalar Gaunt) or T^-1.35 = T^-1.5 * T^0.15 (power law)
-      double tpow = pow_m1p5(Tk);
-      if (MODE == RJP_GFF_POWERLAW) tpow *= pow(Tk, 0.15);
-      const double n0 = fabs(nd[v]) * xi[v];       // steady-state electron density
-      const double g = n0 * n0 * pf[v];            // (n x)^2 * ff/areas at chi = 1
-      const double a = g * tpow;
-      if (Tk > 0.0) { accT[v] += Tk; cnt[v] += 1.0; }
-      if (BURSTS) {
-        const bool red = signbit_d(nd[v]);
-#pragma unroll
-        for (int e = 0; e < ET; ++e) {
-          const double chi = chi_cell(b, red, ep.t[e] - ts[v]);
-          const double c2 = chi * chi;
-          const double ge = g * c2, ae = a * c2;
-          if (ge == ge) accE[e][v] += ge;          // nansum: skip NaN only (inf propagates)
-          if (ae == ae) accA[e][v] += ae;
-        }
-      } else {
-        if (g == g) accE[0][v] += g;
-        if (a == a) accA[0][v] += a;
-      }
-    }
-  };
-
   int y = y0;
   for (; y + kUnroll <= y1; y += kUnroll) {
-    double nd[kUnroll][VEC], xi[kUnroll][VEC], tp[kUnroll][VEC], pf[kUnroll][VEC],
-        ts[kUnroll][VEC];
-#pragma unroll
-    for (int u = 0; u < kUnroll; ++u) {
-      const int64_t o = off + u * stride;
-      load_vec(f.nd + o, nd[u]);
-      load_vec(f.xi + o, xi[u]);
-      load_vec(f.temp + o, tp[u]);
-      load_vec(f.pf + o, pf[u]);
-      if (BURSTS) load_vec(f.ts + o, ts[u]);
-    }
-#pragma unroll
-    for (int u = 0; u < kUnroll; ++u) cell(nd[u], xi[u], tp[u], pf[u], ts[u]);
+    scan_rows<T, VEC, ET, MODE, BURSTS, kUnroll>(f, off, stride, b, ep, accA, accE, accT, cnt);
     off += kUnroll * stride;
   }
   for (; y < y1; ++y) {
-    double nd[VEC], xi[VEC], tp[VEC], pf[VEC], ts[VEC];
-    load_vec(f.nd + off, nd);
-    load_vec(f.xi + off, xi);
-    load_vec(f.temp + off, tp);
-    load_vec(f.pf + off, pf);
-    if (BURSTS) load_vec(f.ts + off, ts);
-    cell(nd, xi, tp, pf, ts);
+    scan_rows<T, VEC, ET, MODE, BURSTS, 1>(f, off, stride, b, ep, accA, accE, accT, cnt);
     off += stride;
   }
 

@@ -48,6 +48,9 @@ hipError_t pack_field_launch(const double* src, const double* den, const uint8_t
 }
 
 // ---- synthetic dense fields --------------------------------------------
+// No FMA contraction from here to the end of K4: the generator must be bit-identical to its
+// host restatement, and K4's inside test must follow NumPy's operation order.
+#pragma clang fp contract(off)
 template <typename T>
 __global__ __launch_bounds__(kFB) void synth_kernel(uint64_t seed, int temp_mode, int nz,
                                                     int64_t cell0, int64_t n, T* nd, T* xi,
@@ -106,7 +109,6 @@ struct GeomDev {
   int ts_closed_form;
 };
 
-#pragma clang fp contract(off)
 __device__ __forceinline__ void xyz_to_rw(const GeomDev& g, double x, double y, double z,
                                           double& r, double& w, double& x2, double& y2) {
   // geometry.py:206 xyz_rotate(order='yx'): y-rotation first, then x-rotation

@@ -14,12 +14,25 @@ template <> struct VecOf<float> { using type = float4; static constexpr int N = 
 
 template <typename T, int V> struct Pack { double v[V]; };
 
+#ifndef RJP_NT_LOADS
+#define RJP_NT_LOADS 1   /* the fields are streamed exactly once: non-temporal loads, +5 % on cfg4 (6.1 -> 6.4 TB/s) */
+#endif
+typedef double rjp_d2 __attribute__((ext_vector_type(2)));
+typedef float rjp_f4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void load_vec(const double* __restrict__ p, double (&out)[2]) {
-  double2 t = *reinterpret_cast<const double2*>(p);
+#if RJP_NT_LOADS
+  rjp_d2 t = __builtin_nontemporal_load(reinterpret_cast<const rjp_d2*>(p));
+#else
+  rjp_d2 t = *reinterpret_cast<const rjp_d2*>(p);
+#endif
   out[0] = t.x; out[1] = t.y;
 }
 __device__ __forceinline__ void load_vec(const float* __restrict__ p, double (&out)[4]) {
-  float4 t = *reinterpret_cast<const float4*>(p);
+#if RJP_NT_LOADS
+  rjp_f4 t = __builtin_nontemporal_load(reinterpret_cast<const rjp_f4*>(p));
+#else
+  rjp_f4 t = *reinterpret_cast<const rjp_f4*>(p);
+#endif
   out[0] = (double)t.x; out[1] = (double)t.y; out[2] = (double)t.z; out[3] = (double)t.w;
 }
 __device__ __forceinline__ void load_vec(const double* __restrict__ p, double (&out)[1]) {
@@ -64,7 +77,7 @@ __device__ __forceinline__ double exp_nonpos(double x) {
   return __builtin_ldexp(p, (int)kd);
 }
 
-// chi for one jet (wave-uniform loop count; parameters come from SGPRs)
+// chi for one cell of one jet (wave-uniform loop count; parameters come from SGPRs)
 __device__ __forceinline__ double chi_jet(const BurstsDev& b, int jet, double tl) {
   double chi = 1.0;
   const int nb = b.n[jet];
@@ -77,15 +90,54 @@ __device__ __forceinline__ double chi_jet(const BurstsDev& b, int jet, double tl
 }
 
 __device__ __forceinline__ double chi_cell(const BurstsDev& b, bool red, double tl) {
-  // Both jets' loops are wave-uniform in trip count; a wave that straddles the red/blue
-  // plane executes both, every other wave exactly one.
-  double chi;
-  if (red) chi = chi_jet(b, 0, tl); else chi = chi_jet(b, 1, tl);
-  return chi;
+  return red ? chi_jet(b, 0, tl) : chi_jet(b, 1, tl);
+}
+
+// chi for a batch of NB independent (cell, epoch) pairs.  The burst loop is outermost and
+// the NB exp() evaluations inside it are independent, so their dependent FMA chains overlap.
+// A wave whose lanes all sit in one jet reads that jet's parameters from SGPRs; a wave that
+// straddles the red/blue plane selects them per lane (unused slots have amp_rel = 0).
+template <int NB>
+__device__ __forceinline__ void chi_batch(const BurstsDev& b, const bool (&red)[NB],
+                                          const double (&tl)[NB], double (&chi)[NB]) {
+  bool any_red = false, any_blue = false;
+#pragma unroll
+  for (int k = 0; k < NB; ++k) { any_red |= red[k]; any_blue |= !red[k]; }
+  const bool wave_red = __builtin_amdgcn_ballot_w64(any_red) != 0;
+  const bool wave_blue = __builtin_amdgcn_ballot_w64(any_blue) != 0;
+#pragma unroll
+  for (int k = 0; k < NB; ++k) chi[k] = 1.0;
+  if (!(wave_red && wave_blue)) {
+    const int jet = wave_red ? 0 : 1;
+    const int nb = b.n[jet];
+    for (int i = 0; i < nb; ++i) {
+      const double t0 = b.t0[jet][i], inv = b.inv2s2[jet][i], amp = b.amp_rel[jet][i];
+#pragma unroll
+      for (int k = 0; k < NB; ++k) {
+        const double d = tl[k] - t0;
+        chi[k] = __builtin_fma(amp, exp_nonpos(-(d * d) * inv), chi[k]);
+      }
+    }
+  } else {
+    const int nb = b.n[0] > b.n[1] ? b.n[0] : b.n[1];
+    for (int i = 0; i < nb; ++i) {
+#pragma unroll
+      for (int k = 0; k < NB; ++k) {
+        const double t0 = red[k] ? b.t0[0][i] : b.t0[1][i];
+        const double inv = red[k] ? b.inv2s2[0][i] : b.inv2s2[1][i];
+        const double amp = red[k] ? b.amp_rel[0][i] : b.amp_rel[1][i];
+        const double d = tl[k] - t0;
+        chi[k] = __builtin_fma(amp, exp_nonpos(-(d * d) * inv), chi[k]);
+      }
+    }
+  }
 }
 
 // T^-1.5 with an f32 rsqrt seed + one fp64 Newton step (rel. err < 1e-13); exact-ish slow
 // path outside the f32 exponent range and for T == 0 / inf / negative.
+__device__ __attribute__((noinline)) double pow_m1p5_slow(double T) {
+  return 1.0 / (T * __builtin_sqrt(T));   // NaN for T<0 or NaN, inf for 0, 0 for inf
+}
 __device__ __forceinline__ double pow_m1p5(double T) {
   if (T > 1e-30 && T < 1e30) {
     double y = (double)__builtin_amdgcn_rsqf((float)T);
@@ -93,7 +145,7 @@ __device__ __forceinline__ double pow_m1p5(double T) {
     y = y * __builtin_fma(-h * y, y, 1.5);
     return y * y * y;
   }
-  return 1.0 / (T * __builtin_sqrt(T));   // NaN for T<0 or NaN, inf for 0, 0 for inf
+  return pow_m1p5_slow(T);
 }
 
 __device__ __forceinline__ bool signbit_d(double v) {

@@ -105,7 +105,9 @@ def test_ff_nan_semantics(eng):
         m = rng.random(shape) < 0.15
         g[k] = np.where(m, np.nan, g[k])
     g["temp"][rng.random(shape) < 0.05] = -5.0          # not counted by T > 0, tau -> NaN term
-    g["nd"][0, :, 0] = np.nan                           # an empty sightline
+    g["nd"][0, :, 0] = np.nan                           # an empty sightline ...
+    g["temp"][0, :, 0] = np.nan                         # ... in every field
+    g["nd"][2, :, 3] = np.nan                           # no density but T finite: flux = 0
     g["temp"][1, :, 1] = np.nan                         # EM finite, tau = 0, flux NaN
     p = copy.deepcopy(U.load_golden("cfg1_example")[2])
     p["power_laws"]["q_T"] = -0.5
@@ -124,6 +126,7 @@ def test_ff_nan_semantics(eng):
     np.testing.assert_allclose(flux[0, 0], ref_flux, rtol=1e-10)
     assert tau[0, 0][0, 0] == 0.0 and em[0][0, 0] == 0.0 and np.isnan(flux[0, 0][0, 0])
     assert tau[0, 0][1, 1] == 0.0 and em[0][1, 1] > 0.0 and np.isnan(flux[0, 0][1, 1])
+    assert tau[0, 0][2, 3] == 0.0 and em[0][2, 3] == 0.0 and flux[0, 0][2, 3] == 0.0
 
 
 @pytest.mark.parametrize("tag", ["cfg1_example", "tilted"])

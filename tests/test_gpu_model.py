@@ -119,9 +119,13 @@ def test_main_cli(tmp_path):
     from rajepy_amd import main as cli
     model = tmp_path / "model-params.py"
     p = example_params()
-    model.write_text("import numpy as np\nparams = " + repr(
-        {k: {kk: (("np.array(%r)" % vv.tolist()) if isinstance(vv, np.ndarray) else vv)
-             for kk, vv in v.items()} for k, v in p.items()}).replace("'np.array(", "np.array(").replace(")'", ")"))
+
+    def lit(v):
+        return "np.array(%r)" % v.tolist() if isinstance(v, np.ndarray) else repr(v)
+
+    body = ",\n".join("  %r: {%s}" % (sec, ", ".join("%r: %s" % (k, lit(v)) for k, v in d.items()))
+                      for sec, d in p.items())
+    model.write_text("import numpy as np\nparams = {\n" + body + "\n}\n")
     out = tmp_path / "cli_out"
     pline = tmp_path / "pipeline-params.py"
     pline.write_text(

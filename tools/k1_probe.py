@@ -1,0 +1,33 @@
+#!/usr/bin/env python3
+"""Times K1 (rjp_ff_scan) alone on a synthetic grid: python tools/k1_probe.py cfg4 f64 [E]"""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+import bench
+from rajepy_amd import engine as E
+from tests import gpu_util as U
+
+cfg, storage = sys.argv[1], sys.argv[2]
+nep = int(sys.argv[3]) if len(sys.argv) > 3 else 1
+shape = bench.CONFIGS[cfg][0]
+eng = E.RTEngine(0)
+dtype = E.RJP_F64 if storage == "f64" else E.RJP_F32
+fields = eng.synth_fields(shape, 20240504, 0, dtype, csize_au=0.5)
+ej = U.example_bursts_params()
+red, blue = [], []
+for t0, hl, chi, which in zip(ej["t_0"], ej["hl"], ej["chi"], ej["which"]):
+    sig = hl * bench.YEAR * 2. / (2. * np.sqrt(2. * np.log(2.)))
+    for jet, lst in (("R", red), ("B", blue)):
+        if jet in str(which):
+            lst.append((t0 * bench.YEAR, chi - 1., sig))
+bursts = E.make_bursts(red, blue)
+ep = list(np.linspace(0.5, 4.5, nep) * bench.YEAR)
+eng.time_ff_scan(fields, bursts, ep, E.RJP_GFF_SCALAR, reps=2)
+ms = min(eng.time_ff_scan(fields, bursts, ep, E.RJP_GFF_SCALAR, reps=5) for _ in range(3))
+n = shape[0] * shape[1] * shape[2]
+npass = -(-nep // 8) if nep > 1 else 1
+gb = npass * 5 * n * int(dtype) / 1e9
+print("%s %s E=%d lib=%s ysplit=%s: %.3f ms  %.0f GB/s (alg)  %.3f ms/epoch" % (
+    cfg, storage, nep, os.path.basename(os.environ.get("RJP_LIB", "default")),
+    os.environ.get("RJP_YSPLIT", "auto"), ms, gb / ms * 1e3, ms / nep))
