@@ -52,6 +52,10 @@ def parse():
                     choices=sorted(CONFIGS))
     ap.add_argument("--storage", default="f64", choices=("f64", "f32"))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", choices=("nccl", "gloo"),
+                    help="gloo = rehearsal of the N>1 path (e.g. several ranks on one GPU)")
+    ap.add_argument("--share-gpu", action="store_true",
+                    help="rehearsal only: all ranks use cuda:0")
     ap.add_argument("--cpu-seconds", type=float, default=20.0,
                     help="target CPU time of the bounded cpu_baseline sample")
     return ap.parse_args()
@@ -123,11 +127,16 @@ def main():
     from rajepy_amd.parallel import EpochShards, gather_flux_vs_time
     from tests import gpu_util as U            # burst parameters of the example model
 
+    if args.share_gpu:
+        local = 0
     torch.cuda.set_device(local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world,
+                                    device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
     eng = E.RTEngine(local)
     shape, nchan, n_ep_cfg, kind = CONFIGS[args.config]
     dtype = E.RJP_F64 if args.storage == "f64" else E.RJP_F32
@@ -201,7 +210,8 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     if world > 1:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=eng.device)
+        tmax = torch.tensor([dt], dtype=torch.float64,
+                            device=eng.device if args.backend == "nccl" else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
     ms_step = dt / args.steps * 1e3

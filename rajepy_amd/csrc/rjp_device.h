@@ -77,6 +77,29 @@ __device__ __forceinline__ double exp_nonpos(double x) {
   return __builtin_ldexp(p, (int)kd);
 }
 
+// exp(x) for |x| <= 700, relative error < 1e-14 (same reduction and polynomial, no clamp)
+__device__ __forceinline__ double exp_any(double x) {
+  const double L2E = 1.4426950408889634074;
+  const double LN2_HI = 6.93147180369123816490e-01;
+  const double LN2_LO = 1.90821492927058770002e-10;
+  double kd = __builtin_rint(x * L2E);
+  double r = __builtin_fma(-kd, LN2_HI, x);
+  r = __builtin_fma(-kd, LN2_LO, r);
+  double p = 2.505210838544172e-08;
+  p = __builtin_fma(p, r, 2.755731922398589e-07);
+  p = __builtin_fma(p, r, 2.7557319223985893e-06);
+  p = __builtin_fma(p, r, 2.48015873015873e-05);
+  p = __builtin_fma(p, r, 1.984126984126984e-04);
+  p = __builtin_fma(p, r, 1.388888888888889e-03);
+  p = __builtin_fma(p, r, 8.333333333333333e-03);
+  p = __builtin_fma(p, r, 4.1666666666666664e-02);
+  p = __builtin_fma(p, r, 1.6666666666666666e-01);
+  p = __builtin_fma(p, r, 0.5);
+  p = __builtin_fma(p, r, 1.0);
+  p = __builtin_fma(p, r, 1.0);
+  return __builtin_ldexp(p, (int)kd);
+}
+
 // chi for one cell of one jet (wave-uniform loop count; parameters come from SGPRs)
 __device__ __forceinline__ double chi_jet(const BurstsDev& b, int jet, double tl) {
   double chi = 1.0;

@@ -18,8 +18,6 @@
 namespace rjp {
 
 constexpr int kRB = 256;     // threads per workgroup
-constexpr int kZT = 16;      // sightlines (z) per tile
-constexpr int kYC = 16;      // y-rows per LDS slab
 
 // ---- Faddeeva: Re w(x + i y), y > 0 ----------------------------------------------------
 // Core: trapezoidal rule with step h on w(z) = (i/pi) Int exp(-t^2)/(z-t) dt plus the residue
@@ -32,24 +30,98 @@ constexpr int kYC = 16;      // y-rows per LDS slab
 // relative error < 3e-10 there.
 constexpr double kH = 0.6;
 constexpr int kNPair = 10;
-__device__ __constant__ double c_node0[kNPair] = {          // exp(-(n h)^2), n = 0 halved
-    0.5, 0.697676326071031, 0.23692775868212176, 0.0391638950989871,
-    0.003151111598444441, 0.00012340980408667956, 2.3525752000097794e-06,
-    2.1829577951254778e-08, 9.859505575991516e-11, 2.1675688826189771e-13};
-__device__ __constant__ double c_node1[kNPair] = {          // exp(-((n + 1/2) h)^2)
-    0.9139311852712282, 0.4448580662229412, 0.10539922456186433, 0.012155178329914935,
-    0.0006823280527563778, 1.864374233151685e-05, 2.479596018045032e-07,
-    1.6052280551856116e-09, 5.058252742843803e-12, 7.758402075696054e-15};
+// node tables for the two lattices (delta = 0 and delta = 1/2): tau = t^2, w = 2 exp(-tau)
+// (the self-paired node t = 0 carries half weight), wt = w tau
+__device__ __constant__ double c_tau0[kNPair] = {0.0, 0.36, 1.44, 3.2399999999999993, 5.76, 9.0, 12.959999999999997, 17.64, 23.04, 29.159999999999993};
+__device__ __constant__ double c_tau1[kNPair] = {0.09, 0.8099999999999998, 2.25, 4.41, 7.289999999999998, 10.889999999999999, 15.209999999999999, 20.25, 26.009999999999998, 32.49};
+__device__ __constant__ double c_w0[kNPair] = {1.0, 1.395352652142062, 0.47385551736424353, 0.0783277901979742, 0.006302223196888882, 0.0002468196081733591, 4.705150400019559e-06, 4.3659155902509556e-08, 1.9719011151983032e-10, 4.3351377652379543e-13};
+__device__ __constant__ double c_w1[kNPair] = {1.8278623705424564, 0.8897161324458824, 0.21079844912372867, 0.02431035665982987, 0.0013646561055127555, 3.72874846630337e-05, 4.959192036090064e-07, 3.2104561103712233e-09, 1.0116505485687606e-11, 1.5516804151392108e-14};
+__device__ __constant__ double c_wt0[kNPair] = {0.0, 0.5023269547711423, 0.6823519450045107, 0.25378204024143636, 0.03630080561407996, 0.002221376473560232, 6.097874918425347e-05, 7.701475101202686e-07, 4.54326016941689e-09, 1.2641261723433871e-11};
+__device__ __constant__ double c_wt1[kNPair] = {0.16450761334882108, 0.7206700672811647, 0.4742965105283895, 0.10720867286984972, 0.009948343009187986, 0.000406060707980437, 7.542931086892987e-06, 6.501173623501727e-08, 2.631303076827346e-10, 5.041409668787296e-13};
 
-__device__ __forceinline__ double rcp_fast(double d) {
-  // f32 seed + one fp64 Newton step: rel. err < 4e-14 for d within the f32 exponent range
-  double r = (double)__builtin_amdgcn_rcpf((float)d);
-  return r * __builtin_fma(-d, r, 2.0);
+// sin(2 pi u), cos(2 pi u): quarter-turn reduction, Taylor polynomials on |w| <= pi/4
+// (truncation < 2e-14 / 1e-15).  |u| < 2^30.
+__device__ __forceinline__ void sincos_2pi(double u, double& sn, double& cs) {
+  const double k = __builtin_rint(4.0 * u);
+  const double w = 6.28318530717958647692 * __builtin_fma(-0.25, k, u);
+  const double w2 = w * w;
+  double ps = -7.6471637318198164759e-13;                 // -1/15!
+  ps = __builtin_fma(ps, w2, 1.6059043836821614599e-10);  //  1/13!
+  ps = __builtin_fma(ps, w2, -2.5052108385441718775e-08); // -1/11!
+  ps = __builtin_fma(ps, w2, 2.7557319223985890653e-06);  //  1/9!
+  ps = __builtin_fma(ps, w2, -1.9841269841269841253e-04); // -1/7!
+  ps = __builtin_fma(ps, w2, 8.3333333333333332177e-03);  //  1/5!
+  ps = __builtin_fma(ps, w2, -1.6666666666666665741e-01); // -1/3!
+  const double s0 = __builtin_fma(ps * w2, w, w);
+  double pc = 4.7794773323873852974e-14;                  //  1/16!
+  pc = __builtin_fma(pc, w2, -1.1470745597729724714e-11); // -1/14!
+  pc = __builtin_fma(pc, w2, 2.0876756987868098979e-09);  //  1/12!
+  pc = __builtin_fma(pc, w2, -2.7557319223985888276e-07); // -1/10!
+  pc = __builtin_fma(pc, w2, 2.4801587301587301566e-05);  //  1/8!
+  pc = __builtin_fma(pc, w2, -1.3888888888888889419e-03); // -1/6!
+  pc = __builtin_fma(pc, w2, 4.1666666666666664354e-02);  //  1/4!
+  pc = __builtin_fma(pc, w2, -0.5);
+  const double c0 = __builtin_fma(pc, w2, 1.0);
+  const int q = (int)k & 3;
+  const double a = (q & 1) ? c0 : s0;       // q=0: s,c  q=1: c,-s  q=2: -s,-c  q=3: -c,s
+  const double b = (q & 1) ? s0 : c0;
+  sn = (q & 2) ? -a : a;
+  cs = (q == 1 || q == 2) ? -b : b;
 }
 
-__device__ double voigt_rew(double ax, double y, double q) {
+__device__ __forceinline__ double rcp_fast(double d) {
+#if defined(RJP_RCP_F32)
+  double r = (double)__builtin_amdgcn_rcpf((float)d);   // f32 seed (d within f32 range)
+#else
+  double r = __builtin_amdgcn_rcp(d);                   // hardware v_rcp_f64 seed
+#endif
+  return r * __builtin_fma(-d, r, 2.0);                 // + one Newton step
+}
+
+// Shifted-lattice evaluation, used only for y < 0.03 (see voigt_rew): nodes (n + delta) h
+// with delta = 1/2 whenever x is within h/4 of a node of the plain lattice, so that the
+// trapezoid sum and the pole term never cancel, however small y is.
+__device__ __forceinline__ double voigt_core_shifted(double ax, double y, double q,
+                                                     double lnq) {
   const double r2 = __builtin_fma(ax, ax, y * y);
-  if (r2 > 64.0 && (ax * ax > 64.0 || y > 1.0)) {
+  const double u = ax * (1.0 / kH);
+  const double fr = u - __builtin_floor(u);
+  const bool half = !(fr >= 0.25 && fr < 0.75);
+  const double U = r2 * r2;
+  const double W = 2.0 * __builtin_fma(-ax, ax, y * y);
+  double s = 0.0;
+#pragma unroll
+  for (int n = 0; n < kNPair; ++n) {
+    const double tau = half ? c_tau1[n] : c_tau0[n];
+    const double c2 = half ? c_w1[n] : c_w0[n];
+    const double c2t = half ? c_wt1[n] : c_wt0[n];
+    const double den = __builtin_fma(tau, W + tau, U);
+    s = __builtin_fma(__builtin_fma(c2, r2, c2t), rcp_fast(den), s);
+  }
+  s *= y * (kH / 3.14159265358979323846);
+  const double e = y * y - ax * ax;
+  if (e + lnq > (double)__logf((float)s) - 31.0) {
+    // Re[ 2 exp(-z^2) q / (q - exp(-i theta)) ], theta = 2 pi (x/h - delta); the shift keeps
+    // |q - e^{-i theta}| >= 1
+    double st, ct, s2, c2;
+    sincos_2pi(fr - (half ? 0.5 : 0.0), st, ct);
+    sincos_2pi(0.31830988618379067154 * ax * y, s2, c2);
+    const double den = __builtin_fma(q, q - 2.0 * ct, 1.0);
+    s += 2.0 * exp_any(e) * q * (c2 * (q - ct) - s2 * st) * rcp_fast(den);
+  }
+  return s;
+}
+
+// Re w(x + i y) for one lane (x = ax >= 0 per lane, y > 0 THE SAME IN EVERY LANE: a wave
+// works on one cell).  Per-cell constants: q = exp(-2 pi y / h) (or -1 when y >= pi/h: no
+// pole term), omq = 1 - q (from expm1), cq = pole-term skip threshold.
+__device__ __forceinline__ double voigt_rew(double ax, double y, double q, double omq,
+                                            double cq) {
+  const double r2 = __builtin_fma(ax, ax, y * y);
+  // the far-field branch is taken only when EVERY active lane qualifies: the core formula is
+  // valid everywhere, so a wave that straddles the boundary runs one path, not both
+  const bool far = r2 > 64.0 && (ax * ax > 64.0 || y > 1.0);
+  if (__builtin_amdgcn_ballot_w64(!far) == 0) {
     // w = (i/sqrt(pi)) / (z - (1/2)/(z - 1/(z - (3/2)/(z - 2/(z - (5/2)/(z - 3/z))))))
     double wr = ax, wi = y;
 #pragma unroll
@@ -60,30 +132,54 @@ __device__ double voigt_rew(double ax, double y, double q) {
     }
     return 0.56418958354775628695 * wi * rcp_fast(__builtin_fma(wr, wr, wi * wi));
   }
-  const double u = ax * (1.0 / kH);
-  const double fr = u - __builtin_floor(u);
-  const bool half = !(fr >= 0.25 && fr < 0.75);
-  const double dh = half ? 0.5 * kH : 0.0;
+  if (y < 0.03) return voigt_core_shifted(ax, y, q, -2.0 * (3.14159265358979323846 / kH) * y);
+
+  // Plain lattice t = n h.  Pair (+t,-t):
+  //   c [1/((x-t)^2+y^2) + 1/((x+t)^2+y^2)] = 2c (A + tau) / (A^2 + tau (W + tau)),
+  //   A = x^2+y^2, W = 2 (y^2 - x^2), tau = t^2 -- all node constants are immediates.
+  // A lane close to a node sees the sum and the pole term cancel and the factored
+  // denominator loses digits ~ x^2/(4 y^2); for y >= 0.03 the result keeps a relative error
+  // < 3e-12 (measured against scipy.special.wofz), below that the shifted lattice is used.
+  const double U = r2 * r2;
+  const double W = 2.0 * __builtin_fma(-ax, ax, y * y);
+  constexpr double tau[kNPair] = {0.0, 0.36, 1.44, 3.2399999999999993, 5.76, 9.0,
+                                  12.959999999999997, 17.64, 23.04, 29.159999999999993};
+  constexpr double w2[kNPair] = {1.0, 1.395352652142062, 0.47385551736424353,
+                                 0.0783277901979742, 0.006302223196888882,
+                                 0.0002468196081733591, 4.705150400019559e-06,
+                                 4.3659155902509556e-08, 1.9719011151983032e-10,
+                                 4.3351377652379543e-13};
+  constexpr double w2t[kNPair] = {0.0, 0.5023269547711423, 0.6823519450045107,
+                                  0.25378204024143636, 0.03630080561407996,
+                                  0.002221376473560232, 6.097874918425347e-05,
+                                  7.701475101202686e-07, 4.54326016941689e-09,
+                                  1.2641261723433871e-11};
   double s = 0.0;
 #pragma unroll
   for (int n = 0; n < kNPair; ++n) {
-    const double t = n * kH + dh;
-    const double c = half ? c_node1[n] : c_node0[n];
-    const double S = __builtin_fma(t, t, r2);
-    const double D = 2.0 * ax * t;
-    // c * [1/((x-t)^2+y^2) + 1/((x+t)^2+y^2)] = c * 2S / (S^2 - D^2)
-    s = __builtin_fma(c * (S + S), rcp_fast((S - D) * (S + D)), s);
+    const double den = __builtin_fma(tau[n], W + tau[n], U);
+    s = __builtin_fma(__builtin_fma(w2[n], r2, w2t[n]), rcp_fast(den), s);
   }
   s *= y * (kH / 3.14159265358979323846);
+  // Pole term P = Re[ 2 exp(-z^2) q / (q - exp(-i theta)) ], theta = 2 pi x / h.
+  // |P| <= 6 exp(y^2-x^2) q / D with D = |q - e^{-i theta}|^2 >= max((1-q)^2, 16 q m^2),
+  // m = distance of x/h to the nearest integer; Re w >= y / (4 (|z|^2 + 1)).  The term is
+  // skipped when that bound is below 1e-13 Re w (cq = per-cell part of the comparison).
   if (q >= 0.0) {
     const double e = y * y - ax * ax;
-    if (e > -80.0) {
-      // Re[ 2 exp(-z^2) q / (q - exp(-i theta)) ], theta = 2 pi (x/h - delta)
-      double st, ct, s2, c2;
-      sincos(6.28318530717958647692 * (fr - (half ? 0.5 : 0.0)), &st, &ct);
-      sincos(2.0 * ax * y, &s2, &c2);
-      const double den = __builtin_fma(q, q - 2.0 * ct, 1.0);
-      s += 2.0 * exp(e) * q * (c2 * (q - ct) - s2 * st) / den;
+    const double u = ax * (1.0 / kH);
+    const double fr = u - __builtin_floor(u);
+    const float m = (float)fmin(fr, 1.0 - fr);
+    const float dmin = fmaxf((float)(omq * omq), 16.0f * (float)q * m * m);
+    if (e + cq + (double)(__logf((float)r2 + 1.0f) - __logf(dmin)) > 0.0) {
+      double sh, ch, s2, c2;
+      sincos_2pi(0.5 * fr, sh, ch);                       // half angle: theta/2 = pi fr
+      sincos_2pi(0.31830988618379067154 * ax * y, s2, c2);
+      const double omc = 2.0 * sh * sh;                   // 1 - cos(theta), no cancellation
+      const double st = 2.0 * sh * ch;                    // sin(theta)
+      const double den = __builtin_fma(omq, omq, 2.0 * q * omc);   // |q - e^{-i theta}|^2
+      const double num = __builtin_fma(c2, omc - omq, -s2 * st);   // Re[e^{-2ixy} conj(q - e^{-i theta})]
+      s += 2.0 * exp_any(e) * q * num * rcp_fast(den);
     }
   }
   return s;
@@ -107,20 +203,34 @@ struct LineDev {
 };
 
 // LF = lanes along the channel axis (16, 64 or 256); G = kRB / LF sightline groups.
+// Tile = ZT z-adjacent sightlines (8 for LF = 256, else 16), slab = 256 / ZT y-rows.
+// The per-(sightline, channel) accumulators live in LDS, one slot per thread and sightline,
+// so the sightline loop is NOT unrolled: one inlined copy of the Voigt code, < 128 VGPRs.
+template <int LF> struct RrlTile {
+  static constexpr int ZT = LF == 256 ? 8 : 16;
+  static constexpr int YC = kRB / ZT;
+  static constexpr int G = kRB / LF;
+  static constexpr int NZP = ZT / G;        // sightlines per thread
+};
+
+#ifndef RJP_K3_WAVES
+#define RJP_K3_WAVES 4      /* 128-VGPR budget: 4 waves per SIMD hide the LDS/constant waits (+8 %) */
+#endif
 template <typename T, int LF, bool BURSTS>
-__global__ __launch_bounds__(kRB) void rrl_scan_kernel(
+__global__ __launch_bounds__(kRB, RJP_K3_WAVES) void rrl_scan_kernel(
     RrlFields<T> f, int nx, int ny, int nz, BurstsDev b, double time_s, LineDev ln,
     const double* __restrict__ nu, int nchan, double* __restrict__ tau) {
-  constexpr int G = kRB / LF;
-  constexpr int NZP = kZT / G;       // sightlines per thread
-  static_assert(kZT % G == 0, "tile/group mismatch");
+  using TL = RrlTile<LF>;
+  constexpr int ZT = TL::ZT, YC = TL::YC, NZP = TL::NZP;
+  static_assert(ZT % TL::G == 0, "tile/group mismatch");
 
   __shared__ double s_nu0[kRB], s_is2[kRB], s_y[kRB], s_C[kRB], s_a[kRB], s_E0[kRB],
-      s_q[kRB];
+      s_q[kRB], s_omq[kRB], s_cq[kRB];
+  __shared__ double s_acc[NZP * kRB];
 
-  const int ntz = (nz + kZT - 1) / kZT;
+  const int ntz = (nz + ZT - 1) / ZT;
   const int x = blockIdx.x / ntz;
-  const int z0 = (blockIdx.x - x * ntz) * kZT;
+  const int z0 = (blockIdx.x - x * ntz) * ZT;
   const int tid = threadIdx.x;
   const int fl = tid % LF;
   const int g = tid / LF;
@@ -129,18 +239,18 @@ __global__ __launch_bounds__(kRB) void rrl_scan_kernel(
   const double nu_f = chan_live ? nu[fi] : ln.nu_ref;
   const double dnu = nu_f - ln.nu_ref;
 
-  double acc[NZP];
 #pragma unroll
-  for (int j = 0; j < NZP; ++j) acc[j] = 0.0;
+  for (int j = 0; j < NZP; ++j) s_acc[j * kRB + tid] = 0.0;
 
-  const int cy = tid / kZT, cz = tid % kZT;     // this thread's cell in the slab (phase 1)
+  const int cy = tid / ZT, cz = tid % ZT;       // this thread's cell in the slab (phase 1)
   const double kPiOverH = 3.14159265358979323846 / kH;
 
-  for (int yb = 0; yb < ny; yb += kYC) {
+  for (int yb = 0; yb < ny; yb += YC) {
     // ---- phase 1: per-cell line constants --------------------------------------------
     {
       const int yy = yb + cy, zz = z0 + cz;
-      double C = 0.0, nu0 = 0.0, is2 = 0.0, yv = 1.0, a = 0.0, E0 = 0.0, q = -1.0;
+      double C = 0.0, nu0 = 0.0, is2 = 0.0, yv = 1.0, a = 0.0, E0 = 0.0, q = -1.0,
+             omq = 1.0, cq = 0.0;
       if (yy < ny && zz < nz) {
         const int64_t o = ((int64_t)x * ny + yy) * nz + zz;
         const double nd = (double)f.nd[o], xi = (double)f.xi[o], Tk = (double)f.temp[o],
@@ -159,25 +269,31 @@ __global__ __launch_bounds__(kRB) void rrl_scan_kernel(
         C = ln.kappa0 * (ne * ne / (Tk * sqrt(Tk))) * exp(ln.en_over_k / Tk) *
             (ln.path0 * pf) / (sigma * 2.5066282746310002);
         E0 = exp(-a * ln.nu_ref);
-        q = (yv < kPiOverH) ? exp(-2.0 * kPiOverH * yv) : -1.0;
+        const double lnq = -2.0 * kPiOverH * yv;
+        q = (yv < kPiOverH) ? exp(lnq) : -1.0;
+        omq = -expm1(lnq);
+        // pole term needed iff e + ln(6 q / D) > ln(1e-13 * y / (4 (|z|^2+1)))
+        cq = lnq + 1.7917594692280550 - log(0.25 * yv) + 29.9336062089226;
         if (!(C == C) || C == 0.0 || !(yv > 0.0)) C = 0.0;           // nansum drops NaN terms
       }
       s_C[tid] = C; s_nu0[tid] = nu0; s_is2[tid] = is2; s_y[tid] = yv; s_a[tid] = a;
-      s_E0[tid] = E0; s_q[tid] = q;
+      s_E0[tid] = E0; s_q[tid] = q; s_omq[tid] = omq; s_cq[tid] = cq;
     }
     __syncthreads();
 
     // ---- phase 2: lanes over channels ------------------------------------------------
-    for (int r = 0; r < kYC; ++r) {
-#pragma unroll
-      for (int j = 0; j < NZP; ++j) {
-        const int ci = r * kZT + g * NZP + j;
-        double C = s_C[ci];
+#pragma unroll 1
+    for (int j = 0; j < NZP; ++j) {
+      double acc = s_acc[j * kRB + tid];
+#pragma unroll 1
+      for (int r = 0; r < YC; ++r) {
+        const int ci = r * ZT + g * NZP + j;
+        const double C = s_C[ci];
         bool live = C != 0.0;
         if (LF >= RJP_WAVE) live = __builtin_amdgcn_readfirstlane((int)live) != 0;
         if (live) {
           const double xv = (nu_f - s_nu0[ci]) * s_is2[ci];
-          const double V = voigt_rew(fabs(xv), s_y[ci], s_q[ci]);
+          const double V = voigt_rew(fabs(xv), s_y[ci], s_q[ci], s_omq[ci], s_cq[ci]);
           // 1 - exp(-h nu / kT) = 1 - E0 * exp(-a (nu - nu_ref))          (rrls.py:387)
           const double a = s_a[ci];
           const double eps = a * dnu;
@@ -187,9 +303,10 @@ __global__ __launch_bounds__(kRB) void rrl_scan_kernel(
           else
             ex = exp(-eps);
           const double term = C * V * (1.0 - s_E0[ci] * ex);
-          if (term == term) acc[j] += term;
+          if (term == term) acc += term;
         }
       }
+      s_acc[j * kRB + tid] = acc;
     }
     __syncthreads();
   }
@@ -198,7 +315,7 @@ __global__ __launch_bounds__(kRB) void rrl_scan_kernel(
     const int64_t base = (int64_t)fi * nx * nz + (int64_t)x * nz + z0 + g * NZP;
 #pragma unroll
     for (int j = 0; j < NZP; ++j)
-      if (z0 + g * NZP + j < nz) tau[base + j] = acc[j];
+      if (z0 + g * NZP + j < nz) tau[base + j] = s_acc[j * kRB + tid];
   }
 }
 
@@ -243,7 +360,7 @@ static hipError_t rrl_launch_t(const rjp_fields* fl, const BurstsDev& b, bool bu
                                int nchan, double* tau, hipStream_t st) {
   RrlFields<T> f{(const T*)fl->d_nd, (const T*)fl->d_xi, (const T*)fl->d_temp,
                  (const T*)fl->d_pf, (const T*)fl->d_ts, (const T*)fl->d_vy};
-  const int ntz = (fl->nz + kZT - 1) / kZT;
+  const int ntz = (fl->nz + RrlTile<LF>::ZT - 1) / RrlTile<LF>::ZT;
   dim3 grid((unsigned)(fl->nx * ntz), (unsigned)((nchan + LF - 1) / LF));
   if (bursts)
     hipLaunchKernelGGL((rrl_scan_kernel<T, LF, true>), grid, dim3(kRB), 0, st, f, fl->nx,

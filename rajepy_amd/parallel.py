@@ -94,9 +94,12 @@ def all_gather_blocks(local, shards, rank, axis=0, group=None):
         pad = torch.zeros((cmax - loc.shape[0],) + tuple(loc.shape[1:]), dtype=loc.dtype,
                           device=loc.device)
         loc = torch.cat([loc, pad], dim=0)
+    dev = loc.device
+    if loc.is_cuda and dist.get_backend(group) == "gloo":
+        loc = loc.cpu()                      # rehearsal backend: gloo gathers host tensors
     out = [torch.empty_like(loc) for _ in range(shards.world)]
     dist.all_gather(out, loc, group=group)
-    full = torch.cat([o[:c] for o, c in zip(out, counts)], dim=0)
+    full = torch.cat([o[:c] for o, c in zip(out, counts)], dim=0).to(dev)
     return full.movedim(0, axis)
 
 
@@ -120,11 +123,14 @@ def gather_to_root(local, shards, rank, axis=0, root=0, group=None):
         pad = torch.zeros((cmax - loc.shape[0],) + tuple(loc.shape[1:]), dtype=loc.dtype,
                           device=loc.device)
         loc = torch.cat([loc, pad], dim=0)
+    dev = loc.device
+    if loc.is_cuda and dist.get_backend(group) == "gloo":
+        loc = loc.cpu()
     bufs = [torch.empty_like(loc) for _ in range(shards.world)] if rank == root else None
     dist.gather(loc, bufs, dst=root, group=group)
     if rank != root:
         return None
-    full = torch.cat([b[:c] for b, c in zip(bufs, counts)], dim=0)
+    full = torch.cat([b[:c] for b, c in zip(bufs, counts)], dim=0).to(dev)
     return full.movedim(0, axis)
 
 
