@@ -89,7 +89,14 @@ def import_vanHoof2014():
 
 
 def gff(freq, temp, z=1.):
-    """Free-free Gaunt factor at one (frequency, temperature) (physics.py:666-698).
+    """Free-free Gaunt factor at one (frequency, temperature) (physics.py:666-698); results
+    are memoised (the reference re-reads its table and refits the spline on every call)."""
+    return _gff_cached(float(freq), float(temp), float(z))
+
+
+@functools.lru_cache(maxsize=65536)
+def _gff_cached(freq, temp, z):
+    """
 
     The reference interpolates the 5x5 table window nearest to (log gamma^2, log u) with
     scipy's interp2d(kind='cubic') on scattered points, i.e. FITPACK surfit through

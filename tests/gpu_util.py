@@ -44,11 +44,18 @@ def bursts_from_oracle(jet):
     return make_bursts(out[0], out[1])
 
 
-def synth_host(shape, seed, temp_mode=0, cell0=0):
-    """Host restatement of rjp_synth_fields -- splitmix64 counter hash."""
+def synth_host(shape, seed, temp_mode=0, cell0=0, cells=None, nz_full=None):
+    """Host restatement of rjp_synth_fields -- splitmix64 counter hash.
+    With `cells` (flat indices into a grid whose z-extent is `nz_full`) it generates exactly
+    those cells, returned in `shape`."""
     nx, ny, nz = shape
     n = nx * ny * nz
-    cell = (np.arange(n, dtype=np.uint64) + np.uint64(cell0))
+    if cells is None:
+        cell = (np.arange(n, dtype=np.uint64) + np.uint64(cell0))
+    else:
+        cell = np.asarray(cells, dtype=np.uint64).ravel()
+        assert cell.size == n
+        nz = nz_full
 
     def u01(field):
         x = np.uint64(seed) ^ (np.uint64(field) << np.uint64(60)) ^ cell
@@ -67,6 +74,7 @@ def synth_host(shape, seed, temp_mode=0, cell0=0):
     pf = np.where(u01(4) < 0.25, 0.5, 1.0)
     ts = 5.0 * u01(5) * 31536000.0
     vy = 6.2 + 60.0 * (u01(6) - 0.5)
+    nx, ny, nz = shape
     r = lambda a: a.reshape(shape)
     return dict(nd=r(nd), xi=r(xi), temp=r(temp), ff=r(pf), areas=r(np.ones(n)), ts=r(ts),
                 rr=r(np.where(red, -1.0, 1.0)), vy=r(vy))

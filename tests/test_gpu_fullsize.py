@@ -1,0 +1,109 @@
+"""Full-size GPU checks at BASELINE.json's grid sizes (512x4096x512 continuum, 512x2048x512
+RRL).  The oracle cannot run a billion cells, so parity is checked (a) EXACTLY on a random
+sample of sightlines -- sightlines are independent, so the sampled columns are regenerated on
+the host from the counter hash, stacked as a (k, n_y, 1) grid and run through the oracle --
+and (b) through size-independent properties: an 8-epoch fused pass equals eight single-epoch
+passes bit for bit, the on-device flux-vs-time reduction equals the sum of the flux cube."""
+import copy
+
+import numpy as np
+import pytest
+
+from oracle import rt_oracle as orc
+from tests import gpu_util as U
+
+pytestmark = pytest.mark.gpu
+SEED = 20240504
+
+
+@pytest.fixture(scope="module")
+def eng():
+    from rajepy_amd.engine import RTEngine
+    e = RTEngine(0)
+    yield e
+    e.close()
+
+
+def _sample_jet(shape, pix, temp_mode, q_T):
+    nx, ny, nz = shape
+    cells = np.array([(x * ny + y) * nz + z for (x, z) in pix for y in range(ny)],
+                     dtype=np.uint64)
+    g = U.synth_host((len(pix), ny, 1), SEED, temp_mode, cells=cells, nz_full=nz)
+    p = copy.deepcopy(U.load_golden("cfg1_example")[2])
+    p["ejection"] = U.example_bursts_params()
+    p["power_laws"]["q_T"] = q_T
+    p["grid"].update(n_x=len(pix), n_y=ny, n_z=1)
+    return orc.OracleJet.from_fields(p, g["nd"], g["xi"], g["temp"], g["ff"], g["areas"],
+                                     g["ts"], g["rr"], g["vy"])
+
+
+@pytest.mark.parametrize("dtype,tol", [(8, 1e-10), (4, 1e-5)])
+def test_cfg4_continuum_full_size(eng, dtype, tol):
+    from rajepy_amd import engine as E
+    from rajepy_amd.maths import physics as ph
+    shape = (512, 4096, 512)
+    nx, ny, nz = shape
+    fields = eng.synth_fields(shape, SEED, 0, dtype, csize_au=0.5)
+    rng = np.random.default_rng(5)
+    pix = [(int(rng.integers(nx)), int(rng.integers(nz))) for _ in range(20)]
+    pix += [(0, 0), (nx - 1, nz - 1), (17, nz // 2 - 1), (17, nz // 2)]   # corners, jet boundary
+    jet = _sample_jet(shape, pix, 0, 0.)
+    bursts = U.bursts_from_oracle(jet)
+    years = [0.3, 0.9, 1.0, 1.7, 2.2, 2.9, 3.6, 4.4]
+    ep = [y * orc.YEAR for y in years]
+    freqs = np.array([1e9, 5e9, 2.2e10, 5e10])
+    gv = [ph.gff(nu, 1e4) for nu in freqs]
+    ctau, cflux = E.ff_channel_coeffs(freqs, 0.5, 120., E.RJP_GFF_SCALAR, gv)
+
+    # (b1) one fused 8-epoch pass == eight single passes, bit for bit
+    sumA8, em8, tavg = eng.ff_scan(fields, bursts, ep, E.RJP_GFF_SCALAR)
+    for e in (0, 3, 7):
+        s1, e1, _ = eng.ff_scan(fields, bursts, [ep[e]], E.RJP_GFF_SCALAR)
+        eng.synchronize()
+        assert bool((s1[0] == sumA8[e]).all()) and bool((e1[0] == em8[e]).all())
+
+    # (b2) device flux-vs-time reduction == sum of the flux cube
+    tau, flux, ftot = eng.ff_maps(sumA8[:2].contiguous(), tavg, ctau, cflux)
+    eng.synchronize()
+    np.testing.assert_allclose(ftot.cpu().numpy(), flux.nansum(dim=2).cpu().numpy(), rtol=1e-12)
+
+    # (a) sampled sightlines == oracle
+    idx = [x * nz + z for (x, z) in pix]
+    tau_s = tau.cpu().numpy()[:, :, idx]
+    flux_s = flux.cpu().numpy()[:, :, idx]
+    em_s = em8.cpu().numpy()[:, idx]
+    for e in range(2):
+        jet.time = ep[e]
+        np.testing.assert_allclose(tau_s[e], jet.optical_depth_ff(freqs)[:, :, 0], rtol=tol)
+        np.testing.assert_allclose(flux_s[e], jet.flux_ff(freqs)[:, :, 0], rtol=tol)
+        np.testing.assert_allclose(em_s[e], jet.emission_measure()[:, 0], rtol=tol)
+    # every sightline of the dense set is optically relevant: no zeros, no NaNs
+    assert bool(torch_all_finite(sumA8)) and float(sumA8.min().item()) > 0.0
+
+
+def torch_all_finite(t):
+    import torch
+    return torch.isfinite(t).all().item()
+
+
+def test_cfg3_rrl_full_size(eng):
+    from rajepy_amd import _lib
+    from rajepy_amd.maths import rrls
+    shape = (512, 2048, 512)
+    nx, ny, nz = shape
+    fields = eng.synth_fields(shape, SEED, 1, 8, csize_au=0.5, with_vy=True)
+    rng = np.random.default_rng(11)
+    pix = [(int(rng.integers(nx)), int(rng.integers(nz))) for _ in range(10)] + [(3, nz // 2)]
+    jet = _sample_jet(shape, pix, 1, -0.5)
+    jet.time = 1.2 * orc.YEAR
+    nchan = 40
+    nu0 = rrls.rrl_nu_0("H", 66, 1)
+    rf = orc.chan_freqs(nu0, nchan * 6e5, 6e5)            # +-12 MHz: core, wings and far field
+    line = _lib.Line(**rrls.line_constants("H66a"))
+    tau = eng.rrl_scan(fields, U.bursts_from_oracle(jet), jet.time, line, rf)
+    eng.synchronize()
+    idx = [x * nz + z for (x, z) in pix]
+    got = tau.cpu().numpy()[:, idx]
+    ref = jet.optical_depth_rrl("H66a", np.asarray(rf))[:, :, 0]
+    np.testing.assert_allclose(got, ref, rtol=1e-9)
+    assert bool(torch_all_finite(tau))
