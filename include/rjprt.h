@@ -179,7 +179,10 @@ typedef struct rjp_geometry {
 } rjp_geometry;
 
 /* d_vy / d_ts may be NULL to skip them; d_ff_raw / d_areas_raw (float64, optional) receive
- * the un-packed fill factors / areas that JetModel.save pickles (classes.py:1704-1709). */
+ * the un-packed fill factors / areas that JetModel.save pickles (classes.py:1704-1709).
+ * Launch times: closed form for q^d_v = 0, otherwise Gauss' 2F1(a, b; b+1; -A) of
+ * maths/geometry.py:166-171 evaluated on the device (Pfaff + 1/z connection formula);
+ * RJP_ERR_ARG if a-b or b is a non-positive integer (logarithmic cases) and d_ts != NULL. */
 int rjp_build_fields(rjp_ctx* ctx, const rjp_geometry* geom, int dtype,
                      void* d_nd, void* d_xi, void* d_temp, void* d_pf, void* d_ts,
                      void* d_vy, double* d_ff_raw, double* d_areas_raw, void* stream);

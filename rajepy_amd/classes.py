@@ -304,11 +304,13 @@ class JetModel:
                 self.log.add_entry("INFO", "Calculating cells' fill factors/projected areas")
             then = _time.time()
             geom = geometry_struct(self.params, self.nx, self.ny, self.nz)
-            closed = self.params['power_laws']['q^d_v'] == 0.
-            self._dev = self.engine.build_fields(geom, self._dtype, want_ts=closed)
-            if not closed:
-                # launch times need 2F1: host evaluation as in the reference
-                # (maths/geometry.py:150-178), uploaded once
+            try:
+                self._dev = self.engine.build_fields(geom, self._dtype, want_ts=True)
+            except _lib.RjprtError:
+                # degenerate 2F1 parameters (q^d_v and the launch-time exponent differ by an
+                # integer): the library refuses; evaluate the launch times with scipy's hyp2f1
+                # exactly as the reference does (maths/geometry.py:150-178) and upload them
+                self._dev = self.engine.build_fields(geom, self._dtype, want_ts=False)
                 self.engine.replace_field(self._dev, "ts", self._host_launch_times())
             self.engine.synchronize()
             if self.log:

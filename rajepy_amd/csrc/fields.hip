@@ -106,7 +106,11 @@ struct GeomDev {
   double q_n, q_x, q_T, q_v, qd_n, qd_x, qd_T, qd_v;
   double rb_frac;
   double ts_const, ts_pow, ts_base;   // ts = ts_const * (rad^ts_pow - ts_base)  [q^d_v == 0]
-  int ts_closed_form;
+  int ts_mode;                        // 0 = skip, 1 = closed form (q^d_v = 0), 2 = with 2F1
+  // q^d_v != 0 (maths/geometry.py:150-178): a = q^d_v, b = (1 - q_v + eps q^d_v)/eps,
+  // hypergeometric connection coefficients K1 = b/(b-a), K2 = Gamma(b+1)Gamma(a-b)/Gamma(a)
+  double hy_a, hy_b, hy_k1, hy_k2, hy_axis;
+  double r1_m, r2_m, w0_m, mr0_m, r0_m;
 };
 
 __device__ __forceinline__ void xyz_to_rw(const GeomDev& g, double x, double y, double z,
@@ -131,6 +135,40 @@ __device__ __forceinline__ double powerlaw(double zero, double rho_, double reff
   double v = zero * pow(rho_, q) * pow(reff / r1, qd);
   if (v == 0.0 || isinf(v)) v = __builtin_nan("");  // classes.py:892, 897
   return v;
+}
+
+// S(a, beta, s) = 2F1(a, 1; beta + 1; s) = sum_k (a)_k / (beta + 1)_k s^k for 0 <= s <= 1/2
+// (terms keep one sign after the first: no cancellation; <= 60 terms to 1e-16).
+__device__ __forceinline__ double hyp_series(double a, double beta, double s) {
+  double term = 1.0, sum = 1.0;
+  for (int k = 0; k < 80; ++k) {
+    term *= (a + k) / (beta + 1.0 + k) * s;
+    sum += term;
+    if (fabs(term) <= 1e-17 * fabs(sum)) break;
+  }
+  return sum;
+}
+
+// A^a * 2F1(a, b; b+1; -A) for A > 0: the product p2*p3*p4 of maths/geometry.py:159-171
+// (p2 p3 = (1 + 1/A)^-a (A + 1)^a = A^a).  Pfaff's transformation for A <= 1, the 1/z
+// connection formula (DLMF 15.8.2 with c = b + 1) followed by Pfaff for A > 1.
+__device__ __forceinline__ double hyp_flow_factor(const GeomDev& g, double A) {
+  const double a = g.hy_a, b = g.hy_b;
+  const double s = A / (1.0 + A);
+  const double sa = pow(s, a);                     // A^a (1 + A)^-a
+  if (A <= 1.0) return sa * hyp_series(a, b, s);
+  return sa * g.hy_k1 * hyp_series(a, a - b, 1.0 / (1.0 + A)) + g.hy_k2 * pow(A, a - b);
+}
+
+// indefinite integral of geometry.py:150-173 at (r_ [m], w_ [m])
+__device__ __forceinline__ double flow_time_antiderivative(const GeomDev& g, double r_m,
+                                                           double w_m) {
+  const double rad = r_m + g.mr0_m - g.r0_m;
+  const double lead = g.ts_const * pow(rad, g.ts_pow);
+  if (w_m == 0.0) return lead * g.hy_axis;          // p2 = p3 = 1, p4 = 1 + q^d_v/(1 - q_v)
+  const double A = (g.r1_m * g.w0_m * pow(rad, g.eps)) /
+                   (w_m * pow(g.mr0_m, g.eps) * (g.r2_m - g.r1_m));
+  return lead * hyp_flow_factor(g, A);
 }
 
 template <typename T>
@@ -188,7 +226,13 @@ __global__ __launch_bounds__(kFB) void build_fields_kernel(GeomDev g, T* nd, T* 
     temp[i] = (T)(jet ? powerlaw(g.T_0, rho_mod(g, rt), reff, g.R_1, g.q_T, g.qd_T) : nan);
   }
   if (pf) pf[i] = (T)(ff / ar);
-  if (ts && g.ts_closed_form) {
+  if (ts && g.ts_mode == 2) {
+    const double au = 149597870700.0;
+    const double t_yr = (flow_time_antiderivative(g, rc * au, ww * au) -
+                         flow_time_antiderivative(g, g.r0_m, ww * au)) / 31536000.0;
+    ts[i] = (T)(t_yr * 31536000.0);
+  }
+  if (ts && g.ts_mode == 1) {
     // geometry.py:150-178 with q^d_v == 0 (p2 = p3 = p4 = 1), in seconds
     const double au = 149597870700.0;
     const double rad = rc * au + g.mr0 * au - g.r_0 * au;

@@ -296,10 +296,6 @@ int rjp_build_fields(rjp_ctx* ctx, const rjp_geometry* gm, int dtype, void* d_nd
   if (dtype != RJP_F32 && dtype != RJP_F64) return fail(ctx, RJP_ERR_ARG, "bad dtype tag");
   if (gm->nx <= 0 || gm->ny <= 0 || gm->nz <= 0 || !(gm->csize > 0))
     return fail(ctx, RJP_ERR_ARG, "bad grid in geometry");
-  if (d_ts && gm->qd_v != 0.0)
-    return fail(ctx, RJP_ERR_ARG,
-                "rjp_build_fields: launch times need 2F1 when q^d_v != 0; pass d_ts = NULL "
-                "and upload ts computed by the host (rajepy_amd.maths.geometry.t_rw)");
   const double au = 149597870700.0, d2r = M_PI / 180.0;
   rjp::GeomDev g;
   g.nx = gm->nx; g.ny = gm->ny; g.nz = gm->nz; g.ccw = gm->rotation_ccw;
@@ -317,13 +313,32 @@ int rjp_build_fields(rjp_ctx* ctx, const rjp_geometry* gm, int dtype, void* d_nd
   g.q_n = gm->q_n; g.q_x = gm->q_x; g.q_T = gm->q_T; g.q_v = gm->q_v;
   g.qd_n = gm->qd_n; g.qd_x = gm->qd_x; g.qd_T = gm->qd_T; g.qd_v = gm->qd_v;
   g.rb_frac = gm->rb_frac;
-  g.ts_closed_form = d_ts != nullptr;
   {
-    // geometry.py:150-156 with q^d_v = 0
+    // maths/geometry.py:150-156
     const double mr0 = gm->mod_r_0 * au, r0 = gm->r_0 * au, v0 = gm->v_0 * 1e3;
+    const double a = gm->qd_v, b = (1. - gm->q_v + gm->epsilon * gm->qd_v) / gm->epsilon;
     g.ts_pow = 1. - gm->q_v;
-    g.ts_const = pow(mr0, gm->q_v) / (v0 * (1. - gm->q_v + gm->epsilon * 0.0));
+    g.ts_const = pow(mr0, gm->q_v) / (v0 * (1. - gm->q_v + gm->epsilon * gm->qd_v));
     g.ts_base = g.ts_const * pow(r0 + mr0 - r0, g.ts_pow);
+    g.mr0_m = mr0; g.r0_m = r0;
+    g.r1_m = gm->R_1 * au; g.r2_m = gm->R_2 * au; g.w0_m = gm->w_0 * au;
+    g.hy_a = a; g.hy_b = b;
+    g.hy_axis = 1. + gm->qd_v / (1. - gm->q_v);
+    g.hy_k1 = g.hy_k2 = 0.0;
+    g.ts_mode = d_ts ? 1 : 0;
+    if (d_ts && a != 0.0) {
+      // connection coefficients need Gamma(a-b) and 1/Gamma(a): degenerate when a - b or b
+      // is an integer <= 0 (logarithmic cases) -> refuse, the caller evaluates ts itself
+      const double amb = a - b;
+      auto nonpos_int = [](double v) { return v < 0.5 && fabs(v - nearbyint(v)) < 1e-6; };
+      if (nonpos_int(amb) || nonpos_int(b) || nonpos_int(b + 1.) || b == a)
+        return fail(ctx, RJP_ERR_ARG,
+                    "rjp_build_fields: degenerate 2F1 parameters (a-b or b a non-positive "
+                    "integer); pass d_ts = NULL and upload host-computed launch times");
+      g.hy_k1 = b / (b - a);
+      g.hy_k2 = nonpos_int(a) ? 0.0 : tgamma(b + 1.) * tgamma(amb) / tgamma(a);
+      g.ts_mode = 2;
+    }
   }
   const int64_t n = (int64_t)g.nx * g.ny * g.nz;
   const unsigned blocks = (unsigned)((n + rjp::kFB - 1) / rjp::kFB);
