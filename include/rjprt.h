@@ -147,6 +147,16 @@ int rjp_rrl_scan(rjp_ctx* ctx, const rjp_fields* fields, const rjp_bursts* burst
                  double time_s, const rjp_line* line, const double* h_nu, int32_t n_chan,
                  double* d_tau_rrl, void* stream);
 
+/* collapse=False forms (classes.py:1382-1383, 1176-1177): the 3-D per-cell optical depths,
+ * d_tau_cells[f * N + cell], NaN outside the jet as in the reference.  h_ctau as for
+ * rjp_ff_maps.  Not used by Pipeline; N*F*8 bytes of output. */
+int rjp_ff_cells(rjp_ctx* ctx, const rjp_fields* fields, const rjp_bursts* bursts,
+                 double time_s, int32_t gff_mode, const double* h_ctau, int32_t n_chan,
+                 double* d_tau_cells, void* stream);
+int rjp_rrl_cells(rjp_ctx* ctx, const rjp_fields* fields, const rjp_bursts* bursts,
+                  double time_s, const rjp_line* line, const double* h_nu, int32_t n_chan,
+                  double* d_tau_cells, void* stream);
+
 /* Map stage of intensity_rrl / flux_rrl (classes.py:1280-1282, 1339-1343;
  * rrls.py:444-449; physics.py:571-574):
  *   I_L = B_nu(tavg) exp(-tau_ff) (1 - exp(-tau_rrl)) 1e-3 ; S = I_L * omega / 1e-26
@@ -179,13 +189,15 @@ typedef struct rjp_geometry {
 } rjp_geometry;
 
 /* d_vy / d_ts may be NULL to skip them; d_ff_raw / d_areas_raw (float64, optional) receive
- * the un-packed fill factors / areas that JetModel.save pickles (classes.py:1704-1709).
+ * the un-packed fill factors / areas that JetModel.save pickles (classes.py:1704-1709);
+ * d_vx_raw / d_vz_raw (float64, optional) the transverse components of JetModel.vel.
  * Launch times: closed form for q^d_v = 0, otherwise Gauss' 2F1(a, b; b+1; -A) of
  * maths/geometry.py:166-171 evaluated on the device (Pfaff + 1/z connection formula);
  * RJP_ERR_ARG if a-b or b is a non-positive integer (logarithmic cases) and d_ts != NULL. */
 int rjp_build_fields(rjp_ctx* ctx, const rjp_geometry* geom, int dtype,
                      void* d_nd, void* d_xi, void* d_temp, void* d_pf, void* d_ts,
-                     void* d_vy, double* d_ff_raw, double* d_areas_raw, void* stream);
+                     void* d_vy, double* d_ff_raw, double* d_areas_raw,
+                     double* d_vx_raw, double* d_vz_raw, void* stream);
 
 /* ---- measurement harness: synthetic dense fields ---------------------
  * Counter-based: u = splitmix64(seed ^ field_id<<60 ^ linear_cell_index) -> [0,1).

@@ -75,10 +75,14 @@ SIGNATURES = {
                               _P, _P, _P, _P, C.c_size_t, _P]),
     "rjp_rrl_scan": (C.c_int, [_P, C.POINTER(Fields), C.POINTER(Bursts), C.c_double,
                                C.POINTER(Line), _DP, C.c_int32, _P, _P]),
+    "rjp_ff_cells": (C.c_int, [_P, C.POINTER(Fields), C.POINTER(Bursts), C.c_double, C.c_int32,
+                               _DP, C.c_int32, _P, _P]),
+    "rjp_rrl_cells": (C.c_int, [_P, C.POINTER(Fields), C.POINTER(Bursts), C.c_double,
+                                C.POINTER(Line), _DP, C.c_int32, _P, _P]),
     "rjp_rrl_maps": (C.c_int, [_P, _P, _P, _P, _P, C.c_int64, _DP, _DP, C.c_int32,
                                _P, _P, _P, C.c_size_t, _P]),
     "rjp_build_fields": (C.c_int, [_P, C.POINTER(Geometry), C.c_int, _P, _P, _P, _P, _P,
-                                   _P, _P, _P, _P]),
+                                   _P, _P, _P, _P, _P, _P]),
     "rjp_synth_fields": (C.c_int, [_P, C.c_uint64, C.c_int32, C.c_int32, C.c_int64,
                                    C.c_int64, C.c_int, _P, _P, _P, _P, _P, _P, _P]),
     "rjp_time_ff_scan": (C.c_int, [_P, C.POINTER(Fields), C.POINTER(Bursts), _DP,

@@ -157,6 +157,7 @@ class JetModel:
         self._scan_cache = {}        # time -> (sumA[P], em[P]) device tensors
         self._tavg = None
         self._host_ts = None
+        self._vxz = None
 
     # ------------------------------------------------------------------ bookkeeping ----
     def __str__(self):
@@ -390,9 +391,14 @@ class JetModel:
 
     @property
     def vel(self):
-        """(None, v_y + v_lsr, None) [km/s]: only the line-of-sight component feeds the RT
-        path (classes.py:1160-1161); the transverse components are not built."""
-        return None, self._grid(self.device_fields.vy), None
+        """(v_x, v_y + v_lsr, v_z) [km/s] (classes.py:1009-1095).  Only v_y feeds the RT path
+        and stays resident; the transverse components are built on demand."""
+        if self._vxz is None:
+            geom = geometry_struct(self.params, self.nx, self.ny, self.nz)
+            tmp = self.engine.build_fields(geom, _lib.RJP_F64, want_ts=False, want_vy=False,
+                                           want_raw=False, want_vxz=True)
+            self._vxz = (self._grid(tmp.vx_raw), self._grid(tmp.vz_raw))
+        return self._vxz[0], self._grid(self.device_fields.vy), self._vxz[1]
 
     # ------------------------------------------------------------------ K1 cache ----
     def prefetch_epochs(self, times_s):
@@ -437,6 +443,30 @@ class JetModel:
         arr = self._map(out, (len(freqs),))
         return arr[0] if scalar else arr
 
+    def _cells(self, freq, savefits, rrl=None):
+        """collapse=False: un-summed per-cell optical depths, (n_x,n_y,n_z) for a scalar
+        frequency, (F,n_x,n_y,n_z) for an array (classes.py:1176-1177, 1382-1383)."""
+        from . import engine as E
+        if savefits:
+            # the reference's writer accepts 2-D / 3-D (freq, dec, ra) data only
+            raise ValueError("Unexpected number of data dimensions (4)")
+        scalar = np.isscalar(freq)
+        freqs = np.atleast_1d(np.asarray(freq, dtype=np.float64))
+        dev = self.device_fields
+        if rrl is None:
+            gv = None
+            if self.gff_mode == _lib.RJP_GFF_SCALAR:
+                gv = [mphys.gff(nu, self.params['properties']['T_0']) for nu in freqs]
+            ctau, _ = E.ff_channel_coeffs(freqs, self.csize, self.params["target"]["dist"],
+                                          self.gff_mode, gv)
+            out = self.engine.ff_cells(dev, self._rjp_bursts(), float(self.time),
+                                       self.gff_mode, ctau)
+        else:
+            out = self.engine.rrl_cells(dev, self._rjp_bursts(), float(self.time),
+                                        _lib.Line(**mrrl.line_constants(rrl)), freqs)
+        arr = out.cpu().numpy().reshape(len(freqs), self.nx, self.ny, self.nz)
+        return arr[0] if scalar else arr
+
     # ------------------------------------------------------------------ RT methods ----
     def emission_measure(self, savefits=False):
         """Emission measure along y [pc cm^-6] (classes.py:1101-1128)."""
@@ -449,8 +479,7 @@ class JetModel:
     def optical_depth_ff(self, freq, savefits=False, collapse=True):
         """Free-free optical depth along y (classes.py:1353-1447)."""
         if not collapse:
-            raise NotImplementedError("collapse=False (the 3-D per-cell optical depths) is "
-                                      "not produced by the line-of-sight scan kernels")
+            return self._cells(freq, savefits)
         tff = self._ff_products(freq, tau=True)
         self._save_cube(tff, savefits, 'tau', freq)
         return tff
@@ -475,8 +504,7 @@ class JetModel:
     def optical_depth_rrl(self, rrl, freq, lte=True, savefits=False, collapse=True):
         """RRL optical depth along y (classes.py:1130-1229)."""
         if not collapse:
-            raise NotImplementedError("collapse=False (the 3-D per-cell optical depths) is "
-                                      "not produced by the line-of-sight scan kernels")
+            return self._cells(freq, savefits, rrl=rrl)
         scalar = np.isscalar(freq)
         freqs = np.atleast_1d(np.asarray(freq, dtype=np.float64))
         tau = self._map(self._rrl_tau_device(rrl, freqs), (len(freqs),))

@@ -240,6 +240,48 @@ __global__ __launch_bounds__(kBlock) void sum_partials_kernel(const double* __re
   }
 }
 
+// collapse=False: the 3-D per-cell free-free optical depths (classes.py:1382-1383, 1395-1397).
+// out[f * ncell + cell] = ctau[f] * T^-1.5|-1.35 * (n chi x)^2 * pf, NaN outside the jet.
+template <typename T, int MODE, bool BURSTS>
+__global__ __launch_bounds__(kBlock) void ff_cells_kernel(FieldPtrs<T> f, int64_t ncell,
+                                                          BurstsDev b, double time_s,
+                                                          const double* __restrict__ ctau,
+                                                          int nchan, double* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= ncell) return;
+  const double nd = (double)f.nd[i], Tk = (double)f.temp[i];
+  double tpow = pow_m1p5(Tk);
+  if (MODE == RJP_GFF_POWERLAW) tpow *= pow(Tk, 0.15);
+  double chi = 1.0;
+  if (BURSTS) chi = chi_cell(b, signbit_d(nd), time_s - (double)f.ts[i]);
+  const double ne = fabs(nd) * chi * (double)f.xi[i];
+  const double a = ne * ne * (double)f.pf[i] * tpow;
+  for (int k = 0; k < nchan; ++k) out[(int64_t)k * ncell + i] = ctau[k] * a;
+}
+
+hipError_t ff_cells_launch(const rjp_fields* fl, const rjp_bursts* hb, double time_s, int mode,
+                           const double* d_ctau, int nchan, double* out, hipStream_t st) {
+  BurstsDev b;
+  const bool bursts = bursts_to_dev(hb, b);
+  if (bursts && !fl->d_ts) return hipErrorInvalidValue;
+  const int64_t n = (int64_t)fl->nx * fl->ny * fl->nz;
+  const dim3 grid((unsigned)((n + kBlock - 1) / kBlock)), blk(kBlock);
+  auto go = [&](auto tag) {
+    using T = decltype(tag);
+    FieldPtrs<T> f{(const T*)fl->d_nd, (const T*)fl->d_xi, (const T*)fl->d_temp,
+                   (const T*)fl->d_pf, (const T*)fl->d_ts};
+    if (mode == RJP_GFF_SCALAR) {
+      if (bursts) hipLaunchKernelGGL((ff_cells_kernel<T, 0, true>), grid, blk, 0, st, f, n, b, time_s, d_ctau, nchan, out);
+      else hipLaunchKernelGGL((ff_cells_kernel<T, 0, false>), grid, blk, 0, st, f, n, b, time_s, d_ctau, nchan, out);
+    } else {
+      if (bursts) hipLaunchKernelGGL((ff_cells_kernel<T, 1, true>), grid, blk, 0, st, f, n, b, time_s, d_ctau, nchan, out);
+      else hipLaunchKernelGGL((ff_cells_kernel<T, 1, false>), grid, blk, 0, st, f, n, b, time_s, d_ctau, nchan, out);
+    }
+  };
+  if (fl->dtype == RJP_F64) go(double{}); else go(float{});
+  return hipGetLastError();
+}
+
 // ---- launch helpers ---------------------------------------------------------------------
 static int choose_ysplit(int64_t nchunks, int ny) {
   static int forced = -1;
@@ -329,16 +371,7 @@ hipError_t ff_scan_launch(const rjp_fields* fl, const rjp_bursts* hb, const doub
                           int n_epochs, int mode, double* sumA, double* em, double* tavg,
                           double* ws, hipStream_t st) {
   BurstsDev b;
-  bool bursts = false;
-  for (int j = 0; j < 2; ++j) {
-    b.n[j] = hb ? hb->n[j] : 0;
-    if (b.n[j] > 0) bursts = true;
-    for (int i = 0; i < RJP_MAX_BURSTS; ++i) {
-      b.t0[j][i] = hb ? hb->t0[j][i] : 0.0;
-      b.amp_rel[j][i] = hb ? hb->amp_rel[j][i] : 0.0;
-      b.inv2s2[j][i] = hb ? hb->inv2s2[j][i] : 0.0;
-    }
-  }
+  const bool bursts = bursts_to_dev(hb, b);
   if (bursts && !fl->d_ts) return hipErrorInvalidValue;
   const int64_t npix = (int64_t)fl->nx * fl->nz;
   const int vec = ff_scan_vec(fl);

@@ -174,7 +174,8 @@ __device__ __forceinline__ double flow_time_antiderivative(const GeomDev& g, dou
 template <typename T>
 __global__ __launch_bounds__(kFB) void build_fields_kernel(GeomDev g, T* nd, T* xi, T* temp,
                                                            T* pf, T* ts, T* vy,
-                                                           double* ff_raw, double* areas_raw) {
+                                                           double* ff_raw, double* areas_raw,
+                                                           double* vx_raw, double* vz_raw) {
   const int64_t n = (int64_t)g.nx * g.ny * g.nz;
   const int64_t i = (int64_t)blockIdx.x * kFB + threadIdx.x;
   if (i >= n) return;
@@ -239,8 +240,8 @@ __global__ __launch_bounds__(kFB) void build_fields_kernel(GeomDev g, T* nd, T* 
     const double t_yr = (g.ts_const * pow(rad, g.ts_pow) - g.ts_base) / 31536000.0;
     ts[i] = (T)(t_yr * 31536000.0);
   }
-  if (vy) {
-    double out = nan;
+  if (vy || vx_raw || vz_raw) {
+    double out = nan, outx = nan, outz = nan;
     if (jet) {
       // classes.py:1056-1093
       double vz = powerlaw(g.v_0, rho_c, reff, g.R_1, g.q_v, g.qd_v);
@@ -255,10 +256,14 @@ __global__ __launch_bounds__(kFB) void build_fields_kernel(GeomDev g, T* nd, T* 
       const double vy0 = vr * cos(phi) * sgn;
       // xyz_rotate(order='xy') with (90 - inc, -pa): x-rotation then y-rotation; the
       // y-component after both is the x-rotated one
-      out = (g.ca2 * vy0 - g.sa2 * vz) + g.v_lsr;
-      (void)vx0;
+      const double y1 = g.ca2 * vy0 - g.sa2 * vz, z1 = g.sa2 * vy0 + g.ca2 * vz;
+      out = y1 + g.v_lsr;
+      outx = g.cb2 * vx0 + g.sb2 * z1;
+      outz = g.cb2 * z1 - g.sb2 * vx0;
     }
-    vy[i] = (T)out;
+    if (vy) vy[i] = (T)out;
+    if (vx_raw) vx_raw[i] = outx;
+    if (vz_raw) vz_raw[i] = outz;
   }
 }
 #pragma clang fp contract(fast)

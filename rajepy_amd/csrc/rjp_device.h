@@ -51,6 +51,22 @@ struct BurstsDev {
   double inv2s2[2][RJP_MAX_BURSTS];
 };
 
+// host: rjp_bursts -> kernel-argument copy; returns true when any burst is present
+static inline bool bursts_to_dev(const rjp_bursts* hb, BurstsDev& b) {
+  bool any = false;
+  for (int j = 0; j < 2; ++j) {
+    b.n[j] = hb ? hb->n[j] : 0;
+    if (b.n[j] > 0) any = true;
+    for (int i = 0; i < RJP_MAX_BURSTS; ++i) {
+      const bool live = hb && i < hb->n[j];
+      b.t0[j][i] = live ? hb->t0[j][i] : 0.0;
+      b.amp_rel[j][i] = live ? hb->amp_rel[j][i] : 0.0;   // unused slots contribute 0
+      b.inv2s2[j][i] = live ? hb->inv2s2[j][i] : 0.0;
+    }
+  }
+  return any;
+}
+
 // exp(x) for x <= 0, relative error < 1e-14 on [-708, 0] (clamped below: ~1e-308).
 // Cody-Waite reduction + degree-11 Taylor polynomial of exp(r), |r| <= ln2/2.  About 19 DP
 // instructions, no denormal/overflow paths (the argument is a Gaussian exponent).

@@ -268,6 +268,43 @@ int rjp_rrl_scan(rjp_ctx* ctx, const rjp_fields* fields, const rjp_bursts* burst
   return release_tables(ctx, st);
 }
 
+int rjp_ff_cells(rjp_ctx* ctx, const rjp_fields* fields, const rjp_bursts* bursts, double time_s,
+                 int32_t gff_mode, const double* h_ctau, int32_t n_chan, double* d_tau_cells,
+                 void* stream) {
+  if (int r = bind(ctx)) return r;
+  if (int r = check_fields(ctx, fields, false)) return r;
+  if (int r = check_bursts(ctx, bursts, fields)) return r;
+  if (!h_ctau || n_chan < 1 || !d_tau_cells)
+    return fail(ctx, RJP_ERR_ARG, "rjp_ff_cells: NULL table / output or n_chan < 1");
+  if (gff_mode != RJP_GFF_SCALAR && gff_mode != RJP_GFF_POWERLAW)
+    return fail(ctx, RJP_ERR_ARG, "bad gff_mode");
+  hipStream_t st = (hipStream_t)stream;
+  const double* src[1] = {h_ctau};
+  const size_t len[1] = {(size_t)n_chan};
+  double* dev[1];
+  if (int r = stage_tables(ctx, st, src, len, 1, dev)) return r;
+  RJP_HIP(ctx, rjp::ff_cells_launch(fields, bursts, time_s, gff_mode, dev[0], n_chan, d_tau_cells, st));
+  return release_tables(ctx, st);
+}
+
+int rjp_rrl_cells(rjp_ctx* ctx, const rjp_fields* fields, const rjp_bursts* bursts,
+                  double time_s, const rjp_line* line, const double* h_nu, int32_t n_chan,
+                  double* d_tau_cells, void* stream) {
+  if (int r = bind(ctx)) return r;
+  if (int r = check_fields(ctx, fields, true)) return r;
+  if (int r = check_bursts(ctx, bursts, fields)) return r;
+  if (!line || !h_nu || n_chan < 1 || !d_tau_cells)
+    return fail(ctx, RJP_ERR_ARG, "rjp_rrl_cells: NULL line / nu / output or n_chan < 1");
+  hipStream_t st = (hipStream_t)stream;
+  const double* src[1] = {h_nu};
+  const size_t len[1] = {(size_t)n_chan};
+  double* dev[1];
+  if (int r = stage_tables(ctx, st, src, len, 1, dev)) return r;
+  RJP_HIP(ctx, rjp::rrl_cells_launch(fields, bursts, time_s, line, h_nu, dev[0], n_chan,
+                                     d_tau_cells, st));
+  return release_tables(ctx, st);
+}
+
 int rjp_rrl_maps(rjp_ctx* ctx, const double* d_tau_rrl, const double* d_tau_ff,
                  const double* d_tavg, const double* d_flux_ff, int64_t n_pix,
                  const double* h_cflux_rrl, const double* h_hnu_k, int32_t n_chan,
@@ -290,7 +327,7 @@ int rjp_rrl_maps(rjp_ctx* ctx, const double* d_tau_rrl, const double* d_tau_ff,
 
 int rjp_build_fields(rjp_ctx* ctx, const rjp_geometry* gm, int dtype, void* d_nd, void* d_xi,
                      void* d_temp, void* d_pf, void* d_ts, void* d_vy, double* d_ff_raw,
-                     double* d_areas_raw, void* stream) {
+                     double* d_areas_raw, double* d_vx_raw, double* d_vz_raw, void* stream) {
   if (int r = bind(ctx)) return r;
   if (!gm) return fail(ctx, RJP_ERR_ARG, "geometry is NULL");
   if (dtype != RJP_F32 && dtype != RJP_F64) return fail(ctx, RJP_ERR_ARG, "bad dtype tag");
@@ -346,11 +383,11 @@ int rjp_build_fields(rjp_ctx* ctx, const rjp_geometry* gm, int dtype, void* d_nd
   if (dtype == RJP_F64)
     hipLaunchKernelGGL(rjp::build_fields_kernel<double>, dim3(blocks), dim3(rjp::kFB), 0, st, g,
                        (double*)d_nd, (double*)d_xi, (double*)d_temp, (double*)d_pf,
-                       (double*)d_ts, (double*)d_vy, d_ff_raw, d_areas_raw);
+                       (double*)d_ts, (double*)d_vy, d_ff_raw, d_areas_raw, d_vx_raw, d_vz_raw);
   else
     hipLaunchKernelGGL(rjp::build_fields_kernel<float>, dim3(blocks), dim3(rjp::kFB), 0, st, g,
                        (float*)d_nd, (float*)d_xi, (float*)d_temp, (float*)d_pf, (float*)d_ts,
-                       (float*)d_vy, d_ff_raw, d_areas_raw);
+                       (float*)d_vy, d_ff_raw, d_areas_raw, d_vx_raw, d_vz_raw);
   RJP_HIP(ctx, hipGetLastError());
   return RJP_OK;
 }

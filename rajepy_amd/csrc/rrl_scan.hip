@@ -202,6 +202,85 @@ struct LineDev {
   double dnu_max;      // max |nu_f - nu_ref| over all channels
 };
 
+// Per-cell line constants: everything of kappa_L * path that does not depend on the channel.
+struct CellLine {
+  double C = 0.0;      // LTE prefactor * path / (sigma sqrt(2 pi)); 0 = cell contributes nothing
+  double nu0 = 0.0;    // Doppler-shifted rest frequency [Hz]
+  double is2 = 0.0;    // 1 / (sigma sqrt 2) [1/Hz]
+  double y = 1.0;      // Voigt y = (fwhm_L / 2) / (sigma sqrt 2)
+  double a = 0.0;      // h / (k T) [1/Hz]
+  double E0 = 0.0;     // exp(-a nu_ref)
+  double q = -1.0, omq = 1.0, cq = 0.0;   // pole-term constants (see voigt_rew)
+};
+
+template <typename T, bool BURSTS>
+__device__ __forceinline__ CellLine cell_line(const RrlFields<T>& f, int64_t o,
+                                              const BurstsDev& b, double time_s,
+                                              const LineDev& ln) {
+  CellLine c;
+  const double kPiOverH = 3.14159265358979323846 / kH;
+  const double nd = (double)f.nd[o], xi = (double)f.xi[o], Tk = (double)f.temp[o],
+               pf = (double)f.pf[o], vy = (double)f.vy[o];
+  double chi = 1.0;
+  if (BURSTS) chi = chi_cell(b, signbit_d(nd), time_s - (double)f.ts[o]);
+  const double ne = fabs(nd) * chi * xi;
+  c.nu0 = ln.nu_rest * (1.0 - vy * 1000.0 / 299792458.0);          // physics.py:557-558
+  const double fwhm_g = ln.kG * sqrt(Tk) * c.nu0;                  // rrls.py:116-118
+  const double sigma = fwhm_g / 2.0 / 1.1774100225154747;          // / sqrt(2 ln 2)
+  c.is2 = 1.0 / (sigma * 1.4142135623730951);
+  const double fwhm_l = ln.kL * ne;                                // rrls.py:101
+  c.y = 0.5 * fwhm_l * c.is2;
+  c.a = ln.h_over_k / Tk;
+  // kappa_L * path without the profile and the stimulated-emission factor
+  c.C = ln.kappa0 * (ne * ne / (Tk * sqrt(Tk))) * exp(ln.en_over_k / Tk) *
+        (ln.path0 * pf) / (sigma * 2.5066282746310002);
+  c.E0 = exp(-c.a * ln.nu_ref);
+  const double lnq = -2.0 * kPiOverH * c.y;
+  c.q = (c.y < kPiOverH) ? exp(lnq) : -1.0;
+  c.omq = -expm1(lnq);
+  // pole term needed iff e + ln(6 q / D) > ln(1e-13 * y / (4 (|z|^2+1)))
+  c.cq = lnq + 1.7917594692280550 - log(0.25 * c.y) + 29.9336062089226;
+  if (!(c.C == c.C) || c.C == 0.0 || !(c.y > 0.0)) c.C = 0.0;     // nansum drops NaN terms
+  return c;
+}
+
+// kappa_L * path of one (cell, channel): C * Re w * (1 - exp(-h nu / kT))   (rrls.py:383-389)
+__device__ __forceinline__ double line_term(const CellLine& c, double nu_f, double dnu,
+                                            double dnu_max) {
+  const double xv = (nu_f - c.nu0) * c.is2;
+  const double V = voigt_rew(fabs(xv), c.y, c.q, c.omq, c.cq);
+  // 1 - exp(-h nu / kT) = 1 - E0 * exp(-a (nu - nu_ref))
+  const double eps = c.a * dnu;
+  double ex;
+  if (c.a * dnu_max < 1e-3)
+    ex = __builtin_fma(eps, __builtin_fma(eps, __builtin_fma(eps, -1.0 / 6.0, 0.5), -1.0), 1.0);
+  else
+    ex = exp(-eps);
+  return c.C * V * (1.0 - c.E0 * ex);
+}
+
+// collapse=False: the 3-D per-cell optical depths (classes.py:1176-1177, 1382-1383).  One
+// thread per cell, serial over channels; out[f * ncell + cell].
+template <typename T, bool BURSTS>
+__global__ __launch_bounds__(kRB) void rrl_cells_kernel(RrlFields<T> f, int64_t ncell,
+                                                        BurstsDev b, double time_s, LineDev ln,
+                                                        const double* __restrict__ nu, int nchan,
+                                                        double* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * kRB + threadIdx.x;
+  if (i >= ncell) return;
+  const CellLine c = cell_line<T, BURSTS>(f, i, b, time_s, ln);
+  const double nan = __builtin_nan("");
+  // a cell outside the jet is NaN in the reference's 3-D output (NaN fields propagate)
+  const bool dead = !((double)f.nd[i] == (double)f.nd[i]) || !((double)f.xi[i] == (double)f.xi[i]) ||
+                    !((double)f.temp[i] == (double)f.temp[i]) || !((double)f.pf[i] == (double)f.pf[i]) ||
+                    !((double)f.vy[i] == (double)f.vy[i]);
+  for (int k = 0; k < nchan; ++k) {
+    double v = nan;
+    if (!dead) v = c.C == 0.0 ? 0.0 : line_term(c, nu[k], nu[k] - ln.nu_ref, ln.dnu_max);
+    out[(int64_t)k * ncell + i] = v;
+  }
+}
+
 // LF = lanes along the channel axis (16, 64 or 256); G = kRB / LF sightline groups.
 // Tile = ZT z-adjacent sightlines (8 for LF = 256, else 16), slab = 256 / ZT y-rows.
 // The per-(sightline, channel) accumulators live in LDS, one slot per thread and sightline,
@@ -243,39 +322,16 @@ __global__ __launch_bounds__(kRB, RJP_K3_WAVES) void rrl_scan_kernel(
   for (int j = 0; j < NZP; ++j) s_acc[j * kRB + tid] = 0.0;
 
   const int cy = tid / ZT, cz = tid % ZT;       // this thread's cell in the slab (phase 1)
-  const double kPiOverH = 3.14159265358979323846 / kH;
 
   for (int yb = 0; yb < ny; yb += YC) {
     // ---- phase 1: per-cell line constants --------------------------------------------
     {
       const int yy = yb + cy, zz = z0 + cz;
-      double C = 0.0, nu0 = 0.0, is2 = 0.0, yv = 1.0, a = 0.0, E0 = 0.0, q = -1.0,
-             omq = 1.0, cq = 0.0;
-      if (yy < ny && zz < nz) {
-        const int64_t o = ((int64_t)x * ny + yy) * nz + zz;
-        const double nd = (double)f.nd[o], xi = (double)f.xi[o], Tk = (double)f.temp[o],
-                     pf = (double)f.pf[o], vy = (double)f.vy[o];
-        double chi = 1.0;
-        if (BURSTS) chi = chi_cell(b, signbit_d(nd), time_s - (double)f.ts[o]);
-        const double ne = fabs(nd) * chi * xi;
-        nu0 = ln.nu_rest * (1.0 - vy * 1000.0 / 299792458.0);        // physics.py:557-558
-        const double fwhm_g = ln.kG * sqrt(Tk) * nu0;                // rrls.py:116-118
-        const double sigma = fwhm_g / 2.0 / 1.1774100225154747;      // / sqrt(2 ln 2)
-        is2 = 1.0 / (sigma * 1.4142135623730951);
-        const double fwhm_l = ln.kL * ne;                            // rrls.py:101
-        yv = 0.5 * fwhm_l * is2;
-        a = ln.h_over_k / Tk;
-        // kappa_L * path without the profile and the stimulated-emission factor
-        C = ln.kappa0 * (ne * ne / (Tk * sqrt(Tk))) * exp(ln.en_over_k / Tk) *
-            (ln.path0 * pf) / (sigma * 2.5066282746310002);
-        E0 = exp(-a * ln.nu_ref);
-        const double lnq = -2.0 * kPiOverH * yv;
-        q = (yv < kPiOverH) ? exp(lnq) : -1.0;
-        omq = -expm1(lnq);
-        // pole term needed iff e + ln(6 q / D) > ln(1e-13 * y / (4 (|z|^2+1)))
-        cq = lnq + 1.7917594692280550 - log(0.25 * yv) + 29.9336062089226;
-        if (!(C == C) || C == 0.0 || !(yv > 0.0)) C = 0.0;           // nansum drops NaN terms
-      }
+      CellLine cl;
+      if (yy < ny && zz < nz)
+        cl = cell_line<T, BURSTS>(f, ((int64_t)x * ny + yy) * nz + zz, b, time_s, ln);
+      const double C = cl.C, nu0 = cl.nu0, is2 = cl.is2, yv = cl.y, a = cl.a, E0 = cl.E0,
+                   q = cl.q, omq = cl.omq, cq = cl.cq;
       s_C[tid] = C; s_nu0[tid] = nu0; s_is2[tid] = is2; s_y[tid] = yv; s_a[tid] = a;
       s_E0[tid] = E0; s_q[tid] = q; s_omq[tid] = omq; s_cq[tid] = cq;
     }
@@ -292,17 +348,10 @@ __global__ __launch_bounds__(kRB, RJP_K3_WAVES) void rrl_scan_kernel(
         bool live = C != 0.0;
         if (LF >= RJP_WAVE) live = __builtin_amdgcn_readfirstlane((int)live) != 0;
         if (live) {
-          const double xv = (nu_f - s_nu0[ci]) * s_is2[ci];
-          const double V = voigt_rew(fabs(xv), s_y[ci], s_q[ci], s_omq[ci], s_cq[ci]);
-          // 1 - exp(-h nu / kT) = 1 - E0 * exp(-a (nu - nu_ref))          (rrls.py:387)
-          const double a = s_a[ci];
-          const double eps = a * dnu;
-          double ex;
-          if (a * ln.dnu_max < 1e-3)
-            ex = __builtin_fma(eps, __builtin_fma(eps, __builtin_fma(eps, -1.0 / 6.0, 0.5), -1.0), 1.0);
-          else
-            ex = exp(-eps);
-          const double term = C * V * (1.0 - s_E0[ci] * ex);
+          CellLine cl;
+          cl.C = C; cl.nu0 = s_nu0[ci]; cl.is2 = s_is2[ci]; cl.y = s_y[ci]; cl.a = s_a[ci];
+          cl.E0 = s_E0[ci]; cl.q = s_q[ci]; cl.omq = s_omq[ci]; cl.cq = s_cq[ci];
+          const double term = line_term(cl, nu_f, dnu, ln.dnu_max);
           if (term == term) acc += term;
         }
       }
@@ -382,20 +431,10 @@ static hipError_t rrl_launch_lf(const rjp_fields* fl, const BurstsDev& b, bool b
 
 hipError_t rrl_scan_launch(const rjp_fields* fl, const rjp_bursts* hb, double time_s,
                            const rjp_line* line, const double* h_nu, const double* d_nu,
-                           int nchan, double* tau, hipStream_t st) {
-  BurstsDev b;
-  bool bursts = false;
-  for (int j = 0; j < 2; ++j) {
-    b.n[j] = hb ? hb->n[j] : 0;
-    if (b.n[j] > 0) bursts = true;
-    for (int i = 0; i < RJP_MAX_BURSTS; ++i) {
-      b.t0[j][i] = hb ? hb->t0[j][i] : 0.0;
-      b.amp_rel[j][i] = hb ? hb->amp_rel[j][i] : 0.0;
-      b.inv2s2[j][i] = hb ? hb->inv2s2[j][i] : 0.0;
-    }
-  }
-  if (bursts && !fl->d_ts) return hipErrorInvalidValue;
-  LineDev ln;
+                           int nchan, double* tau, hipStream_t st);
+
+static void fill_line(const rjp_fields* fl, const rjp_line* line, const double* h_nu, int nchan,
+                      LineDev& ln) {
   ln.nu_rest = line->nu_rest; ln.kG = line->kG; ln.kL = line->kL; ln.kappa0 = line->kappa0;
   ln.en_over_k = line->en_over_k; ln.h_over_k = line->h_over_k;
   ln.path0 = fl->csize_au * 149597870700.0 * 1e2;
@@ -403,6 +442,41 @@ hipError_t rrl_scan_launch(const rjp_fields* fl, const rjp_bursts* hb, double ti
   for (int i = 1; i < nchan; ++i) { lo = h_nu[i] < lo ? h_nu[i] : lo; hi = h_nu[i] > hi ? h_nu[i] : hi; }
   ln.nu_ref = 0.5 * (lo + hi);
   ln.dnu_max = 0.5 * (hi - lo);
+}
+
+hipError_t rrl_cells_launch(const rjp_fields* fl, const rjp_bursts* hb, double time_s,
+                            const rjp_line* line, const double* h_nu, const double* d_nu,
+                            int nchan, double* out, hipStream_t st) {
+  BurstsDev b;
+  const bool bursts = bursts_to_dev(hb, b);
+  if (bursts && !fl->d_ts) return hipErrorInvalidValue;
+  LineDev ln;
+  fill_line(fl, line, h_nu, nchan, ln);
+  const int64_t n = (int64_t)fl->nx * fl->ny * fl->nz;
+  const unsigned blocks = (unsigned)((n + kRB - 1) / kRB);
+  auto go = [&](auto tag) {
+    using T = decltype(tag);
+    RrlFields<T> f{(const T*)fl->d_nd, (const T*)fl->d_xi, (const T*)fl->d_temp,
+                   (const T*)fl->d_pf, (const T*)fl->d_ts, (const T*)fl->d_vy};
+    if (bursts)
+      hipLaunchKernelGGL((rrl_cells_kernel<T, true>), dim3(blocks), dim3(kRB), 0, st, f, n, b,
+                         time_s, ln, d_nu, nchan, out);
+    else
+      hipLaunchKernelGGL((rrl_cells_kernel<T, false>), dim3(blocks), dim3(kRB), 0, st, f, n, b,
+                         time_s, ln, d_nu, nchan, out);
+  };
+  if (fl->dtype == RJP_F64) go(double{}); else go(float{});
+  return hipGetLastError();
+}
+
+hipError_t rrl_scan_launch(const rjp_fields* fl, const rjp_bursts* hb, double time_s,
+                           const rjp_line* line, const double* h_nu, const double* d_nu,
+                           int nchan, double* tau, hipStream_t st) {
+  BurstsDev b;
+  const bool bursts = bursts_to_dev(hb, b);
+  if (bursts && !fl->d_ts) return hipErrorInvalidValue;
+  LineDev ln;
+  fill_line(fl, line, h_nu, nchan, ln);
   if (fl->dtype == RJP_F64)
     return rrl_launch_lf<double>(fl, b, bursts, time_s, ln, d_nu, nchan, tau, st);
   return rrl_launch_lf<float>(fl, b, bursts, time_s, ln, d_nu, nchan, tau, st);

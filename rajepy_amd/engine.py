@@ -168,7 +168,8 @@ class RTEngine:
         self.synchronize()
         setattr(fields, name, dst)
 
-    def build_fields(self, geom, dtype=RJP_F64, want_ts=True, want_vy=True, want_raw=True):
+    def build_fields(self, geom, dtype=RJP_F64, want_ts=True, want_vy=True, want_raw=True,
+                     want_vxz=False):
         """K4: geometry -> packed fields on the device (`geom` is a _lib.Geometry)."""
         n = geom.nx * geom.ny * geom.nz
         nd, xi, temp, pf = (self._empty(n, dtype) for _ in range(4))
@@ -176,14 +177,19 @@ class RTEngine:
         vy = self._empty(n, dtype) if want_vy else None
         ffr = self._f64(n) if want_raw else None
         arr = self._f64(n) if want_raw else None
+        vxr = self._f64(n) if want_vxz else None
+        vzr = self._f64(n) if want_vxz else None
         _lib.check(self.lib.rjp_build_fields(
             self.ctx, C.byref(geom), dtype, nd.data_ptr(), xi.data_ptr(), temp.data_ptr(),
             pf.data_ptr(), ts.data_ptr() if want_ts else None,
             vy.data_ptr() if want_vy else None, ffr.data_ptr() if want_raw else None,
-            arr.data_ptr() if want_raw else None, self._stream()), self.ctx,
+            arr.data_ptr() if want_raw else None, vxr.data_ptr() if want_vxz else None,
+            vzr.data_ptr() if want_vxz else None, self._stream()), self.ctx,
             "rjp_build_fields")
-        return DeviceFields((geom.nx, geom.ny, geom.nz), dtype, geom.csize, nd, xi, temp, pf,
-                            ts, vy, ffr, arr)
+        out = DeviceFields((geom.nx, geom.ny, geom.nz), dtype, geom.csize, nd, xi, temp, pf,
+                           ts, vy, ffr, arr)
+        out.vx_raw, out.vz_raw = vxr, vzr
+        return out
 
     def synth_fields(self, shape, seed, temp_mode=0, dtype=RJP_F64, csize_au=0.5,
                      with_vy=False, cell0=0):
@@ -262,6 +268,28 @@ class RTEngine:
             ptr(ftot), ptr(work), work.numel() if work is not None else 0, self._stream()),
             self.ctx, "rjp_ff_maps")
         return tau, flux, ftot
+
+    def ff_cells(self, fields, bursts, time_s, gff_mode, ctau):
+        """collapse=False: per-cell free-free optical depths -> device tensor [F, N]."""
+        F = len(ctau)
+        out = self._f64(F, fields.ncells)
+        fs = fields.struct()
+        _lib.check(self.lib.rjp_ff_cells(
+            self.ctx, C.byref(fs), C.byref(bursts) if bursts is not None else None,
+            float(time_s), int(gff_mode), _lib.dbl_array(ctau), F, out.data_ptr(),
+            self._stream()), self.ctx, "rjp_ff_cells")
+        return out
+
+    def rrl_cells(self, fields, bursts, time_s, line, nus):
+        """collapse=False: per-cell RRL optical depths -> device tensor [F, N]."""
+        F = len(nus)
+        out = self._f64(F, fields.ncells)
+        fs = fields.struct()
+        _lib.check(self.lib.rjp_rrl_cells(
+            self.ctx, C.byref(fs), C.byref(bursts) if bursts is not None else None,
+            float(time_s), C.byref(line), _lib.dbl_array(nus), F, out.data_ptr(),
+            self._stream()), self.ctx, "rjp_rrl_cells")
+        return out
 
     # -- K3 ------------------------------------------------------------------------------------
     def rrl_scan(self, fields, bursts, time_s, line, nus):

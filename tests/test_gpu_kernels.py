@@ -198,7 +198,7 @@ def test_field_builder_vs_reference(eng, tag):
     z, meta, p = U.load_golden(tag)
     jet = orc.OracleJet(p)                      # derived params (mod_r_0, q_n, n_0 ...)
     geom = geometry_struct(jet.params, jet.nx, jet.ny, jet.nz)
-    f = eng.build_fields(geom, 8, want_ts=True)     # tilted: q^d_v != 0 -> device 2F1
+    f = eng.build_fields(geom, 8, want_ts=True, want_vxz=True)   # tilted: device 2F1
     eng.synchronize()
     idx = z["f_idx"]
     ff = f.ff_raw.cpu().numpy()
@@ -214,6 +214,8 @@ def test_field_builder_vs_reference(eng, tag):
         np.testing.assert_allclose(got[idx], z["f_" + key], rtol=1e-11, atol=1e-12, err_msg=name)
         assert not np.isfinite(np.delete(got, idx)).any()
     np.testing.assert_allclose(f.pf.cpu().numpy()[idx], z["f_ff"] / z["f_areas"], rtol=0)
+    np.testing.assert_allclose(f.vx_raw.cpu().numpy()[idx], z["f_vx"], rtol=1e-11, atol=1e-12)
+    np.testing.assert_allclose(f.vz_raw.cpu().numpy()[idx], z["f_vz"], rtol=1e-11, atol=1e-12)
     np.testing.assert_allclose(f.ts.cpu().numpy()[idx], z["f_ts0"], rtol=1e-10, atol=1e-3)
 
 

@@ -88,6 +88,35 @@ def test_jetmodel_setters_and_accessors(tmp_path):
                                jm2.optical_depth_ff(5e9) * 4.0 * 4.0 ** -1.5, rtol=1e-9)
 
 
+def test_collapse_false_and_vel(tmp_path):
+    """collapse=False returns the un-summed per-cell optical depths whose y-sum is the map;
+    vel returns all three components (tilted model: every rotation term is exercised)."""
+    from oracle import rt_oracle as orc
+    z, meta, p, g, jet = U.golden_dense("tilted")
+    jm = classes.JetModel(tilted_params(), log=logger.Log(str(tmp_path / "a.log"), verbose=False))
+    jm.time = jet.time = 0.4 * YEAR
+    freqs = z["freqs"]
+    cells = jm.optical_depth_ff(freqs, collapse=False)
+    assert cells.shape == (len(freqs), jm.nx, jm.ny, jm.nz)
+    ref = jet.optical_depth_ff(freqs, collapse=False)
+    assert np.array_equal(np.isnan(cells), np.isnan(ref))
+    np.testing.assert_allclose(cells, ref, rtol=1e-9)
+    np.testing.assert_allclose(np.nansum(cells, axis=2), jm.optical_depth_ff(freqs), rtol=1e-12)
+    one = jm.optical_depth_ff(float(freqs[0]), collapse=False)
+    assert one.shape == (jm.nx, jm.ny, jm.nz)
+    rf = z["rrl_freqs"]
+    rc = jm.optical_depth_rrl(meta["rrl"], rf, collapse=False)
+    rref = jet.optical_depth_rrl(meta["rrl"], rf, collapse=False)
+    assert np.array_equal(np.isnan(rc), np.isnan(rref))
+    np.testing.assert_allclose(rc, rref, rtol=1e-8, atol=1e-300)
+    with pytest.raises(ValueError):
+        jm.optical_depth_ff(freqs, collapse=False, savefits=str(tmp_path / "x.fits"))
+    vx, vy, vz = jm.vel
+    idx = z["f_idx"]
+    for got, key in ((vx, "vx"), (vy, "vy"), (vz, "vz")):
+        np.testing.assert_allclose(got.ravel()[idx], z["f_" + key], rtol=1e-11, atol=1e-12)
+
+
 def test_pipeline_execute_matches_reference_products(tmp_path):
     """`main.py -rt` flow on config 1: same tree, same run results, FITS headers identical
     and data within 1e-9 of the reference's files."""

@@ -55,6 +55,7 @@ def test_abi_struct_layouts_match_header():
     assert ctypes.sizeof(_lib.Bursts) == 8 + 3 * 2 * 8 * 8
     assert ctypes.sizeof(_lib.Line) == 6 * 8
     assert ctypes.sizeof(_lib.Geometry) == 4 * 4 + 24 * 8
+    assert _lib.Geometry.rb_frac.offset == 4 * 4 + 23 * 8
 
 
 def test_no_gpu_fails_loudly_not_silently():
