@@ -52,6 +52,10 @@ def parse():
                     choices=sorted(CONFIGS))
     ap.add_argument("--storage", default="f64", choices=("f64", "f32"))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--sharding", default="epochs", choices=("epochs", "xslab"),
+                    help="N>1: epochs = one epoch of the full grid per rank (weak scaling, the "
+                         "default); xslab = the ONE grid split into n_x/N row slabs (strong "
+                         "scaling, per-channel fluxes all_reduced)")
     ap.add_argument("--backend", default="nccl", choices=("nccl", "gloo"),
                     help="gloo = rehearsal of the N>1 path (e.g. several ranks on one GPU)")
     ap.add_argument("--share-gpu", action="store_true",
@@ -124,7 +128,7 @@ def main():
     import torch.distributed as dist
     from rajepy_amd import _lib, engine as E
     from rajepy_amd.maths import physics as ph, rrls
-    from rajepy_amd.parallel import EpochShards, gather_flux_vs_time
+    from rajepy_amd.parallel import EpochShards, SlabShards, gather_flux_vs_time
     from tests import gpu_util as U            # burst parameters of the example model
 
     if args.share_gpu:
@@ -141,11 +145,19 @@ def main():
     shape, nchan, n_ep_cfg, kind = CONFIGS[args.config]
     dtype = E.RJP_F64 if args.storage == "f64" else E.RJP_F32
     seed = 20240504
-    ncell = shape[0] * shape[1] * shape[2]
-    P = shape[0] * shape[2]
+    ncell = shape[0] * shape[1] * shape[2]          # cells of the whole grid
     rrl = kind == "rrl"
+    xslab = args.sharding == "xslab" and world > 1
+    if xslab:
+        x0, x1 = SlabShards(shape[0], world).bounds[rank]
+        lshape = (x1 - x0, shape[1], shape[2])
+        cell0 = x0 * shape[1] * shape[2]
+    else:
+        lshape, cell0 = shape, 0
+    P = lshape[0] * lshape[2]
+    ncell_loc = lshape[0] * lshape[1] * lshape[2]
 
-    fields = eng.synth_fields(shape, seed, 0, dtype, csize_au=0.5, with_vy=rrl)
+    fields = eng.synth_fields(lshape, seed, 0, dtype, csize_au=0.5, with_vy=rrl, cell0=cell0)
     ej = U.example_bursts_params()
     red, blue = [], []
     for t0, hl, chi, which in zip(ej["t_0"], ej["hl"], ej["chi"], ej["which"]):
@@ -169,10 +181,12 @@ def main():
     # step (weak scaling over the burst-time sweep)
     if n_ep_cfg:
         epochs = np.linspace(0., 5., n_ep_cfg) * YEAR
+    elif xslab:
+        epochs = np.array([1.0 * YEAR])
     else:
         epochs = np.linspace(0., 5., world) * YEAR if world > 1 else np.array([1.0 * YEAR])
-    shards = EpochShards(epochs, world)
-    my_epochs = [float(t) for t in shards.local(rank)]
+    shards = EpochShards(epochs, 1 if xslab else world)
+    my_epochs = [float(t) for t in shards.local(0 if xslab else rank)]
     E_loc = len(my_epochs)
 
     sumA = eng._f64(E_loc, P)
@@ -194,6 +208,14 @@ def main():
             _, res = eng.rrl_maps(tau_rrl, tau.reshape(nchan, P), tavg, flux.reshape(nchan, P),
                                   cfl_rrl, hnu_k)
             res = res.reshape(1, nchan)
+        if xslab:                 # partial per-channel fluxes of this slab -> whole-map totals
+            if args.backend == "nccl":
+                dist.all_reduce(res)
+            else:
+                tmp = res.cpu()
+                dist.all_reduce(tmp)
+                res = tmp.to(res.device)
+            return res
         return gather_flux_vs_time(res, shards, rank) if world > 1 else res
 
     def fence():
@@ -229,12 +251,12 @@ def main():
         k_ms = ev0.elapsed_time(ev1) / 2
         # K3 is vector-ALU bound by construction (SURVEY.md finding 3): report its HBM rate
         # against the HBM peak anyway and the Voigt-evaluation rate beside it
-        alg_bytes = 6 * ncell * int(dtype) + nchan * P * 8
-        kname, extra = "rrl_scan_kernel", {"voigt_evals_per_s": ncell * nchan / (k_ms * 1e-3)}
+        alg_bytes = 6 * ncell_loc * int(dtype) + nchan * P * 8
+        kname, extra = "rrl_scan_kernel", {"voigt_evals_per_s": ncell_loc * nchan / (k_ms * 1e-3)}
     else:
         k_ms = eng.time_ff_scan(fields, bursts, my_epochs, E.RJP_GFF_SCALAR, reps=5)
         npass = -(-E_loc // 8) if E_loc > 1 else 1        # epoch tiles of <= 8 share a pass
-        alg_bytes = npass * 5 * ncell * int(dtype) + E_loc * P * 2 * 8
+        alg_bytes = npass * 5 * ncell_loc * int(dtype) + E_loc * P * 2 * 8
         kname, extra = "ff_scan_kernel", {"grid_passes_per_launch": npass}
     achieved = alg_bytes / (k_ms * 1e-3) / 1e9
     traffic = None
@@ -253,7 +275,7 @@ def main():
         "metric": "Mvoxel-freq/s", "value": value, "unit": "Mvoxel-freq/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": ms_step, "higher_is_better": True,
-        "scaling": "strong" if n_ep_cfg else "weak",
+        "scaling": "strong" if (n_ep_cfg or xslab) else "weak",
         "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": "%s: %dx%dx%d grid x %d %s, %d epoch(s) per step, %s"
                                % ((args.config,) + shape + (
@@ -262,8 +284,9 @@ def main():
                                    "K3 RRL scan + K1/K2 continuum + line flux cube" if rrl else
                                    "K1 scan + K2 flux-vs-time" if n_ep_cfg else
                                    "K1 scan + K2 tau/flux cubes")),
-                   "storage": args.storage, "sharding": "epochs" if world > 1 else "none",
-                   "gather": "all_gather of flux-vs-time [E,F]" if world > 1 else "none"},
+                   "storage": args.storage, "sharding": ("xslab" if xslab else "epochs") if world > 1 else "none",
+                   "gather": ("all_reduce of per-channel fluxes [E,F]" if xslab else
+                              "all_gather of flux-vs-time [E,F]") if world > 1 else "none"},
         "roofline": roofline,
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -186,6 +186,9 @@ typedef struct rjp_geometry {
   double q_n, q_x, q_T, q_v;          /* power laws along r */
   double qd_n, qd_x, qd_T, qd_v;      /* power laws across the jet */
   double rb_frac;             /* mlr_rj / mlr_bj (classes.py:228-229, 895) */
+  /* x-slab sharding: build rows [ix0, ix0 + nx) of a grid that is nx_total rows wide
+   * (cell x-coordinate = csize * (ix0 + i_x - nx_total / 2)); nx_total = 0 means nx. */
+  int32_t ix0, nx_total;
 } rjp_geometry;
 
 /* d_vy / d_ts may be NULL to skip them; d_ff_raw / d_areas_raw (float64, optional) receive

@@ -53,7 +53,8 @@ class Geometry(C.Structure):
                 ("q_n", C.c_double), ("q_x", C.c_double), ("q_T", C.c_double),
                 ("q_v", C.c_double),
                 ("qd_n", C.c_double), ("qd_x", C.c_double), ("qd_T", C.c_double),
-                ("qd_v", C.c_double), ("rb_frac", C.c_double)]
+                ("qd_v", C.c_double), ("rb_frac", C.c_double),
+                ("ix0", C.c_int32), ("nx_total", C.c_int32)]
 
 
 _P = C.c_void_p

@@ -27,8 +27,9 @@ from .miscellaneous import functions as miscf
 _STORAGE = {'f64': _lib.RJP_F64, 'f32': _lib.RJP_F32, 8: _lib.RJP_F64, 4: _lib.RJP_F32}
 
 
-def geometry_struct(params, nx, ny, nz):
-    """`rjp_geometry` (include/rjprt.h) from a model params dict with derived keys."""
+def geometry_struct(params, nx, ny, nz, ix0=0, nx_total=0):
+    """`rjp_geometry` (include/rjprt.h) from a model params dict with derived keys; with
+    `ix0`/`nx_total` only rows [ix0, ix0+nx) of an nx_total-wide grid are described."""
     g, t, pl, pr = (params['geometry'], params['target'], params['power_laws'],
                     params['properties'])
     s = _lib.Geometry()
@@ -42,6 +43,7 @@ def geometry_struct(params, nx, ny, nz):
     s.q_n, s.q_x, s.q_T, s.q_v = pl['q_n'], pl['q_x'], pl['q_T'], pl['q_v']
     s.qd_n, s.qd_x, s.qd_T, s.qd_v = pl['q^d_n'], pl['q^d_x'], pl['q^d_T'], pl['q^d_v']
     s.rb_frac = pr['mlr_rj'] / pr['mlr_bj']
+    s.ix0, s.nx_total = int(ix0), int(nx_total)
     return s
 
 

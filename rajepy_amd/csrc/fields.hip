@@ -96,6 +96,7 @@ hipError_t synth_launch(uint64_t seed, int temp_mode, int nz, int64_t cell0, int
 // (NumPy) and passed in, as the reference does (maths/geometry.py:249-253).
 struct GeomDev {
   int nx, ny, nz, ccw;
+  int ix0, nx_total;              // x-slab: rows [ix0, ix0+nx) of an nx_total-wide grid
   double cs;
   double ca, sa, cb, sb;          // derotation: alpha = inc - 90 (about x), beta = pa (about y)
   double ca2, sa2, cb2, sb2;      // velocity rotation: alpha = 90 - inc, beta = -pa
@@ -183,7 +184,7 @@ __global__ __launch_bounds__(kFB) void build_fields_kernel(GeomDev g, T* nd, T* 
   const int iy = (int)((i / g.nz) % g.ny);
   const int ix = (int)(i / ((int64_t)g.nz * g.ny));
   // classes.py:497-499: bottom-left-front corner
-  const double x0 = g.cs * (ix - g.nx / 2), y0 = g.cs * (iy - g.ny / 2),
+  const double x0 = g.cs * (g.ix0 + ix - g.nx_total / 2), y0 = g.cs * (iy - g.ny / 2),
                z0 = g.cs * (iz - g.nz / 2);
 
   int n_in = 0;

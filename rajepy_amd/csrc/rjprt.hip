@@ -336,6 +336,10 @@ int rjp_build_fields(rjp_ctx* ctx, const rjp_geometry* gm, int dtype, void* d_nd
   const double au = 149597870700.0, d2r = M_PI / 180.0;
   rjp::GeomDev g;
   g.nx = gm->nx; g.ny = gm->ny; g.nz = gm->nz; g.ccw = gm->rotation_ccw;
+  g.nx_total = gm->nx_total > 0 ? gm->nx_total : gm->nx;
+  g.ix0 = gm->ix0;
+  if (g.ix0 < 0 || g.ix0 + g.nx > g.nx_total)
+    return fail(ctx, RJP_ERR_ARG, "rjp_build_fields: x-slab [ix0, ix0+nx) outside [0, nx_total)");
   g.cs = gm->csize;
   // numpy.radians(x) = x * (pi/180); cos/sin in libm double, as maths/geometry.py:249-253
   const double a = (gm->inc - 90.) * d2r, b = gm->pa * d2r;

@@ -176,3 +176,57 @@ def sweep_channel_sharded(model, freqs, rank=0, world=1, root=0, group=None, kin
                             device=model.engine.device)
     full = gather_to_root(block, shards, rank, axis=0, root=root, group=group)
     return None if full is None else full.cpu().numpy()
+
+
+def xslab_local(model, epochs_s, freqs, rank, world, want_maps=True):
+    """This rank's share of an x-slab sharded continuum sweep: build rows [x0, x1) of the
+    model grid on the local GPU (K4 with an x offset -- the grid is never replicated), scan
+    them and run the map stage for every channel.  Returns (x-range, tau[E,F,nx_loc,n_z] or
+    None, flux[...] or None, ftot_partial[E,F]) as device tensors."""
+    from . import engine as E
+    from .classes import geometry_struct
+    from .maths import physics as mphys
+    x0, x1 = SlabShards(model.nx, world).bounds[rank]
+    eng = model.engine
+    freqs = np.atleast_1d(np.asarray(freqs, dtype=np.float64))
+    epochs = [float(t) for t in epochs_s]
+    F, Ep = len(freqs), len(epochs)
+    if x1 == x0:
+        return (x0, x1), None, None, eng._f64(Ep, F).zero_()
+    geom = geometry_struct(model.params, x1 - x0, model.ny, model.nz, ix0=x0,
+                           nx_total=model.nx)
+    dev = eng.build_fields(geom, model._dtype, want_ts=True, want_vy=False, want_raw=False)
+    gv = None
+    if model.gff_mode == E.RJP_GFF_SCALAR:
+        gv = [mphys.gff(nu, model.params['properties']['T_0']) for nu in freqs]
+    ctau, cflux = E.ff_channel_coeffs(freqs, model.csize, model.params["target"]["dist"],
+                                      model.gff_mode, gv)
+    sumA, _, tavg = eng.ff_scan(dev, model._rjp_bursts(), epochs, model.gff_mode,
+                                want_em=False)
+    tau, flux, ftot = eng.ff_maps(sumA, tavg, ctau, cflux, want_tau=want_maps,
+                                  want_flux=want_maps, want_ftot=True)
+    shp = (Ep, F, x1 - x0, model.nz)
+    return ((x0, x1), tau.reshape(shp) if want_maps else None,
+            flux.reshape(shp) if want_maps else None, ftot)
+
+
+def sweep_xslab(model, epochs_s, freqs, rank=0, world=1, gather_maps=False, group=None):
+    """x-slab sharded sweep (strong scaling of one model): every rank scans n_x/world rows.
+    The per-channel total fluxes are summed over ranks (one all_reduce of [E,F]); with
+    `gather_maps` the tau / flux slabs are all_gathered along x as well.
+    Returns (ftot[E,F] host array, tau or None, flux or None)."""
+    dist = _dist()
+    _, tau, flux, ftot = xslab_local(model, epochs_s, freqs, rank, world, want_maps=gather_maps)
+    if world > 1:
+        if ftot.is_cuda and dist.get_backend(group) == "gloo":
+            t = ftot.cpu()
+            dist.all_reduce(t, group=group)
+            ftot = t
+        else:
+            dist.all_reduce(ftot, group=group)
+    out_t = out_f = None
+    if gather_maps:
+        slabs = SlabShards(model.nx, world)
+        out_t = all_gather_blocks(tau, slabs, rank, axis=2, group=group).cpu().numpy()
+        out_f = all_gather_blocks(flux, slabs, rank, axis=2, group=group).cpu().numpy()
+    return ftot.cpu().numpy(), out_t, out_f

@@ -231,3 +231,56 @@ def test_field_builder_refuses_degenerate_2f1(eng):
     with pytest.raises(_lib.RjprtError, match="degenerate"):
         eng.build_fields(geom, 8, want_ts=True)
     eng.build_fields(geom, 8, want_ts=False)
+
+
+def test_abi_error_reporting(eng):
+    """Every entry point returns a negative status + message instead of crashing on bad
+    arguments (include/rjprt.h conventions)."""
+    import ctypes as C
+    from rajepy_amd import _lib, engine as E
+    lib = eng.lib
+    fields = eng.synth_fields((2, 8, 8), 1, 0, 8)
+    fs = fields.struct()
+    ep = _lib.dbl_array([0.0])
+    out = eng._f64(1, 16)
+    tavg = eng._f64(16)
+    work = eng._workspace(lib.rjp_ff_scan_workspace(2, 8, 8, 1))
+    st = eng._stream()
+    call = lambda **kw: None
+
+    def scan(f=fs, e=ep, ne=1, mode=0, o=out, w=work, wb=None):
+        return lib.rjp_ff_scan(eng.ctx, C.byref(f) if f is not None else None, None, e, ne, mode,
+                               o.data_ptr() if o is not None else None, None, tavg.data_ptr(),
+                               w.data_ptr() if w is not None else None,
+                               w.numel() if wb is None else wb, st)
+    assert scan() == 0
+    assert scan(f=None) == -1 and b"fields" in lib.rjp_last_error(eng.ctx)
+    assert scan(ne=0) == -1
+    assert scan(mode=7) == -1 and b"gff_mode" in lib.rjp_last_error(eng.ctx)
+    assert scan(o=None) == -1
+    assert scan(wb=16) == -4 and b"workspace" in lib.rjp_last_error(eng.ctx)
+    bad = fields.struct()
+    bad.dtype = 3
+    assert scan(f=bad) == -1 and b"dtype" in lib.rjp_last_error(eng.ctx)
+    bad = fields.struct()
+    bad.ny = 0
+    assert scan(f=bad) == -1
+    # bursts without launch times
+    nots = fields.struct()
+    nots.d_ts = None
+    b = E.make_bursts([(1.0, 2.0, 3.0)], [])
+    assert lib.rjp_ff_scan(eng.ctx, C.byref(nots), C.byref(b), ep, 1, 0, out.data_ptr(), None,
+                           tavg.data_ptr(), work.data_ptr(), work.numel(), st) == -1
+    # RRL needs vy
+    line = _lib.Line(1e10, 1e-6, 1.0, 1e-12, -30.0, 4.8e-11)
+    assert lib.rjp_rrl_scan(eng.ctx, C.byref(fs), None, 0.0, C.byref(line),
+                            _lib.dbl_array([1e10]), 1, out.data_ptr(), st) == -1
+    assert b"vy" in lib.rjp_last_error(eng.ctx)
+    with pytest.raises(ValueError):
+        E.make_bursts([(0., 1., 1.)] * 9, [])
+    with pytest.raises(_lib.RjprtError):
+        _lib.check(-2, eng.ctx, "demo")
+    # out-of-range device index
+    ctx = C.c_void_p()
+    assert lib.rjp_ctx_create(10 ** 6, C.byref(ctx)) == -1
+    eng.synchronize()

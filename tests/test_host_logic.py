@@ -54,7 +54,7 @@ def test_abi_struct_layouts_match_header():
     assert ctypes.sizeof(_lib.Fields) == 6 * 8 + 4 * 4 + 8
     assert ctypes.sizeof(_lib.Bursts) == 8 + 3 * 2 * 8 * 8
     assert ctypes.sizeof(_lib.Line) == 6 * 8
-    assert ctypes.sizeof(_lib.Geometry) == 4 * 4 + 24 * 8
+    assert ctypes.sizeof(_lib.Geometry) == 4 * 4 + 24 * 8 + 2 * 4
     assert _lib.Geometry.rb_frac.offset == 4 * 4 + 23 * 8
 
 
