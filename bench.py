@@ -43,6 +43,12 @@ CONFIGS = {
 }
 
 
+# the four ejection bursts of the reference's example model
+# (files/example-model-params.py:51-54): peak time [yr], FWHM [yr], burst factor, jet(s)
+EXAMPLE_BURSTS = {"t_0": [0.5, 0.75, 1., 2.], "hl": [0.15, 0.15, 0.45, 0.5],
+                  "chi": [5., 5., 2.5, 10.], "which": ["R", "B", "B", "RB"]}
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -129,7 +135,6 @@ def main():
     from rajepy_amd import _lib, engine as E
     from rajepy_amd.maths import physics as ph, rrls
     from rajepy_amd.parallel import EpochShards, SlabShards, gather_flux_vs_time
-    from tests import gpu_util as U            # burst parameters of the example model
 
     if args.share_gpu:
         local = 0
@@ -158,7 +163,7 @@ def main():
     ncell_loc = lshape[0] * lshape[1] * lshape[2]
 
     fields = eng.synth_fields(lshape, seed, 0, dtype, csize_au=0.5, with_vy=rrl, cell0=cell0)
-    ej = U.example_bursts_params()
+    ej = EXAMPLE_BURSTS
     red, blue = [], []
     for t0, hl, chi, which in zip(ej["t_0"], ej["hl"], ej["chi"], ej["which"]):
         sig = hl * YEAR * 2. / (2. * np.sqrt(2. * np.log(2.)))

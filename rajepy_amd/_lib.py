@@ -99,6 +99,10 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # PyTorch ships its own ROCm runtime (torch/lib/libamdhip64.so); it must be the one the
+    # process binds, so torch is imported BEFORE librjprt.so pulls in a HIP runtime by
+    # SONAME -- two runtimes in one process do not see each other's devices or pointers.
+    import torch  # noqa: F401
     if not os.path.exists(LIB_PATH):
         raise RjprtError(
             "%s not found: the HIP library has not been built (rajepy_amd/csrc/build.sh). "

@@ -30,8 +30,11 @@ struct EpochTile { double t[ET]; };
 constexpr int kBlock = 256;
 // y-rows of loads kept in flight per lane; fewer when many accumulators are live so the
 // kernel stays inside the 256-VGPR budget without scratch
+#ifndef RJP_UNROLL_BASE
+#define RJP_UNROLL_BASE 4
+#endif
 __host__ __device__ constexpr int unroll_for(int vec, int et) {
-  return vec * et >= 16 ? 1 : (vec * et >= 8 ? 2 : 4);
+  return vec * et >= 16 ? 1 : (vec * et >= 8 ? 2 : RJP_UNROLL_BASE);
 }
 
 // number of accumulator planes a tile of ET epochs writes per y-split

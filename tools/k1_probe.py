@@ -6,7 +6,6 @@ sys.path.insert(0, ROOT)
 import numpy as np
 import bench
 from rajepy_amd import engine as E
-from tests import gpu_util as U
 
 cfg, storage = sys.argv[1], sys.argv[2]
 nep = int(sys.argv[3]) if len(sys.argv) > 3 else 1
@@ -14,7 +13,7 @@ shape = bench.CONFIGS[cfg][0]
 eng = E.RTEngine(0)
 dtype = E.RJP_F64 if storage == "f64" else E.RJP_F32
 fields = eng.synth_fields(shape, 20240504, 0, dtype, csize_au=0.5)
-ej = U.example_bursts_params()
+ej = bench.EXAMPLE_BURSTS
 red, blue = [], []
 for t0, hl, chi, which in zip(ej["t_0"], ej["hl"], ej["chi"], ej["which"]):
     sig = hl * bench.YEAR * 2. / (2. * np.sqrt(2. * np.log(2.)))

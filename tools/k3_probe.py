@@ -8,7 +8,6 @@ import torch
 import bench
 from rajepy_amd import _lib, engine as E
 from rajepy_amd.maths import rrls
-from tests import gpu_util as U
 
 cfg, storage = sys.argv[1], sys.argv[2]
 shape, nchan = bench.CONFIGS[cfg][0], bench.CONFIGS[cfg][1]
@@ -17,7 +16,7 @@ if len(sys.argv) > 3:
 eng = E.RTEngine(0)
 dtype = E.RJP_F64 if storage == "f64" else E.RJP_F32
 fields = eng.synth_fields(shape, 20240504, 0, dtype, csize_au=0.5, with_vy=True)
-ej = U.example_bursts_params()
+ej = bench.EXAMPLE_BURSTS
 red, blue = [], []
 for t0, hl, chi, which in zip(ej["t_0"], ej["hl"], ej["chi"], ej["which"]):
     sig = hl * bench.YEAR * 2. / (2. * np.sqrt(2. * np.log(2.)))
