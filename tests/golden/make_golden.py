@@ -205,6 +205,14 @@ def golden_scalars():
     rec["phi_voigt_x_mhz"] = xs.tolist()
     rec["freq_str"] = {str(f): RaJePy.miscellaneous.functions.freq_str(f)
                        for f in (5e9, 2.2364e10, 1.4e9, 3.3e8, 2.3e11)}
+    # host-side JetModel behaviour without any RT: grid override by l_z, burst-less table
+    p = example_params()
+    p["grid"]["l_z"] = 2.
+    jm = new_model(p, "lz")
+    rec["lz_grid_dims"] = [jm.nx, jm.ny, jm.nz]
+    p = example_params()
+    p["ejection"] = {k: np.array([]) for k in ("t_0", "hl", "chi", "which")}
+    rec["jetmodel_str_no_bursts"] = str(new_model(p, "nob"))
     with open(os.path.join(HERE, "scalars.json"), "w") as f:
         json.dump(rec, f, indent=1, sort_keys=True)
 
@@ -293,6 +301,9 @@ def golden_pipeline(model_params):
 
 
 if __name__ == "__main__":
+    if sys.argv[1:] == ["scalars"]:          # regenerate scalars.json only
+        golden_scalars()
+        sys.exit(0)
     golden_gff()
     golden_scalars()
     golden_model("cfg1_example", example_params(), years=[0., 0.5, 1., 2., 3.],

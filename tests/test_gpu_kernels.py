@@ -284,3 +284,44 @@ def test_abi_error_reporting(eng):
     ctx = C.c_void_p()
     assert lib.rjp_ctx_create(10 ** 6, C.byref(ctx)) == -1
     eng.synchronize()
+
+
+@pytest.mark.parametrize("dtype", [8, 4])
+def test_no_bursts_paths(eng, dtype):
+    """A model without ejection events (chi == 1): the BURSTS=false kernels, `ts` absent,
+    several epochs requested (all identical), continuum and RRL."""
+    from rajepy_amd import _lib, engine as E
+    from rajepy_amd.maths import physics as ph, rrls
+    shape = (3, 41, 12)
+    g = U.synth_host(shape, 77, 1)
+    p = copy.deepcopy(U.load_golden("cfg1_example")[2])
+    p["ejection"] = {k: np.array([]) for k in ("t_0", "hl", "chi", "which")}
+    p["power_laws"]["q_T"] = -0.5
+    p["grid"].update(n_x=shape[0], n_y=shape[1], n_z=shape[2])
+    jet = orc.OracleJet.from_fields(p, g["nd"], g["xi"], g["temp"], g["ff"], g["areas"],
+                                    g["ts"], g["rr"], g["vy"])
+    fields = eng.upload_fields(g["nd"], g["xi"], g["temp"], g["ff"], g["areas"], None,
+                               g["rr"] < 0, g["vy"], csize_au=jet.csize, dtype=dtype)
+    assert fields.ts is None
+    years, freqs = [0., 1.5, 3.0], [2e9, 3e10]
+    for bursts in (None, E.make_bursts([], [])):
+        ctau, cflux = E.ff_channel_coeffs(freqs, jet.csize, p["target"]["dist"], E.RJP_GFF_POWERLAW)
+        sumA, em, tavg = eng.ff_scan(fields, bursts, [y * orc.YEAR for y in years],
+                                     E.RJP_GFF_POWERLAW)
+        tau, flux, _ = eng.ff_maps(sumA, tavg, ctau, cflux)
+        eng.synchronize()
+        tol = 1e-11 if dtype == 8 else RTOL
+        ref_tau, ref_flux, ref_em = (jet.optical_depth_ff(np.array(freqs)),
+                                     jet.flux_ff(np.array(freqs)), jet.emission_measure())
+        for e in range(len(years)):          # every epoch equals the steady state
+            np.testing.assert_allclose(tau[e].cpu().numpy().reshape(ref_tau.shape), ref_tau, rtol=tol)
+            np.testing.assert_allclose(flux[e].cpu().numpy().reshape(ref_tau.shape), ref_flux,
+                                       rtol=max(tol, 1e-10))
+            np.testing.assert_allclose(em[e].cpu().numpy().reshape(ref_em.shape), ref_em, rtol=tol)
+    rf = orc.chan_freqs(rrls.rrl_nu_0("H", 66, 1), 20 * 2e5, 2e5)
+    line = _lib.Line(**rrls.line_constants("H66a"))
+    t = eng.rrl_scan(fields, None, 0.0, line, rf)
+    eng.synchronize()
+    ref = jet.optical_depth_rrl("H66a", np.asarray(rf))
+    np.testing.assert_allclose(t.cpu().numpy().reshape(ref.shape), ref,
+                               rtol=1e-9 if dtype == 8 else RTOL)

@@ -127,11 +127,17 @@ def test_param_file_surface(tmp_path):
         classes.JetModel(str(bad))
 
 
-def test_lz_overrides_grid(tmp_path):
+def test_lz_overrides_grid_and_burstless_table(tmp_path):
+    ref = json.load(open(os.path.join(GOLDEN, "scalars.json")))
     p = example_params()
     p["grid"]["l_z"] = 2.
     jm = make_model(tmp_path, p)
-    assert (jm.nx, jm.ny, jm.nz) == (108, 110, 588)      # SURVEY.md finding 4
+    assert [jm.nx, jm.ny, jm.nz] == ref["lz_grid_dims"] == [108, 110, 588]   # SURVEY finding 4
+    p = example_params()
+    p["ejection"] = {k: np.array([]) for k in ("t_0", "hl", "chi", "which")}
+    jm = make_model(tmp_path, p)
+    assert str(jm) == ref["jetmodel_str_no_bursts"]
+    assert jm.ejections == {} and jm._rjp_bursts().n[0] == 0
 
 
 def test_validators_return_exceptions():
