@@ -69,6 +69,11 @@ typedef struct rjp_fields {
   int32_t nx, ny, nz;
   int32_t dtype;            /* enum rjp_dtype */
   double csize_au;          /* cell size [au] */
+  /* Optional per-sightline occupied y-range [d_ylo[p], d_yhi[p]) from rjp_y_bounds() (both
+   * NULL = scan every row).  Real jets fill a few per cent of the grid; rows outside the
+   * range hold only cells that cannot contribute (NaN density / T <= 0) and are skipped. */
+  const int32_t* d_ylo;
+  const int32_t* d_yhi;
 } rjp_fields;
 
 /* Ejection bursts (classes.py:399-463): mdot(t)/mdot_ss = 1 + sum_b amp_rel_b *
@@ -103,6 +108,14 @@ const char* rjp_last_error(const rjp_ctx* ctx);   /* ctx may be NULL: last creat
  * stores d_src[i]/d_den[i] -> the `pf` field from fill_factor and areas. */
 int rjp_pack_field(rjp_ctx* ctx, const double* d_src, const double* d_den,
                    const uint8_t* d_red, void* d_dst, int64_t n, int dtype, void* stream);
+
+/* Per-sightline occupied y-range of a packed field set: d_ylo[p] = first row, d_yhi[p] = one
+ * past the last row whose cell can contribute to any product of the path, i.e. T > 0 (counts
+ * in the nanmean of intensity_ff, classes.py:1471) or n, x and ff/areas all non-NaN (emission
+ * measure, classes.py:1116-1118); empty sightlines get [ny, 0).  One pass over 4 fields,
+ * amortised over every later scan of the same model. */
+int rjp_y_bounds(rjp_ctx* ctx, const rjp_fields* fields, int32_t* d_ylo, int32_t* d_yhi,
+                 void* stream);
 
 /* ---- K1: free-free / emission-measure scan -------------------------------------------
  * Replaces the y-reductions of JetModel.emission_measure (classes.py:1116-1120),

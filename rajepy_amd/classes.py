@@ -315,6 +315,9 @@ class JetModel:
                 # exactly as the reference does (maths/geometry.py:150-178) and upload them
                 self._dev = self.engine.build_fields(geom, self._dtype, want_ts=False)
                 self.engine.replace_field(self._dev, "ts", self._host_launch_times())
+            # a jet fills a few per cent of its grid: record each sightline's occupied rows
+            # once so that every later scan touches only those
+            self.engine.compute_y_bounds(self._dev)
             self.engine.synchronize()
             if self.log:
                 self.log.add_entry("INFO", _time.strftime(

@@ -22,6 +22,8 @@ struct FieldPtrs {
   const T* temp;
   const T* pf;
   const T* ts;
+  const int32_t* ylo;      // optional occupied y-range per sightline (nullptr = all rows)
+  const int32_t* yhi;
 };
 
 template <int ET>
@@ -113,12 +115,28 @@ __global__ __launch_bounds__(kBlock) void ff_scan_kernel(
     EpochTile<ET> ep, double* __restrict__ ws) {
   constexpr int kUnroll = unroll_for(VEC, ET);
   const int64_t c = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-  if (c >= nchunks) return;
+  const bool lane_live = c < nchunks;
   const int64_t p0 = c * VEC;              // first sightline (pixel) of this lane
+  int y0 = blockIdx.y * ylen;
+  int y1 = min(ny, y0 + ylen);
+  if (f.ylo) {
+    // sparse models: clip this workgroup's rows to the occupied range of its sightlines
+    __shared__ int s_lo, s_hi;
+    if (threadIdx.x == 0) { s_lo = ny; s_hi = 0; }
+    __syncthreads();
+    if (lane_live) {
+      int lo = ny, hi = 0;
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) { lo = min(lo, f.ylo[p0 + v]); hi = max(hi, f.yhi[p0 + v]); }
+      if (lo < hi) { atomicMin(&s_lo, lo); atomicMax(&s_hi, hi); }
+    }
+    __syncthreads();
+    y0 = max(y0, s_lo);
+    y1 = min(y1, s_hi);
+  }
+  if (!lane_live) return;
   const int64_t x = p0 / nz;
   const int z = (int)(p0 - x * nz);
-  const int y0 = blockIdx.y * ylen;
-  const int y1 = min(ny, y0 + ylen);
 
   double accA[ET][VEC], accE[ET][VEC], accT[VEC], cnt[VEC];
 #pragma unroll
@@ -243,6 +261,43 @@ __global__ __launch_bounds__(kBlock) void sum_partials_kernel(const double* __re
   }
 }
 
+// Occupied y-range per sightline: one lane per sightline, lanes adjacent along z.
+template <typename T>
+__global__ __launch_bounds__(kBlock) void y_bounds_kernel(FieldPtrs<T> f, int ny, int nz,
+                                                          int64_t npix, int32_t* __restrict__ ylo,
+                                                          int32_t* __restrict__ yhi) {
+  const int64_t p = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (p >= npix) return;
+  const int64_t x = p / nz;
+  const int z = (int)(p - x * nz);
+  int64_t off = x * ny * (int64_t)nz + z;
+  int lo = ny, hi = 0;
+  for (int y = 0; y < ny; ++y, off += nz) {
+    const double nd = (double)f.nd[off], xi = (double)f.xi[off], pf = (double)f.pf[off],
+                 tk = (double)f.temp[off];
+    const bool matters = (tk > 0.0) || (nd == nd && xi == xi && pf == pf);
+    if (matters) { lo = min(lo, y); hi = y + 1; }
+  }
+  ylo[p] = lo;
+  yhi[p] = hi;
+}
+
+hipError_t y_bounds_launch(const rjp_fields* fl, int32_t* ylo, int32_t* yhi, hipStream_t st) {
+  const int64_t npix = (int64_t)fl->nx * fl->nz;
+  const dim3 grid((unsigned)((npix + kBlock - 1) / kBlock)), blk(kBlock);
+  if (fl->dtype == RJP_F64) {
+    FieldPtrs<double> f{(const double*)fl->d_nd, (const double*)fl->d_xi,
+                        (const double*)fl->d_temp, (const double*)fl->d_pf, nullptr, nullptr,
+                        nullptr};
+    hipLaunchKernelGGL(y_bounds_kernel<double>, grid, blk, 0, st, f, fl->ny, fl->nz, npix, ylo, yhi);
+  } else {
+    FieldPtrs<float> f{(const float*)fl->d_nd, (const float*)fl->d_xi, (const float*)fl->d_temp,
+                       (const float*)fl->d_pf, nullptr, nullptr, nullptr};
+    hipLaunchKernelGGL(y_bounds_kernel<float>, grid, blk, 0, st, f, fl->ny, fl->nz, npix, ylo, yhi);
+  }
+  return hipGetLastError();
+}
+
 // collapse=False: the 3-D per-cell free-free optical depths (classes.py:1382-1383, 1395-1397).
 // out[f * ncell + cell] = ctau[f] * T^-1.5|-1.35 * (n chi x)^2 * pf, NaN outside the jet.
 template <typename T, int MODE, bool BURSTS>
@@ -272,7 +327,7 @@ hipError_t ff_cells_launch(const rjp_fields* fl, const rjp_bursts* hb, double ti
   auto go = [&](auto tag) {
     using T = decltype(tag);
     FieldPtrs<T> f{(const T*)fl->d_nd, (const T*)fl->d_xi, (const T*)fl->d_temp,
-                   (const T*)fl->d_pf, (const T*)fl->d_ts};
+                   (const T*)fl->d_pf, (const T*)fl->d_ts, nullptr, nullptr};
     if (mode == RJP_GFF_SCALAR) {
       if (bursts) hipLaunchKernelGGL((ff_cells_kernel<T, 0, true>), grid, blk, 0, st, f, n, b, time_s, d_ctau, nchan, out);
       else hipLaunchKernelGGL((ff_cells_kernel<T, 0, false>), grid, blk, 0, st, f, n, b, time_s, d_ctau, nchan, out);
@@ -331,7 +386,7 @@ template <typename T, int VEC, int ET, int MODE, bool BURSTS>
 static hipError_t launch_tile(const rjp_fields* fl, const BurstsDev& b, const double* t,
                               int nsplit, int ylen, double* ws, hipStream_t st) {
   FieldPtrs<T> f{(const T*)fl->d_nd, (const T*)fl->d_xi, (const T*)fl->d_temp,
-                 (const T*)fl->d_pf, (const T*)fl->d_ts};
+                 (const T*)fl->d_pf, (const T*)fl->d_ts, fl->d_ylo, fl->d_yhi};
   EpochTile<ET> ep;
   for (int e = 0; e < ET; ++e) ep.t[e] = t[e];
   const int64_t npix = (int64_t)fl->nx * fl->nz;

@@ -99,6 +99,8 @@ static int check_fields(rjp_ctx* ctx, const rjp_fields* f, bool need_vy) {
     return fail(ctx, RJP_ERR_ARG, "fields nd/xi/temp/pf must be device pointers");
   if (need_vy && !f->d_vy) return fail(ctx, RJP_ERR_ARG, "fields.d_vy required for RRL");
   if (!(f->csize_au > 0.0)) return fail(ctx, RJP_ERR_ARG, "fields.csize_au must be > 0");
+  if ((f->d_ylo == nullptr) != (f->d_yhi == nullptr))
+    return fail(ctx, RJP_ERR_ARG, "fields.d_ylo and d_yhi must both be set or both be NULL");
   return RJP_OK;
 }
 
@@ -178,6 +180,15 @@ int rjp_pack_field(rjp_ctx* ctx, const double* d_src, const double* d_den,
   if (!d_src || !d_dst || n <= 0) return fail(ctx, RJP_ERR_ARG, "rjp_pack_field: bad pointers/size");
   if (dtype != RJP_F32 && dtype != RJP_F64) return fail(ctx, RJP_ERR_ARG, "bad dtype tag");
   RJP_HIP(ctx, rjp::pack_field_launch(d_src, d_den, d_red, d_dst, n, dtype, (hipStream_t)stream));
+  return RJP_OK;
+}
+
+int rjp_y_bounds(rjp_ctx* ctx, const rjp_fields* fields, int32_t* d_ylo, int32_t* d_yhi,
+                 void* stream) {
+  if (int r = bind(ctx)) return r;
+  if (int r = check_fields(ctx, fields, false)) return r;
+  if (!d_ylo || !d_yhi) return fail(ctx, RJP_ERR_ARG, "rjp_y_bounds: NULL output");
+  RJP_HIP(ctx, rjp::y_bounds_launch(fields, d_ylo, d_yhi, (hipStream_t)stream));
   return RJP_OK;
 }
 

@@ -193,6 +193,8 @@ struct RrlFields {
   const T* pf;
   const T* ts;
   const T* vy;
+  const int32_t* ylo;      // optional occupied y-range per sightline
+  const int32_t* yhi;
 };
 
 struct LineDev {
@@ -323,7 +325,23 @@ __global__ __launch_bounds__(kRB, RJP_K3_WAVES) void rrl_scan_kernel(
 
   const int cy = tid / ZT, cz = tid % ZT;       // this thread's cell in the slab (phase 1)
 
-  for (int yb = 0; yb < ny; yb += YC) {
+  int ya = 0, ye = ny;
+  if (f.ylo) {
+    // sparse models: only the slabs that intersect the tile's occupied y-range
+    __shared__ int s_lo, s_hi;
+    if (tid == 0) { s_lo = ny; s_hi = 0; }
+    __syncthreads();
+    if (tid < ZT && z0 + tid < nz) {
+      const int64_t p = (int64_t)x * nz + z0 + tid;
+      const int lo = f.ylo[p], hi = f.yhi[p];
+      if (lo < hi) { atomicMin(&s_lo, lo); atomicMax(&s_hi, hi); }
+    }
+    __syncthreads();
+    ya = (s_lo / YC) * YC;
+    ye = s_hi;
+  }
+
+  for (int yb = ya; yb < ye; yb += YC) {
     // ---- phase 1: per-cell line constants --------------------------------------------
     {
       const int yy = yb + cy, zz = z0 + cz;
@@ -408,7 +426,7 @@ static hipError_t rrl_launch_t(const rjp_fields* fl, const BurstsDev& b, bool bu
                                double time_s, const LineDev& ln, const double* d_nu,
                                int nchan, double* tau, hipStream_t st) {
   RrlFields<T> f{(const T*)fl->d_nd, (const T*)fl->d_xi, (const T*)fl->d_temp,
-                 (const T*)fl->d_pf, (const T*)fl->d_ts, (const T*)fl->d_vy};
+                 (const T*)fl->d_pf, (const T*)fl->d_ts, (const T*)fl->d_vy, fl->d_ylo, fl->d_yhi};
   const int ntz = (fl->nz + RrlTile<LF>::ZT - 1) / RrlTile<LF>::ZT;
   dim3 grid((unsigned)(fl->nx * ntz), (unsigned)((nchan + LF - 1) / LF));
   if (bursts)
@@ -457,7 +475,7 @@ hipError_t rrl_cells_launch(const rjp_fields* fl, const rjp_bursts* hb, double t
   auto go = [&](auto tag) {
     using T = decltype(tag);
     RrlFields<T> f{(const T*)fl->d_nd, (const T*)fl->d_xi, (const T*)fl->d_temp,
-                   (const T*)fl->d_pf, (const T*)fl->d_ts, (const T*)fl->d_vy};
+                   (const T*)fl->d_pf, (const T*)fl->d_ts, (const T*)fl->d_vy, nullptr, nullptr};
     if (bursts)
       hipLaunchKernelGGL((rrl_cells_kernel<T, true>), dim3(blocks), dim3(kRB), 0, st, f, n, b,
                          time_s, ln, d_nu, nchan, out);

@@ -28,6 +28,7 @@ class DeviceFields:
         self.csize_au = float(csize_au)
         self.nd, self.xi, self.temp, self.pf, self.ts, self.vy = nd, xi, temp, pf, ts, vy
         self.ff_raw, self.areas_raw = ff_raw, areas_raw
+        self.ylo = self.yhi = None          # optional occupied y-range per sightline (int32)
 
     @property
     def ncells(self):
@@ -46,6 +47,8 @@ class DeviceFields:
         f.nx, f.ny, f.nz = self.shape
         f.dtype = self.dtype
         f.csize_au = self.csize_au
+        f.d_ylo = self.ylo.data_ptr() if self.ylo is not None else None
+        f.d_yhi = self.yhi.data_ptr() if self.yhi is not None else None
         return f
 
     def nbytes(self, rrl=False):
@@ -152,6 +155,19 @@ class RTEngine:
         self.synchronize()
         return DeviceFields(shape, dtype, csize_au, d_nd, d_xi, d_t, d_pf, d_ts, d_vy)
 
+    def compute_y_bounds(self, fields):
+        """Attach the per-sightline occupied y-range to `fields` (rjp_y_bounds): later scans
+        skip the rows no cell of which can contribute.  Recompute after changing a field."""
+        torch = _torch()
+        fields.ylo = fields.yhi = None
+        lo = torch.empty(fields.npix, dtype=torch.int32, device=self.device)
+        hi = torch.empty(fields.npix, dtype=torch.int32, device=self.device)
+        fs = fields.struct()
+        _lib.check(self.lib.rjp_y_bounds(self.ctx, C.byref(fs), lo.data_ptr(), hi.data_ptr(),
+                                         self._stream()), self.ctx, "rjp_y_bounds")
+        fields.ylo, fields.yhi = lo, hi
+        return lo, hi
+
     def replace_field(self, fields, name, host_array):
         """Re-upload one plain field (the reference's public setters: ts, ion_fraction,
         temperature; classes.py:857-859, 938-940, 998-1000)."""
@@ -167,6 +183,8 @@ class RTEngine:
                                            self._stream()), self.ctx, "rjp_pack_field")
         self.synchronize()
         setattr(fields, name, dst)
+        if fields.ylo is not None and name in ("xi", "temp"):
+            self.compute_y_bounds(fields)       # the occupied range depends on these fields
 
     def build_fields(self, geom, dtype=RJP_F64, want_ts=True, want_vy=True, want_raw=True,
                      want_vxz=False):

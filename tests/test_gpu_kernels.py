@@ -325,3 +325,38 @@ def test_no_bursts_paths(eng, dtype):
     ref = jet.optical_depth_rrl("H66a", np.asarray(rf))
     np.testing.assert_allclose(t.cpu().numpy().reshape(ref.shape), ref,
                                rtol=1e-9 if dtype == 8 else RTOL)
+
+
+@pytest.mark.parametrize("dtype", [8, 4])
+def test_y_bounds_skip_is_exact(eng, dtype):
+    """The sparse-model shortcut: occupied y-ranges equal the host definition and scans with
+    them are bit-identical to scans without (continuum base maps and RRL cube)."""
+    from rajepy_amd import _lib, engine as E
+    from rajepy_amd.maths import rrls
+    z, meta, p, g, jet = U.golden_dense("tilted")
+    # a stray finite temperature outside the jet must widen the range (it counts in T_avg)
+    g["temp"][5, 60, 7] = 123.0
+    fields = eng.upload_fields(g["nd"], g["xi"], g["temp"], g["ff"], g["areas"], g["ts"],
+                               g["rr"] < 0, g["vy"], csize_au=jet.csize, dtype=dtype)
+    bursts = U.bursts_from_oracle(jet)
+    ep = [y * orc.YEAR for y in (0., 0.4, 0.9)]
+    ref = [t.clone() for t in eng.ff_scan(fields, bursts, ep, E.RJP_GFF_POWERLAW)]
+    line = _lib.Line(**rrls.line_constants(meta["rrl"]))
+    ref_rrl = eng.rrl_scan(fields, bursts, ep[1], line, z["rrl_freqs"]).clone()
+    lo, hi = eng.compute_y_bounds(fields)
+    eng.synchronize()
+    matters = (g["temp"] > 0) | (np.isfinite(g["nd"]) & np.isfinite(g["xi"]) &
+                                 np.isfinite(g["ff"] / g["areas"]))
+    any_ = matters.any(axis=1)
+    exp_lo = np.where(any_, matters.argmax(axis=1), jet.ny)
+    exp_hi = np.where(any_, jet.ny - matters[:, ::-1, :].argmax(axis=1), 0)
+    assert np.array_equal(lo.cpu().numpy().reshape(jet.nx, jet.nz), exp_lo)
+    assert np.array_equal(hi.cpu().numpy().reshape(jet.nx, jet.nz), exp_hi)
+    assert exp_hi[5, 7] >= 61
+    got = eng.ff_scan(fields, bursts, ep, E.RJP_GFF_POWERLAW)
+    got_rrl = eng.rrl_scan(fields, bursts, ep[1], line, z["rrl_freqs"])
+    eng.synchronize()
+    import torch
+    for a, b in zip(got, ref):
+        assert torch.equal(torch.nan_to_num(a, nan=-1.0), torch.nan_to_num(b, nan=-1.0))
+    assert torch.equal(got_rrl, ref_rrl)

@@ -51,7 +51,7 @@ def test_abi_exports_every_declared_symbol():
 
 
 def test_abi_struct_layouts_match_header():
-    assert ctypes.sizeof(_lib.Fields) == 6 * 8 + 4 * 4 + 8
+    assert ctypes.sizeof(_lib.Fields) == 6 * 8 + 4 * 4 + 8 + 2 * 8
     assert ctypes.sizeof(_lib.Bursts) == 8 + 3 * 2 * 8 * 8
     assert ctypes.sizeof(_lib.Line) == 6 * 8
     assert ctypes.sizeof(_lib.Geometry) == 4 * 4 + 24 * 8 + 2 * 4

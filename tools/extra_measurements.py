@@ -29,6 +29,16 @@ tmp = tempfile.mkdtemp()
 jm = classes.JetModel(p, log=logger.Log(os.path.join(tmp, "a.log"), verbose=False), engine=eng)
 t0 = time.perf_counter(); dev = jm.device_fields; eng.synchronize()
 out["k4_build_512x4096x512_s"] = time.perf_counter() - t0
+# sparse-model shortcut: 8-epoch scan of the example jet with / without the occupied y-ranges
+ep = list(np.linspace(0., 3.5, 8) * 31536000.0)
+b = jm._rjp_bursts()
+for tag in ("with_ybounds", "without_ybounds"):
+    if tag == "without_ybounds":
+        keep = (dev.ylo, dev.yhi); dev.ylo = dev.yhi = None
+    eng.ff_scan(dev, b, ep, jm.gff_mode); eng.synchronize()
+    t0 = time.perf_counter(); eng.ff_scan(dev, b, ep, jm.gff_mode); eng.synchronize()
+    out["jet_8epoch_scan_512x4096x512_%s_s" % tag] = time.perf_counter() - t0
+dev.ylo, dev.yhi = keep
 t0 = time.perf_counter(); jm.time = 0.; f = jm.flux_ff(np.geomspace(1e9, 5e10, 256))
 out["jetmodel_flux_ff_256ch_512x4096x512_incl_d2h_s"] = time.perf_counter() - t0
 out["jet_filled_fraction"] = float(np.isfinite(f[0]).mean())
