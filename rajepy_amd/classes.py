@@ -160,6 +160,7 @@ class JetModel:
         self._tavg = None
         self._host_ts = None
         self._vxz = None
+        self._rrl_cache = None
 
     # ------------------------------------------------------------------ bookkeeping ----
     def __str__(self):
@@ -292,6 +293,7 @@ class JetModel:
         self._version = getattr(self, "_version", 0) + 1
         self._scan_cache = {}
         self._tavg = None
+        self._rrl_cache = None
 
     @property
     def gff_mode(self):
@@ -502,9 +504,17 @@ class JetModel:
         return fluxes
 
     def _rrl_tau_device(self, rrl, freqs):
+        """tau_rrl[F, P] on the device.  The last cube is kept: `Pipeline` asks for the optical
+        depths and then for the fluxes of the same line, channels and epoch
+        (classes.py:2437, 2450), and the Voigt scan is the expensive kernel."""
+        key = (rrl, tuple(float(f) for f in freqs), float(self.time), self._version)
+        if self._rrl_cache is not None and self._rrl_cache[0] == key:
+            return self._rrl_cache[1]
         line = _lib.Line(**mrrl.line_constants(rrl))
-        return self.engine.rrl_scan(self.device_fields, self._rjp_bursts(), float(self.time),
-                                    line, freqs)
+        tau = self.engine.rrl_scan(self.device_fields, self._rjp_bursts(), float(self.time),
+                                   line, freqs)
+        self._rrl_cache = (key, tau)
+        return tau
 
     def optical_depth_rrl(self, rrl, freq, lte=True, savefits=False, collapse=True):
         """RRL optical depth along y (classes.py:1130-1229)."""

@@ -8,11 +8,6 @@ namespace rjp {
 
 constexpr int kFB = 256;
 
-template <typename T>
-__device__ __forceinline__ void store_as(void* dst, int64_t i, double v) {
-  reinterpret_cast<T*>(dst)[i] = (T)v;
-}
-
 __device__ __forceinline__ double with_sign(double mag, bool neg) {
   long long bits = __double_as_longlong(mag) & 0x7FFFFFFFFFFFFFFFll;
   if (neg) bits |= (long long)0x8000000000000000ull;

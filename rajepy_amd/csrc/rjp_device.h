@@ -8,12 +8,6 @@
 #define RJP_WAVE 64
 
 // ---- vector loads: 16 B per lane -------------------------------------------------------
-template <typename T> struct VecOf;
-template <> struct VecOf<double> { using type = double2; static constexpr int N = 2; };
-template <> struct VecOf<float> { using type = float4; static constexpr int N = 4; };
-
-template <typename T, int V> struct Pack { double v[V]; };
-
 #ifndef RJP_NT_LOADS
 #define RJP_NT_LOADS 1   /* the fields are streamed exactly once: non-temporal loads, +5 % on cfg4 (6.1 -> 6.4 TB/s) */
 #endif
