@@ -122,3 +122,18 @@ def _gff_cached(freq, temp, z):
 def v_rot(r, reff, rho, epsilon, m_star):
     """Rotation speed [km/s] (physics.py:66-90)."""
     return np.sqrt(con.G * m_star * con.MSOL / (reff * con.au)) * rho ** -epsilon / 1e3
+
+
+A_K = 0.212        # Reynolds (1986) free-free absorption constant (_constants.py:13)
+
+
+def tau_r(r, r_0, w_0, n_0, chi_0, T_0, freq, inc, epsilon, q_n, q_x, q_T, opang):
+    """Analytic optical depth through the jet at distance r [au] along its axis, equations
+    4-5 of Reynolds (1986) (physics.py:93-142).  Used as a physics cross-check of the maps
+    (the reference's sed_plot does the same, plotting/functions.py:1194-1227)."""
+    from . import geometry as geom
+    cm = con.au * 1e2
+    mr0 = geom.mod_r_0(opang, epsilon, w_0 * cm)
+    q = epsilon + 2. * q_n + 2. * q_x - 1.35 * q_T
+    return (2. * A_K * (w_0 * cm) * n_0 ** 2. * chi_0 ** 2. * T_0 ** -1.35 *
+            geom.rho(r * cm, r_0 * cm, mr0) ** q * freq ** -2.1 / np.sin(np.radians(inc)))

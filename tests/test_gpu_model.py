@@ -88,6 +88,31 @@ def test_jetmodel_setters_and_accessors(tmp_path):
                                jm2.optical_depth_ff(5e9) * 4.0 * 4.0 ** -1.5, rtol=1e-9)
 
 
+def test_maps_follow_reynolds86_analytic_optical_depth(tmp_path):
+    """Physics cross-check: along the axis of the steady-state example jet the
+    optical-depth map follows Reynolds' (1986) analytic tau(r) -- same power law, amplitude
+    within the few-per-cent difference between his Gaunt approximation and van Hoof's table
+    plus the half-cell discretisation of the jet edge."""
+    from rajepy_amd.maths import physics as mphys
+    p = example_params()
+    p["ejection"] = {k: np.array([]) for k in ("t_0", "hl", "chi", "which")}
+    p["properties"]["mlr_rj"] = p["properties"]["mlr_bj"]
+    jm = classes.JetModel(p, log=logger.Log(str(tmp_path / "a.log"), verbose=False))
+    nu = 5e9
+    tau = jm.optical_depth_ff(nu)
+    g, pr, pl = jm.params["geometry"], jm.params["properties"], jm.params["power_laws"]
+    iz = np.arange(jm.nz // 2 + 8, jm.nz - 1)                    # blue jet, r = 4.25 .. 12 au
+    r = jm.csize * (iz - jm.nz // 2) + jm.csize / 2.
+    ix = jm.nx // 2                                              # axis column (x = +0.25 au)
+    ana = mphys.tau_r(r, g["r_0"], g["w_0"], pr["n_0"], pr["x_0"], pr["T_0"], nu, g["inc"],
+                      g["epsilon"], pl["q_n"], pl["q_x"], pl["q_T"], g["opang"])
+    ratio = tau[ix, iz] / ana
+    assert np.all((ratio > 0.75) & (ratio < 1.25)), ratio
+    rho = (r + g["mod_r_0"] - g["r_0"]) / g["mod_r_0"]
+    slope = np.polyfit(np.log(rho), np.log(tau[ix, iz]), 1)[0]
+    assert slope == pytest.approx(pl["q_tau"], abs=0.3)          # tau ~ rho^q_tau
+
+
 def test_collapse_false_and_vel(tmp_path):
     """collapse=False returns the un-summed per-cell optical depths whose y-sum is the map;
     vel returns all three components (tilted model: every rotation term is exercised)."""
