@@ -89,14 +89,27 @@ __device__ __forceinline__ double voigt_core_shifted(double ax, double y, double
   const bool half = !(fr >= 0.25 && fr < 0.75);
   const double U = r2 * r2;
   const double W = 2.0 * __builtin_fma(-ax, ax, y * y);
-  double s = 0.0;
+  double num[kNPair], den[kNPair];
 #pragma unroll
   for (int n = 0; n < kNPair; ++n) {
     const double tau = half ? c_tau1[n] : c_tau0[n];
     const double c2 = half ? c_w1[n] : c_w0[n];
     const double c2t = half ? c_wt1[n] : c_wt0[n];
-    const double den = __builtin_fma(tau, W + tau, U);
-    s = __builtin_fma(__builtin_fma(c2, r2, c2t), rcp_fast(den), s);
+    den[n] = __builtin_fma(tau, W + tau, U);
+    num[n] = __builtin_fma(c2, r2, c2t);
+  }
+  double s = 0.0;
+#pragma unroll
+  for (int n = 0; n + 4 <= kNPair; n += 4) {       // one reciprocal per four pairs
+    const double d01 = den[n] * den[n + 1], d23 = den[n + 2] * den[n + 3];
+    const double a = __builtin_fma(num[n], den[n + 1], num[n + 1] * den[n]);
+    const double b = __builtin_fma(num[n + 2], den[n + 3], num[n + 3] * den[n + 2]);
+    s = __builtin_fma(__builtin_fma(a, d23, b * d01), rcp_fast(d01 * d23), s);
+  }
+  {
+    constexpr int n = kNPair - 2;
+    s = __builtin_fma(__builtin_fma(num[n], den[n + 1], num[n + 1] * den[n]),
+                      rcp_fast(den[n] * den[n + 1]), s);
   }
   s *= y * (kH / 3.14159265358979323846);
   const double e = y * y - ax * ax;
@@ -154,11 +167,28 @@ __device__ __forceinline__ double voigt_rew(double ax, double y, double q, doubl
                                   0.002221376473560232, 6.097874918425347e-05,
                                   7.701475101202686e-07, 4.54326016941689e-09,
                                   1.2641261723433871e-11};
-  double s = 0.0;
+  // one reciprocal per FOUR pairs: n0/d0 + n1/d1 + n2/d2 + n3/d3 over the common
+  // denominator (the d's are bounded, their products stay far inside the FP64 range; the
+  // hardware reciprocal is the slow instruction here)
+  double num[kNPair], den[kNPair];
 #pragma unroll
   for (int n = 0; n < kNPair; ++n) {
-    const double den = __builtin_fma(tau[n], W + tau[n], U);
-    s = __builtin_fma(__builtin_fma(w2[n], r2, w2t[n]), rcp_fast(den), s);
+    den[n] = __builtin_fma(tau[n], W + tau[n], U);
+    num[n] = __builtin_fma(w2[n], r2, w2t[n]);
+  }
+  double s = 0.0;
+#pragma unroll
+  for (int n = 0; n + 4 <= kNPair; n += 4) {
+    const double d01 = den[n] * den[n + 1], d23 = den[n + 2] * den[n + 3];
+    const double a = __builtin_fma(num[n], den[n + 1], num[n + 1] * den[n]);
+    const double b = __builtin_fma(num[n + 2], den[n + 3], num[n + 3] * den[n + 2]);
+    s = __builtin_fma(__builtin_fma(a, d23, b * d01), rcp_fast(d01 * d23), s);
+  }
+  static_assert(kNPair % 4 == 2, "tail below handles exactly two pairs");
+  {
+    constexpr int n = kNPair - 2;
+    s = __builtin_fma(__builtin_fma(num[n], den[n + 1], num[n + 1] * den[n]),
+                      rcp_fast(den[n] * den[n + 1]), s);
   }
   s *= y * (kH / 3.14159265358979323846);
   // Pole term P = Re[ 2 exp(-z^2) q / (q - exp(-i theta)) ], theta = 2 pi x / h.
@@ -315,8 +345,14 @@ __global__ __launch_bounds__(kRB, RJP_K3_WAVES) void rrl_scan_kernel(
   const int tid = threadIdx.x;
   const int fl = tid % LF;
   const int g = tid / LF;
-  const int fi = blockIdx.y * LF + fl;
-  const bool chan_live = fi < nchan;
+  // Lanes take the channels of this block folded about the block centre: lane 0 -> first,
+  // lane 1 -> last, lane 2 -> second, ...  A band centred on the line then gives each wave
+  // a narrow range of |x|: the outermost wave is entirely far-field (continued fraction) and
+  // only the innermost needs the pole term, instead of every wave straddling both regimes.
+  const int fbase = blockIdx.y * LF;
+  const int nblk = min(LF, nchan - fbase);
+  const int fi = fbase + ((fl & 1) ? nblk - 1 - (fl >> 1) : (fl >> 1));
+  const bool chan_live = fl < nblk;
   const double nu_f = chan_live ? nu[fi] : ln.nu_ref;
   const double dnu = nu_f - ln.nu_ref;
 
