@@ -58,10 +58,13 @@ def parse():
                     choices=sorted(CONFIGS))
     ap.add_argument("--storage", default="f64", choices=("f64", "f32"))
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--sharding", default="epochs", choices=("epochs", "xslab"),
+    ap.add_argument("--sharding", default="epochs", choices=("epochs", "xslab", "channels"),
                     help="N>1: epochs = one epoch of the full grid per rank (weak scaling, the "
                          "default); xslab = the ONE grid split into n_x/N row slabs (strong "
-                         "scaling, per-channel fluxes all_reduced)")
+                         "scaling, per-channel fluxes all_reduced); channels = the north "
+                         "star's frequency-sharded sweep: every rank scans the whole grid and "
+                         "maps 1/N of the channels (continuum channels share the grid pass, so "
+                         "this cannot scale the scan -- SURVEY finding 2)")
     ap.add_argument("--backend", default="nccl", choices=("nccl", "gloo"),
                     help="gloo = rehearsal of the N>1 path (e.g. several ranks on one GPU)")
     ap.add_argument("--share-gpu", action="store_true",
@@ -134,7 +137,8 @@ def main():
     import torch.distributed as dist
     from rajepy_amd import _lib, engine as E
     from rajepy_amd.maths import physics as ph, rrls
-    from rajepy_amd.parallel import EpochShards, SlabShards, gather_flux_vs_time
+    from rajepy_amd.parallel import (ChannelShards, EpochShards, SlabShards,
+                                     all_gather_blocks, gather_flux_vs_time)
 
     if args.share_gpu:
         local = 0
@@ -153,6 +157,7 @@ def main():
     ncell = shape[0] * shape[1] * shape[2]          # cells of the whole grid
     rrl = kind == "rrl"
     xslab = args.sharding == "xslab" and world > 1
+    chsh = args.sharding == "channels" and world > 1 and not rrl
     if xslab:
         x0, x1 = SlabShards(shape[0], world).bounds[rank]
         lshape = (x1 - x0, shape[1], shape[2])
@@ -179,6 +184,11 @@ def main():
         cfl_rrl, hnu_k = E.rrl_channel_coeffs(freqs, 0.5, 120.)
     else:
         freqs = np.geomspace(1e9, 5e10, nchan)
+    nchan_total = nchan
+    if chsh:                      # this rank's slice of the channel list
+        cshards = ChannelShards(freqs, world)
+        freqs = cshards.local(rank)
+        nchan = len(freqs)
     gv = [ph.gff(nu, 1e4) for nu in freqs]
     ctau, cflux = E.ff_channel_coeffs(freqs, 0.5, 120., E.RJP_GFF_SCALAR, gv)
 
@@ -186,12 +196,12 @@ def main():
     # step (weak scaling over the burst-time sweep)
     if n_ep_cfg:
         epochs = np.linspace(0., 5., n_ep_cfg) * YEAR
-    elif xslab:
+    elif xslab or chsh:
         epochs = np.array([1.0 * YEAR])
     else:
         epochs = np.linspace(0., 5., world) * YEAR if world > 1 else np.array([1.0 * YEAR])
-    shards = EpochShards(epochs, 1 if xslab else world)
-    my_epochs = [float(t) for t in shards.local(0 if xslab else rank)]
+    shards = EpochShards(epochs, 1 if (xslab or chsh) else world)
+    my_epochs = [float(t) for t in shards.local(0 if (xslab or chsh) else rank)]
     E_loc = len(my_epochs)
 
     sumA = eng._f64(E_loc, P)
@@ -213,6 +223,8 @@ def main():
             _, res = eng.rrl_maps(tau_rrl, tau.reshape(nchan, P), tavg, flux.reshape(nchan, P),
                                   cfl_rrl, hnu_k)
             res = res.reshape(1, nchan)
+        if chsh:                  # [1, F/N] per rank -> [1, F]
+            return all_gather_blocks(res, cshards, rank, axis=1)
         if xslab:                 # partial per-channel fluxes of this slab -> whole-map totals
             if args.backend == "nccl":
                 dist.all_reduce(res)
@@ -243,7 +255,7 @@ def main():
         dt = float(tmax.item())
     ms_step = dt / args.steps * 1e3
     total_epochs = shards.n_epochs
-    value = ncell * nchan * total_epochs / (ms_step * 1e-3) / 1e6
+    value = ncell * nchan_total * total_epochs / (ms_step * 1e-3) / 1e6
 
     # dominant kernel, timed live with HIP events on the launch stream
     if rrl:
@@ -280,17 +292,19 @@ def main():
         "metric": "Mvoxel-freq/s", "value": value, "unit": "Mvoxel-freq/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": ms_step, "higher_is_better": True,
-        "scaling": "strong" if (n_ep_cfg or xslab) else "weak",
+        "scaling": "strong" if (n_ep_cfg or xslab or chsh) else "weak",
         "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": "%s: %dx%dx%d grid x %d %s, %d epoch(s) per step, %s"
                                % ((args.config,) + shape + (
-                                   nchan, "H66a channels of 100 kHz" if rrl else
+                                   nchan_total, "H66a channels of 100 kHz" if rrl else
                                    "continuum channels 1-50 GHz", total_epochs,
                                    "K3 RRL scan + K1/K2 continuum + line flux cube" if rrl else
                                    "K1 scan + K2 flux-vs-time" if n_ep_cfg else
                                    "K1 scan + K2 tau/flux cubes")),
-                   "storage": args.storage, "sharding": ("xslab" if xslab else "epochs") if world > 1 else "none",
+                   "storage": args.storage, "sharding": ("xslab" if xslab else "channels" if chsh else "epochs")
+                   if world > 1 else "none",
                    "gather": ("all_reduce of per-channel fluxes [E,F]" if xslab else
+                              "all_gather of per-channel fluxes along F" if chsh else
                               "all_gather of flux-vs-time [E,F]") if world > 1 else "none"},
         "roofline": roofline,
     }
