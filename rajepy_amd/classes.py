@@ -47,6 +47,18 @@ def geometry_struct(params, nx, ny, nz, ix0=0, nx_total=0):
     return s
 
 
+def _dist_info():
+    """(rank, world, torch.distributed or None) -- world > 1 only inside an initialised
+    process group (one process per GPU, e.g. under torchrun)."""
+    try:
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized():
+            return dist.get_rank(), dist.get_world_size(), dist
+    except ImportError:
+        pass
+    return 0, 1, None
+
+
 def _load_params_file(py_file, checker):
     if not os.path.exists(py_file):
         raise FileNotFoundError(py_file + " does not exist")
@@ -286,7 +298,10 @@ class JetModel:
     def engine(self):
         if self._engine is None:
             from .engine import RTEngine
-            self._engine = RTEngine(int(os.environ.get("LOCAL_RANK", "0")))
+            # one process per GPU: LOCAL_RANK picks the device (RJP_DEVICE overrides it,
+            # e.g. to rehearse several ranks on one GPU)
+            self._engine = RTEngine(int(os.environ.get("RJP_DEVICE",
+                                                       os.environ.get("LOCAL_RANK", "0"))))
         return self._engine
 
     def _invalidate(self):
@@ -796,7 +811,7 @@ class Pipeline:
                                                            _time.localtime()))
         created = not os.path.exists(self.dcy)
         if created:
-            os.mkdir(self.dcy)
+            os.makedirs(self.dcy, exist_ok=True)      # several ranks may get here together
         self._log = log if log is not None else logger.Log(os.sep.join([self.dcy, log_name]))
         if created:
             self.log.add_entry("INFO", f"Creating pipeline directory, {self.dcy}")
@@ -888,14 +903,26 @@ class Pipeline:
         if resume and os.path.exists(self.model_file):
             self.model = JetModel.load_model(self.model_file, engine=self.model._engine)
 
+        # Multi-GPU (one process per GPU inside an initialised torch.distributed group): the
+        # EPOCHS of the run table are dealt round-robin to the ranks -- every epoch is a pass
+        # over the grid, each rank holds its own copy of the model on its GPU and writes the
+        # products of its runs; only the run results are exchanged at the end.
+        rank, world, dist = _dist_info()
+        years = sorted({float(r.year) for r in self.runs})
+        owner = {y: i % world for i, y in enumerate(years)}
+        mine = [i for i, r in enumerate(self.runs) if owner[float(r.year)] == rank]
+        self._multi_rank = world > 1
+
         if not dryrun:
             # one pass over HBM serves up to eight epochs
-            pending = [r.year * con.year for r in self.runs if r.radiative_transfer and
-                       not (r.completed and resume and not clobber)]
+            pending = [self.runs[i].year * con.year for i in mine
+                       if self.runs[i].radiative_transfer and
+                       not (self.runs[i].completed and resume and not clobber)]
             if pending:
                 self.model.prefetch_epochs(pending)
 
-        for idx, run in enumerate(self.runs):
+        for idx in mine:
+            run = self.runs[idx]
             self.model.time = run.year * con.year
             self.log.add_entry("INFO", "Executing run #{} -> Details:\n{}"
                                        "".format(idx + 1, run.__str__()))
@@ -907,17 +934,31 @@ class Pipeline:
                 if not os.path.exists(run.rt_dcy):
                     self.log.add_entry("INFO", "{} doesn't exist, creating"
                                                "".format(run.rt_dcy), timestamp=False)
-                    os.makedirs(run.rt_dcy)
+                    os.makedirs(run.rt_dcy, exist_ok=True)
                 if not dryrun and run.radiative_transfer:
                     self._radiative_transfer(idx, run, clobber)
             except KeyboardInterrupt:
                 self.log.add_entry("ERROR", "Pipeline interrupted by user, saving state")
-                self.save(self.save_file)
-                self.model.save(self.model_file)
+                if rank == 0:
+                    self.save(self.save_file)
+                    self.model.save(self.model_file)
                 raise KeyboardInterrupt("Pipeline interrupted by user")
             run.completed = True                                   # classes.py:2853
-        self.save(self.save_file)
-        self.model.save(self.model_file)
+
+        if world > 1:
+            # one small object gather: {run index: (results, completed)} from every rank
+            local = {i: (self.runs[i].results, self.runs[i].completed) for i in mine}
+            parts = [None] * world
+            dist.all_gather_object(parts, local)
+            for part in parts:
+                for i, (res, done) in part.items():
+                    self.runs[i].results = res
+                    self.runs[i].completed = done
+        if rank == 0:
+            self.save(self.save_file)
+            self.model.save(self.model_file)
+        if world > 1:
+            dist.barrier()
 
     def _radiative_transfer(self, idx, run, clobber):
         m = self.model
@@ -962,6 +1003,9 @@ class Pipeline:
             else:
                 flux = np.nansum(np.nansum(fluxes, axis=1), axis=1)     # classes.py:2471
         self.runs[idx].results['flux'] = flux
-        if not os.path.exists(self.model_file):
-            m.save(self.model_file)
-        self.save(self.save_file, absolute_directories=True)
+        if not getattr(self, "_multi_rank", False):
+            # single process: checkpoint after every run as the reference does
+            # (classes.py:2475-2479); with several ranks rank 0 saves once at the end
+            if not os.path.exists(self.model_file):
+                m.save(self.model_file)
+            self.save(self.save_file, absolute_directories=True)

@@ -68,3 +68,43 @@ def test_gathers_gloo(world, n_epochs):
     ret = mgr.dict()
     mp.spawn(_worker, args=(world, _free_port(), n_epochs, ret), nprocs=world, join=True)
     assert all(ret[r] for r in range(world)), dict(ret)
+
+
+def _pipeline_worker(rank, world, port, dcy, ret):
+    """Pipeline.execute under a 2-rank gloo group, dry run (no GPU here): epochs are dealt to
+    the ranks, results/completion flags are gathered, rank 0 writes the state files."""
+    import pickle
+    from rajepy_amd import classes, logger
+    from tests.test_host_logic import example_params, pline_params
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        log = logger.Log(os.path.join(dcy, "rank%d.log" % rank), verbose=False)
+        pp = pline_params(dcy)
+        pp["continuum"]["times"] = np.array([0., 0.5, 1., 1.5, 2.])
+        pl = classes.Pipeline(classes.JetModel(example_params(), log=log), pp, log=log)
+        pl.execute(simobserve=False, verbose=False, dryrun=True, resume=False, clobber=True)
+        text = open(log.filename).read()
+        years = sorted({float(r.year) for r in pl.runs})
+        mine = {y for i, y in enumerate(years) if i % world == rank}
+        executed = {float(r.year) for i, r in enumerate(pl.runs)
+                    if "Executing run #%d " % (i + 1) in text}
+        ok = executed == mine and all(r.completed for r in pl.runs)
+        dist.barrier()
+        if rank == 0:
+            saved = pickle.load(open(os.path.join(dcy, "pipeline.save"), "rb"))
+            ok = ok and len(saved["runs"]) == len(pl.runs) and all(r.completed for r in saved["runs"])
+            ok = ok and os.path.exists(os.path.join(dcy, "jetmodel.save"))
+        ret[rank] = bool(ok)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_pipeline_epoch_sharding_gloo(tmp_path):
+    dcy = str(tmp_path / "out")
+    os.makedirs(dcy)
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_pipeline_worker, args=(2, _free_port(), dcy, ret), nprocs=2, join=True)
+    assert all(ret[r] for r in range(2)), dict(ret)
