@@ -59,6 +59,22 @@ def _dist_info():
     return 0, 1, None
 
 
+def _to_host(tensor):
+    """Device tensor -> NumPy array.  Large products go through page-locked memory (6x the
+    pageable rate on MI355X: 19 ms instead of 121 ms for the 1.07 GB cfg4 cubes); the array
+    returned is backed by that buffer, which PyTorch's host allocator recycles once the array
+    is dropped."""
+    import torch
+    if tensor.is_cuda and tensor.numel() * tensor.element_size() >= (8 << 20):
+        try:
+            host = torch.empty(tensor.shape, dtype=tensor.dtype, pin_memory=True)
+            host.copy_(tensor)
+            return host.numpy()
+        except RuntimeError:
+            pass                                   # page-locked allocation refused: plain copy
+    return tensor.cpu().numpy()
+
+
 def _load_params_file(py_file, checker):
     if not os.path.exists(py_file):
         raise FileNotFoundError(py_file + " does not exist")
@@ -443,7 +459,7 @@ class JetModel:
         return self._scan_cache[t] + (self._tavg,)
 
     def _map(self, tensor, lead=()):
-        return tensor.cpu().numpy().reshape(*lead, self.nx, self.nz)
+        return _to_host(tensor).reshape(*lead, self.nx, self.nz)
 
     def _ff_products(self, freq, tau=False, flux=False, intensity=False, device=False):
         from . import engine as E
@@ -486,7 +502,7 @@ class JetModel:
         else:
             out = self.engine.rrl_cells(dev, self._rjp_bursts(), float(self.time),
                                         _lib.Line(**mrrl.line_constants(rrl)), freqs)
-        arr = out.cpu().numpy().reshape(len(freqs), self.nx, self.ny, self.nz)
+        arr = _to_host(out).reshape(len(freqs), self.nx, self.ny, self.nz)
         return arr[0] if scalar else arr
 
     # ------------------------------------------------------------------ RT methods ----

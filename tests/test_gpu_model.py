@@ -197,6 +197,42 @@ def test_pipeline_execute_matches_reference_products(tmp_path):
     assert "previously completed, skipping" in open(pl2.log.filename).read()
 
 
+def test_pipeline_reuses_existing_products(tmp_path):
+    """clobber=False with products on disk: fluxes are read back from the FITS files instead
+    of being recomputed (classes.py:2393-2453) and give the same run results."""
+    dcy = str(tmp_path / "out")
+    os.makedirs(dcy)
+    log = logger.Log(os.path.join(dcy, "model.log"), verbose=False)
+    pl = classes.Pipeline(classes.JetModel(example_params(), log=log), pline_params(dcy), log=log)
+    pl.execute(simobserve=False, verbose=False, resume=False, clobber=True)
+    first = [np.atleast_1d(r.results["flux"]).copy() for r in pl.runs]
+    mtimes = {f: os.path.getmtime(os.path.join(r, f)) for r, _, fs in os.walk(dcy) for f in fs
+              if f.endswith(".fits")}
+    log2 = logger.Log(os.path.join(dcy, "again.log"), verbose=False)
+    pl2 = classes.Pipeline(classes.JetModel(example_params(), log=log2), pline_params(dcy), log=log2)
+    pl2.execute(simobserve=False, verbose=False, resume=False, clobber=False)
+    for a, r in zip(first, pl2.runs):
+        # read back in FITS axis order (F, n_z, n_x): the sum runs in another order
+        np.testing.assert_allclose(np.atleast_1d(r.results["flux"]), a, rtol=1e-14)
+    assert "Fluxes already exist" in open(pl2.log.filename).read()
+    for r, _, fs in os.walk(dcy):
+        for f in fs:
+            if f.endswith(".fits"):
+                assert os.path.getmtime(os.path.join(r, f)) == mtimes[f]      # untouched
+
+
+def test_large_products_take_the_pinned_path(tmp_path):
+    """Cubes above 8 MiB are returned through page-locked memory; values are unaffected."""
+    p = example_params()
+    p["grid"].update(n_x=128, n_y=64, n_z=128)
+    jm = classes.JetModel(p, log=logger.Log(str(tmp_path / "a.log"), verbose=False))
+    freqs = np.geomspace(1e9, 5e10, 80)                    # 80 x 128 x 128 x 8 B = 10.5 MB
+    cube = jm.flux_ff(freqs)
+    assert cube.shape == (80, 128, 128) and cube.dtype == np.float64
+    np.testing.assert_array_equal(cube[17], jm.flux_ff(float(freqs[17])))
+    np.testing.assert_array_equal(np.nan_to_num(cube[3:5]), np.nan_to_num(jm.flux_ff(freqs[3:5])))
+
+
 def test_main_cli(tmp_path):
     from rajepy_amd import main as cli
     model = tmp_path / "model-params.py"
