@@ -77,7 +77,7 @@ __device__ __forceinline__ void scan_rows(const FieldPtrs<T>& f, int64_t off, in
           tl[k] = ep.t[e] - ts[u][v];
           red[k] = signbit_d(nd[u][v]);
         }
-    chi_batch<NB>(b, red, tl, chi);
+    chi_batch<NB, sizeof(T) == 4>(b, red, tl, chi);
   }
 
 #pragma unroll
