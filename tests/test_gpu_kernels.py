@@ -360,3 +360,51 @@ def test_y_bounds_skip_is_exact(eng, dtype):
     for a, b in zip(got, ref):
         assert torch.equal(torch.nan_to_num(a, nan=-1.0), torch.nan_to_num(b, nan=-1.0))
     assert torch.equal(got_rrl, ref_rrl)
+
+
+@pytest.mark.parametrize("shape", [(1, 1, 2), (2, 3, 4), (1, 17, 6), (5, 2, 2), (3, 16, 18),
+                                   (2, 33, 64), (7, 5, 130), (4, 257, 8), (2, 1000, 3)])
+def test_shape_edge_cases_with_and_without_bounds(eng, shape):
+    """Degenerate and ragged shapes (single row/column, n_y below the unroll and y-split sizes,
+    n_z odd / not a multiple of the lane width, tile tails), sparse random masks, both field
+    widths, scans with and without the occupied-range shortcut -- continuum and RRL."""
+    from rajepy_amd import _lib, engine as E
+    from rajepy_amd.maths import rrls
+    rng = np.random.default_rng(sum(shape))
+    g = U.synth_host(shape, 4242, 1)
+    hole = rng.random(shape) < 0.6                      # 60 % of the cells outside the "jet"
+    for k in ("nd", "xi", "temp", "ff", "areas", "vy"):
+        g[k] = np.where(hole, np.nan, g[k])
+    p = copy.deepcopy(U.load_golden("cfg1_example")[2])
+    p["ejection"] = U.example_bursts_params()
+    p["power_laws"]["q_T"] = -0.5
+    p["grid"].update(n_x=shape[0], n_y=shape[1], n_z=shape[2])
+    jet = orc.OracleJet.from_fields(p, g["nd"], g["xi"], g["temp"], g["ff"], g["areas"],
+                                    g["ts"], g["rr"], g["vy"])
+    jet.time = 1.1 * orc.YEAR
+    freqs = np.array([3e9, 2e10])
+    rf = orc.chan_freqs(rrls.rrl_nu_0("H", 66, 1), 5 * 3e5, 3e5)
+    line = _lib.Line(**rrls.line_constants("H66a"))
+    ref_tau, ref_em = jet.optical_depth_ff(freqs), jet.emission_measure()
+    ref_flux, ref_rrl = jet.flux_ff(freqs), jet.optical_depth_rrl("H66a", np.asarray(rf))
+    bursts = U.bursts_from_oracle(jet)
+    ctau, cflux = E.ff_channel_coeffs(freqs, jet.csize, p["target"]["dist"], E.RJP_GFF_POWERLAW)
+    for dtype in (8, 4):
+        tol = 1e-10 if dtype == 8 else RTOL
+        fields = _upload(eng, g, jet.csize, dtype)
+        for use_bounds in (False, True):
+            if use_bounds:
+                eng.compute_y_bounds(fields)
+            sumA, em, tavg = eng.ff_scan(fields, bursts, [jet.time], E.RJP_GFF_POWERLAW)
+            tau, flux, _ = eng.ff_maps(sumA, tavg, ctau, cflux)
+            trrl = eng.rrl_scan(fields, bursts, jet.time, line, rf)
+            eng.synchronize()
+            np.testing.assert_allclose(tau.cpu().numpy().reshape(ref_tau.shape), ref_tau, rtol=tol)
+            np.testing.assert_allclose(em.cpu().numpy().reshape(ref_em.shape), ref_em, rtol=tol)
+            got = flux.cpu().numpy().reshape(ref_flux.shape)
+            assert np.array_equal(np.isnan(got), np.isnan(ref_flux))
+            # 1 - exp(-tau) amplifies the last-bit difference between libm's and the
+            # device's exp by 1/tau; these thin columns reach tau ~ 1e-6
+            np.testing.assert_allclose(got, ref_flux, rtol=max(tol, 1e-9))
+            np.testing.assert_allclose(trrl.cpu().numpy().reshape(ref_rrl.shape), ref_rrl,
+                                       rtol=max(tol, 1e-9))
