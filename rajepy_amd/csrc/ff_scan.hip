@@ -10,6 +10,7 @@
 // second kernel reduces them in a fixed order (bitwise reproducible, no atomics).
 // HBM-bound: algorithmic bytes = 5 fields * sizeof(T) per cell per epoch tile.
 #include <algorithm>
+#include <cmath>
 
 #include "rjp_device.h"
 
@@ -27,7 +28,10 @@ struct FieldPtrs {
 };
 
 template <int ET>
-struct EpochTile { double t[ET]; };
+struct EpochTile {
+  double t[ET];
+  UnifDev un;        // uniform-spacing recurrence for the burst factor (ET >= 4 only)
+};
 
 constexpr int kBlock = 256;
 // y-rows of loads kept in flight per lane; fewer when many accumulators are live so the
@@ -46,7 +50,7 @@ __host__ __device__ constexpr int nacc(int et) { return 2 * et + 2; }
 // then the burst factors of all U*VEC*ET (cell, epoch) pairs as ONE batch so their exp()
 // polynomial chains interleave (FP64 FMA latency is what limits a single chain), then the
 // accumulation.
-template <typename T, int VEC, int ET, int MODE, bool BURSTS, int U>
+template <typename T, int VEC, int ET, int MODE, bool BURSTS, bool UNIF, int U>
 __device__ __forceinline__ void scan_rows(const FieldPtrs<T>& f, int64_t off, int64_t stride,
                                           const BurstsDev& b, const EpochTile<ET>& ep,
                                           double (&accA)[ET][VEC], double (&accE)[ET][VEC],
@@ -64,7 +68,19 @@ __device__ __forceinline__ void scan_rows(const FieldPtrs<T>& f, int64_t off, in
 
   constexpr int NB = ET * U * VEC;
   double chi[NB];
-  if (BURSTS) {
+  if (BURSTS && UNIF) {
+    // uniformly spaced epochs: two exp() per (cell, burst) for the whole tile
+    double tlm[U * VEC];
+    bool red[U * VEC];
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) {
+        tlm[u * VEC + v] = ep.t[ET / 2] - ts[u][v];
+        red[u * VEC + v] = signbit_d(nd[u][v]);
+      }
+    chi_batch_uniform<ET, U * VEC>(b, ep.un, red, tlm, chi);
+  } else if (BURSTS) {
     double tl[NB];
     bool red[NB];
 #pragma unroll
@@ -109,7 +125,7 @@ __device__ __forceinline__ void scan_rows(const FieldPtrs<T>& f, int64_t off, in
   }
 }
 
-template <typename T, int VEC, int ET, int MODE, bool BURSTS>
+template <typename T, int VEC, int ET, int MODE, bool BURSTS, bool UNIF>
 __global__ __launch_bounds__(kBlock) void ff_scan_kernel(
     FieldPtrs<T> f, int ny, int nz, int64_t nchunks, int64_t npix, int ylen, BurstsDev b,
     EpochTile<ET> ep, double* __restrict__ ws) {
@@ -151,11 +167,11 @@ __global__ __launch_bounds__(kBlock) void ff_scan_kernel(
 
   int y = y0;
   for (; y + kUnroll <= y1; y += kUnroll) {
-    scan_rows<T, VEC, ET, MODE, BURSTS, kUnroll>(f, off, stride, b, ep, accA, accE, accT, cnt);
+    scan_rows<T, VEC, ET, MODE, BURSTS, UNIF, kUnroll>(f, off, stride, b, ep, accA, accE, accT, cnt);
     off += kUnroll * stride;
   }
   for (; y < y1; ++y) {
-    scan_rows<T, VEC, ET, MODE, BURSTS, 1>(f, off, stride, b, ep, accA, accE, accT, cnt);
+    scan_rows<T, VEC, ET, MODE, BURSTS, UNIF, 1>(f, off, stride, b, ep, accA, accE, accT, cnt);
     off += stride;
   }
 
@@ -382,6 +398,37 @@ size_t ff_scan_workspace_bytes(int nx, int ny, int nz, int n_epochs) {
   return (size_t)s * nacc(et > 8 ? 8 : et) * npix * sizeof(double) + 256;
 }
 
+// Decide whether a tile of epochs may use the uniform-spacing recurrence and fill its
+// per-burst constants.  RJP_NO_UNIFORM=1 forces the direct evaluation (A/B, tests).
+static void uniform_tile(const double* t, int et, const BurstsDev& b, UnifDev& un) {
+  un.on = 0;
+  un.dt = 0.0;
+  for (int j = 0; j < 2; ++j)
+    for (int i = 0; i < RJP_MAX_BURSTS; ++i) un.q[j][i] = 1.0;
+  static int disabled = -1;
+  if (disabled < 0) disabled = getenv("RJP_NO_UNIFORM") ? 1 : 0;
+  if (et < 4 || disabled) return;
+  const double dt = (t[et - 1] - t[0]) / (et - 1);
+  double tmax = 0.0, dev = 0.0;
+  for (int e = 0; e < et; ++e) {
+    tmax = std::max(tmax, std::fabs(t[e]));
+    dev = std::max(dev, std::fabs(t[e] - (t[0] + e * dt)));
+  }
+  if (!(dev <= 8.0 * 2.220446049250313e-16 * tmax)) return;     // not (numerically) uniform
+  const int m = et / 2;
+  const double half_span = std::max(m, et - 1 - m) * std::fabs(dt);
+  for (int j = 0; j < 2; ++j)
+    for (int i = 0; i < b.n[j]; ++i) {
+      const double inv = b.inv2s2[j][i];
+      if (!(inv > 0.0)) return;
+      const double sigma = std::sqrt(0.5 / inv);
+      if (!(half_span <= 28.0 * sigma)) return;   // anchor underflow would hide live epochs
+      un.q[j][i] = std::exp(-2.0 * inv * dt * dt);
+    }
+  un.on = 1;
+  un.dt = dt;
+}
+
 template <typename T, int VEC, int ET, int MODE, bool BURSTS>
 static hipError_t launch_tile(const rjp_fields* fl, const BurstsDev& b, const double* t,
                               int nsplit, int ylen, double* ws, hipStream_t st) {
@@ -389,11 +436,21 @@ static hipError_t launch_tile(const rjp_fields* fl, const BurstsDev& b, const do
                  (const T*)fl->d_pf, (const T*)fl->d_ts, fl->d_ylo, fl->d_yhi};
   EpochTile<ET> ep;
   for (int e = 0; e < ET; ++e) ep.t[e] = t[e];
+  uniform_tile(t, ET, b, ep.un);
   const int64_t npix = (int64_t)fl->nx * fl->nz;
   const int64_t nchunks = npix / VEC;
   dim3 grid((unsigned)((nchunks + kBlock - 1) / kBlock), (unsigned)nsplit);
-  hipLaunchKernelGGL((ff_scan_kernel<T, VEC, ET, MODE, BURSTS>), grid, dim3(kBlock), 0, st, f,
-                     fl->ny, fl->nz, nchunks, npix, ylen, b, ep, ws);
+  // the recurrence pays only with the FP64 exp (f32 storage uses a 9-instruction exp) and
+  // with at least 4 epochs per tile
+  if constexpr (BURSTS && ET >= 4 && sizeof(T) == 8) {
+    if (ep.un.on) {
+      hipLaunchKernelGGL((ff_scan_kernel<T, VEC, ET, MODE, true, true>), grid, dim3(kBlock), 0,
+                         st, f, fl->ny, fl->nz, nchunks, npix, ylen, b, ep, ws);
+      return hipGetLastError();
+    }
+  }
+  hipLaunchKernelGGL((ff_scan_kernel<T, VEC, ET, MODE, BURSTS, false>), grid, dim3(kBlock), 0,
+                     st, f, fl->ny, fl->nz, nchunks, npix, ylen, b, ep, ws);
   return hipGetLastError();
 }
 

@@ -182,6 +182,81 @@ __device__ __forceinline__ void chi_batch(const BurstsDev& b, const bool (&red)[
   }
 }
 
+// Uniformly spaced epochs t_e = t_m + (e - m) dt: for one burst the Gaussian exponents of a
+// cell form a quadratic in e, so E_e = exp(arg_e) obeys E_{e+1} = E_e R_e, R_{e+1} = R_e Q
+// with Q = exp(-2 inv dt^2) the same for every cell.  Two exp() per (cell, burst) serve the
+// whole tile instead of one per epoch.  The anchor is the middle epoch m; when its Gaussian
+// underflows (arg_m < -700) every epoch of the tile is negligible -- the launcher guarantees
+// that by using this path only while the tile's half-span is below 28 sigma of the
+// narrowest burst.
+struct UnifDev {
+  int on;                                   // 0 = evaluate every epoch directly
+  double dt;                                // epoch spacing [s]
+  double q[2][RJP_MAX_BURSTS];              // exp(-2 inv2s2 dt^2)
+};
+
+template <int ET, int UV>
+__device__ __forceinline__ void chi_batch_uniform(const BurstsDev& b, const UnifDev& un,
+                                                  const bool (&red)[UV],
+                                                  const double (&tlm)[UV],   // anchor epoch
+                                                  double (&chi)[ET * UV]) {
+  constexpr int M = ET / 2;
+  bool any_red = false, any_blue = false;
+#pragma unroll
+  for (int c = 0; c < UV; ++c) { any_red |= red[c]; any_blue |= !red[c]; }
+  const bool wave_red = __builtin_amdgcn_ballot_w64(any_red) != 0;
+  const bool wave_blue = __builtin_amdgcn_ballot_w64(any_blue) != 0;
+  const bool mixed = wave_red && wave_blue;
+  const int jet = wave_red ? 0 : 1;
+#pragma unroll
+  for (int k = 0; k < ET * UV; ++k) chi[k] = 1.0;
+  const int nb = mixed ? (b.n[0] > b.n[1] ? b.n[0] : b.n[1]) : b.n[jet];
+  auto one = [&](int i, int c) __attribute__((always_inline)) {
+    const bool r = mixed ? red[c] : (jet == 0);
+    const double t0 = r ? b.t0[0][i] : b.t0[1][i];
+    const double inv = r ? b.inv2s2[0][i] : b.inv2s2[1][i];
+    const double amp = r ? b.amp_rel[0][i] : b.amp_rel[1][i];
+    const double q = r ? un.q[0][i] : un.q[1][i];
+    const double vm = tlm[c] - t0;
+    const double argm = -(vm * vm) * inv;
+    const bool dead = argm < -700.0;
+    const double em = exp_nonpos(argm);
+    const double idt = inv * un.dt;
+    const double xr = -__builtin_fma(2.0 * idt, vm, idt * un.dt);    // ln(E_{m+1} / E_m)
+    const double rup = exp_any(xr);
+    // E_{m-1} / E_m = q / rup: hardware reciprocal + one Newton step (rup is a finite
+    // normal number whenever the cell is not `dead`)
+    double ir = __builtin_amdgcn_rcp(rup);
+    ir = ir * __builtin_fma(-rup, ir, 2.0);
+    const double rdn = q * ir;
+    const double a = dead ? 0.0 : amp;          // a dead cell adds exactly nothing ...
+    const double em0 = dead ? 0.0 : em;         // ... and must not turn 0 * inf into NaN
+    chi[M * UV + c] = __builtin_fma(a, em0, chi[M * UV + c]);
+    double e = em0, rr = dead ? 0.0 : rup;
+#pragma unroll
+    for (int j = M + 1; j < ET; ++j) {
+      e *= rr; rr *= q;
+      chi[j * UV + c] = __builtin_fma(a, e, chi[j * UV + c]);
+    }
+    e = em0; rr = dead ? 0.0 : rdn;
+#pragma unroll
+    for (int j = M - 1; j >= 0; --j) {
+      e *= rr; rr *= q;
+      chi[j * UV + c] = __builtin_fma(a, e, chi[j * UV + c]);
+    }
+  };
+  // two bursts per trip: their exp chains are independent and interleave
+  int i = 0;
+  for (; i + 1 < nb; i += 2) {
+#pragma unroll
+    for (int c = 0; c < UV; ++c) { one(i, c); one(i + 1, c); }
+  }
+  for (; i < nb; ++i) {
+#pragma unroll
+    for (int c = 0; c < UV; ++c) one(i, c);
+  }
+}
+
 // T^-1.5 with an f32 rsqrt seed + one fp64 Newton step (rel. err < 1e-13); exact-ish slow
 // path outside the f32 exponent range and for T == 0 / inf / negative.
 __device__ __attribute__((noinline)) double pow_m1p5_slow(double T) {

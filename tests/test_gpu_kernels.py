@@ -408,3 +408,31 @@ def test_shape_edge_cases_with_and_without_bounds(eng, shape):
             np.testing.assert_allclose(got, ref_flux, rtol=max(tol, 1e-9))
             np.testing.assert_allclose(trrl.cpu().numpy().reshape(ref_rrl.shape), ref_rrl,
                                        rtol=max(tol, 1e-9))
+
+
+@pytest.mark.parametrize("dtype", [8, 4])
+@pytest.mark.parametrize("n_ep,t1", [(8, 3.5), (16, 5.0), (12, 0.55), (4, 2.0)])
+def test_uniform_epoch_sweeps_use_the_recurrence_correctly(eng, dtype, n_ep, t1):
+    """Uniformly spaced epochs take the two-exp-per-burst recurrence (tiles of 8 and 4, and a
+    ragged tail); results must equal the oracle at every epoch, including epochs far from any
+    burst (anchor Gaussian underflows) and bursts that peak inside a tile."""
+    from rajepy_amd import engine as E
+    shape = (4, 37, 16)
+    seed = 20240507
+    fields = eng.synth_fields(shape, seed, 0, dtype, csize_au=0.5)
+    g = U.synth_host(shape, seed, 0)
+    p = copy.deepcopy(U.load_golden("cfg1_example")[2])
+    p["ejection"] = U.example_bursts_params()
+    p["ejection"]["hl"] = np.array([0.02, 0.15, 0.45, 0.5])      # one very narrow burst
+    p["grid"].update(n_x=shape[0], n_y=shape[1], n_z=shape[2])
+    jet = orc.OracleJet.from_fields(p, g["nd"], g["xi"], g["temp"], g["ff"], g["areas"],
+                                    g["ts"], g["rr"], g["vy"])
+    years = np.linspace(0., t1, n_ep)
+    sumA, em, tavg = eng.ff_scan(fields, U.bursts_from_oracle(jet), years * orc.YEAR,
+                                 E.RJP_GFF_SCALAR)
+    eng.synchronize()
+    tol = 1e-11 if dtype == 8 else RTOL
+    em_h = em.cpu().numpy().reshape(n_ep, shape[0], shape[2])
+    for e, yr in enumerate(years):
+        jet.time = yr * orc.YEAR
+        np.testing.assert_allclose(em_h[e], jet.emission_measure(), rtol=tol, err_msg=str(e))
