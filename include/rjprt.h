@@ -30,7 +30,7 @@ extern "C" {
 
 #define RJP_VERSION 100          /* 0.1.0 */
 #define RJP_MAX_BURSTS 8         /* per jet (red / blue) */
-#define RJP_MAX_EPOCH_TILE 8     /* epochs evaluated per grid pass */
+#define RJP_MAX_EPOCH_TILE 16    /* most epochs evaluated per grid pass (uniformly spaced, f64 lanes; else 8) */
 
 enum rjp_status {
   RJP_OK = 0,
@@ -121,7 +121,7 @@ int rjp_y_bounds(rjp_ctx* ctx, const rjp_fields* fields, int32_t* d_ylo, int32_t
  * Replaces the y-reductions of JetModel.emission_measure (classes.py:1116-1120),
  * .optical_depth_ff (1375-1432) and the nanmean of .intensity_ff (1471-1472, 1484-1485),
  * with number_density = _nd * chi_xyz (classes.py:861-875) evaluated in registers for
- * each of E epochs.  One pass over the grid per tile of RJP_MAX_EPOCH_TILE epochs.
+ * each of E epochs.  One pass over the grid per tile of up to RJP_MAX_EPOCH_TILE epochs.
  *   d_sumA [E*P]  sum_y T^-1.5 (n x)^2 pf          (RJP_GFF_SCALAR)
  *                 sum_y T^-1.35 (n x)^2 pf         (RJP_GFF_POWERLAW)   [cm^-6 K^-1.5|-1.35]
  *   d_em   [E*P]  emission measure [pc cm^-6]      (may be NULL)

@@ -34,6 +34,7 @@ struct EpochTile {
 };
 
 constexpr int kBlock = 256;
+constexpr int kMaxTile = 16;     // largest epoch tile (uniformly spaced epochs, f64 lanes)
 // y-rows of loads kept in flight per lane; fewer when many accumulators are live so the
 // kernel stays inside the 256-VGPR budget without scratch
 #ifndef RJP_UNROLL_BASE
@@ -76,7 +77,7 @@ __device__ __forceinline__ void scan_rows(const FieldPtrs<T>& f, int64_t off, in
     for (int u = 0; u < U; ++u)
 #pragma unroll
       for (int v = 0; v < VEC; ++v) {
-        tlm[u * VEC + v] = ep.t[ET / 2] - ts[u][v];
+        tlm[u * VEC + v] = ep.t[ET / 2] - (ts[u][v] == ts[u][v] ? ts[u][v] : 0.0);
         red[u * VEC + v] = signbit_d(nd[u][v]);
       }
     chi_batch_uniform<ET, U * VEC>(b, ep.un, red, tlm, chi);
@@ -90,7 +91,7 @@ __device__ __forceinline__ void scan_rows(const FieldPtrs<T>& f, int64_t off, in
 #pragma unroll
         for (int v = 0; v < VEC; ++v) {
           const int k = (e * U + u) * VEC + v;
-          tl[k] = ep.t[e] - ts[u][v];
+          tl[k] = ep.t[e] - (ts[u][v] == ts[u][v] ? ts[u][v] : 0.0);
           red[k] = signbit_d(nd[u][v]);
         }
     chi_batch<NB, sizeof(T) == 4>(b, red, tl, chi);
@@ -109,13 +110,18 @@ __device__ __forceinline__ void scan_rows(const FieldPtrs<T>& f, int64_t off, in
       const double a = g * tpow;
       if (Tk > 0.0) { accT[v] += Tk; cnt[v] += 1.0; }
       if (BURSTS) {
+        // nansum semantics hoisted out of the epoch loop: g chi^2 is NaN iff g is NaN or
+        // chi is (chi is NaN iff the launch time is -- such cells were given chi = 1 above);
+        // a masked cell contributes an exact zero at every epoch
+        const bool tsok = ts[u][v] == ts[u][v];
+        const double gm = (g == g && tsok) ? g : 0.0;
+        const double am = (a == a && tsok) ? a : 0.0;
 #pragma unroll
         for (int e = 0; e < ET; ++e) {
           const double c = chi[(e * U + u) * VEC + v];
           const double c2 = c * c;
-          const double ge = g * c2, ae = a * c2;
-          if (ge == ge) accE[e][v] += ge;            // nansum: skip NaN only (inf propagates)
-          if (ae == ae) accA[e][v] += ae;
+          accE[e][v] = __builtin_fma(gm, c2, accE[e][v]);
+          accA[e][v] = __builtin_fma(am, c2, accA[e][v]);
         }
       } else {
         if (g == g) accE[0][v] += g;
@@ -386,8 +392,7 @@ int ff_scan_vec(const rjp_fields* fl) {
 
 size_t ff_scan_workspace_bytes(int nx, int ny, int nz, int n_epochs) {
   const int64_t npix = (int64_t)nx * nz;
-  const int et = n_epochs < RJP_MAX_EPOCH_TILE ? (n_epochs < 1 ? 1 : n_epochs)
-                                               : RJP_MAX_EPOCH_TILE;
+  const int et = n_epochs < kMaxTile ? (n_epochs < 1 ? 1 : n_epochs) : kMaxTile;
   // worst case split count is bounded by choose_ysplit's target / (npix/4/64) and ny/16
   int64_t smax = std::max(1, ny / 16);
   const int64_t waves_min = std::max<int64_t>(1, (npix / 4 + RJP_WAVE - 1) / RJP_WAVE);
@@ -395,7 +400,7 @@ size_t ff_scan_workspace_bytes(int nx, int ny, int nz, int n_epochs) {
   if (const char* f = getenv("RJP_YSPLIT")) s = std::max<int64_t>(s, atoi(f));
   s = std::min(s, smax);
   s = std::max<int64_t>(s, 1);
-  return (size_t)s * nacc(et > 8 ? 8 : et) * npix * sizeof(double) + 256;
+  return (size_t)s * nacc(et) * npix * sizeof(double) + 256;
 }
 
 // Decide whether a tile of epochs may use the uniform-spacing recurrence and fill its
@@ -449,9 +454,12 @@ static hipError_t launch_tile(const rjp_fields* fl, const BurstsDev& b, const do
       return hipGetLastError();
     }
   }
-  hipLaunchKernelGGL((ff_scan_kernel<T, VEC, ET, MODE, BURSTS, false>), grid, dim3(kBlock), 0,
-                     st, f, fl->ny, fl->nz, nchunks, npix, ylen, b, ep, ws);
-  return hipGetLastError();
+  if constexpr (ET <= 8) {
+    hipLaunchKernelGGL((ff_scan_kernel<T, VEC, ET, MODE, BURSTS, false>), grid, dim3(kBlock), 0,
+                       st, f, fl->ny, fl->nz, nchunks, npix, ylen, b, ep, ws);
+    return hipGetLastError();
+  }
+  return hipErrorInvalidValue;       // a 16-epoch tile that is not uniform: launcher bug
 }
 
 template <typename T, int VEC, int MODE>
@@ -468,6 +476,11 @@ static hipError_t dispatch_et(const rjp_fields* fl, const BurstsDev& b, bool bur
       // epoch tile at 4 for 4-wide (f32) lanes
       if constexpr (VEC == 4) return hipErrorInvalidValue;
       else return launch_tile<T, VEC, 8, MODE, true>(fl, b, t, nsplit, ylen, ws, st);
+    case 16:
+      // only the uniform-epoch recurrence keeps 16 epochs of state in registers
+      if constexpr (VEC == 2 && sizeof(T) == 8)
+        return launch_tile<T, VEC, 16, MODE, true>(fl, b, t, nsplit, ylen, ws, st);
+      else return hipErrorInvalidValue;
   }
   return hipErrorInvalidValue;
 }
@@ -502,6 +515,11 @@ hipError_t ff_scan_launch(const rjp_fields* fl, const rjp_bursts* hb, const doub
     if (bursts) {
       const int left = n_epochs - e0;
       et = (left >= 8 && vec != 4) ? 8 : left >= 4 ? 4 : left >= 2 ? 2 : 1;
+      if (left >= 16 && vec == 2 && fl->dtype == RJP_F64) {
+        UnifDev probe;
+        uniform_tile(epochs + e0, 16, b, probe);
+        if (probe.on) et = 16;
+      }
     }
     hipError_t err;
     const double* t = epochs + e0;
