@@ -387,7 +387,9 @@ int ff_scan_vec(const rjp_fields* fl) {
   for (const void* p : ptrs)
     if (p && ((uintptr_t)p % 16) != 0) ok = false;
   (void)esz;
-  return ok ? full : 1;
+  static int force1 = -1;
+  if (force1 < 0) force1 = getenv("RJP_FORCE_VEC1") ? 1 : 0;     // experiments only
+  return (ok && !force1) ? full : 1;
 }
 
 size_t ff_scan_workspace_bytes(int nx, int ny, int nz, int n_epochs) {
@@ -478,7 +480,7 @@ static hipError_t dispatch_et(const rjp_fields* fl, const BurstsDev& b, bool bur
       else return launch_tile<T, VEC, 8, MODE, true>(fl, b, t, nsplit, ylen, ws, st);
     case 16:
       // only the uniform-epoch recurrence keeps 16 epochs of state in registers
-      if constexpr (VEC == 2 && sizeof(T) == 8)
+      if constexpr (VEC <= 2 && sizeof(T) == 8)
         return launch_tile<T, VEC, 16, MODE, true>(fl, b, t, nsplit, ylen, ws, st);
       else return hipErrorInvalidValue;
   }
@@ -515,7 +517,7 @@ hipError_t ff_scan_launch(const rjp_fields* fl, const rjp_bursts* hb, const doub
     if (bursts) {
       const int left = n_epochs - e0;
       et = (left >= 8 && vec != 4) ? 8 : left >= 4 ? 4 : left >= 2 ? 2 : 1;
-      if (left >= 16 && vec == 2 && fl->dtype == RJP_F64) {
+      if (left >= 16 && vec <= 2 && fl->dtype == RJP_F64) {
         UnifDev probe;
         uniform_tile(epochs + e0, 16, b, probe);
         if (probe.on) et = 16;
@@ -524,8 +526,11 @@ hipError_t ff_scan_launch(const rjp_fields* fl, const rjp_bursts* hb, const doub
     hipError_t err;
     const double* t = epochs + e0;
     if (fl->dtype == RJP_F64) {
-      err = vec == 2 ? dispatch_mode<double, 2>(fl, b, bursts, mode, t, et, nsplit, ylen, ws, st)
-                     : dispatch_mode<double, 1>(fl, b, bursts, mode, t, et, nsplit, ylen, ws, st);
+      // 16-epoch tiles are ALU-bound and register-hungry: one sightline per lane (160 VGPRs,
+      // 3 waves/SIMD) beats two (256 VGPRs, 1 wave/SIMD) by 15 %
+      err = (vec == 2 && et != 16)
+                ? dispatch_mode<double, 2>(fl, b, bursts, mode, t, et, nsplit, ylen, ws, st)
+                : dispatch_mode<double, 1>(fl, b, bursts, mode, t, et, nsplit, ylen, ws, st);
     } else {
       err = vec == 4 ? dispatch_mode<float, 4>(fl, b, bursts, mode, t, et, nsplit, ylen, ws, st)
                      : dispatch_mode<float, 1>(fl, b, bursts, mode, t, et, nsplit, ylen, ws, st);
