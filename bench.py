@@ -272,9 +272,9 @@ def main():
         kname, extra = "rrl_scan_kernel", {"voigt_evals_per_s": ncell_loc * nchan / (k_ms * 1e-3)}
     else:
         k_ms = eng.time_ff_scan(fields, bursts, my_epochs, E.RJP_GFF_SCALAR, reps=5)
-        # epoch tiles share a pass over the grid: 16 epochs (uniformly spaced, f64 lanes),
-        # else 8 (f64) or 4 (f32 lanes)
-        tile = (16 if E_loc >= 16 else 8) if args.storage == "f64" else 4
+        # epoch tiles share a pass over the grid: 16 uniformly spaced epochs, else 8 (f64
+        # lanes) or 4 (f32 lanes)
+        tile = 16 if E_loc >= 16 else (8 if args.storage == "f64" else 4)
         npass = -(-E_loc // tile) if E_loc > 1 else 1
         alg_bytes = npass * 5 * ncell_loc * int(dtype) + E_loc * P * 2 * 8
         kname, extra = "ff_scan_kernel", {"grid_passes_per_launch": npass}

@@ -447,9 +447,9 @@ static hipError_t launch_tile(const rjp_fields* fl, const BurstsDev& b, const do
   const int64_t npix = (int64_t)fl->nx * fl->nz;
   const int64_t nchunks = npix / VEC;
   dim3 grid((unsigned)((nchunks + kBlock - 1) / kBlock), (unsigned)nsplit);
-  // the recurrence pays only with the FP64 exp (f32 storage uses a 9-instruction exp) and
-  // with at least 4 epochs per tile
-  if constexpr (BURSTS && ET >= 4 && sizeof(T) == 8) {
+  // the recurrence pays with at least 4 epochs per tile; short tiles of f32 storage keep
+  // their 9-instruction float-accuracy exp instead
+  if constexpr (BURSTS && ET >= 4 && (sizeof(T) == 8 || ET == 16)) {
     if (ep.un.on) {
       hipLaunchKernelGGL((ff_scan_kernel<T, VEC, ET, MODE, true, true>), grid, dim3(kBlock), 0,
                          st, f, fl->ny, fl->nz, nchunks, npix, ylen, b, ep, ws);
@@ -480,7 +480,7 @@ static hipError_t dispatch_et(const rjp_fields* fl, const BurstsDev& b, bool bur
       else return launch_tile<T, VEC, 8, MODE, true>(fl, b, t, nsplit, ylen, ws, st);
     case 16:
       // only the uniform-epoch recurrence keeps 16 epochs of state in registers
-      if constexpr (VEC <= 2 && sizeof(T) == 8)
+      if constexpr (VEC == 1)
         return launch_tile<T, VEC, 16, MODE, true>(fl, b, t, nsplit, ylen, ws, st);
       else return hipErrorInvalidValue;
   }
@@ -517,7 +517,7 @@ hipError_t ff_scan_launch(const rjp_fields* fl, const rjp_bursts* hb, const doub
     if (bursts) {
       const int left = n_epochs - e0;
       et = (left >= 8 && vec != 4) ? 8 : left >= 4 ? 4 : left >= 2 ? 2 : 1;
-      if (left >= 16 && vec <= 2 && fl->dtype == RJP_F64) {
+      if (left >= 16) {
         UnifDev probe;
         uniform_tile(epochs + e0, 16, b, probe);
         if (probe.on) et = 16;
@@ -532,8 +532,9 @@ hipError_t ff_scan_launch(const rjp_fields* fl, const rjp_bursts* hb, const doub
                 ? dispatch_mode<double, 2>(fl, b, bursts, mode, t, et, nsplit, ylen, ws, st)
                 : dispatch_mode<double, 1>(fl, b, bursts, mode, t, et, nsplit, ylen, ws, st);
     } else {
-      err = vec == 4 ? dispatch_mode<float, 4>(fl, b, bursts, mode, t, et, nsplit, ylen, ws, st)
-                     : dispatch_mode<float, 1>(fl, b, bursts, mode, t, et, nsplit, ylen, ws, st);
+      err = (vec == 4 && et != 16)
+                ? dispatch_mode<float, 4>(fl, b, bursts, mode, t, et, nsplit, ylen, ws, st)
+                : dispatch_mode<float, 1>(fl, b, bursts, mode, t, et, nsplit, ylen, ws, st);
     }
     if (err != hipSuccess) return err;
     hipLaunchKernelGGL(ff_reduce_kernel, dim3(rblocks), dim3(kBlock), 0, st, ws, nsplit, et,
