@@ -300,9 +300,35 @@ def golden_pipeline(model_params):
     print("pipeline: runs", [(r["obs_type"], r["year"], r["flux"][:2]) for r in rec["runs"]])
 
 
+def golden_as_shipped():
+    """files/example-model-params.py exactly as shipped: l_z = 2 arcsec overrides the grid to
+    108 x 110 x 588 (7 M cells).  Outputs only (the grids are built from the parameters), one
+    epoch inside the burst history."""
+    p = runpy.run_path(os.path.join(REF, "files", "example-model-params.py"))["params"]
+    t0 = time.time()
+    jm = new_model(p, "shipped")
+    jm.time = 1.0 * con.year
+    freqs = np.array([5e9, 4.3e10])
+    nu0 = mrrl.rrl_nu_0("H", 66, 1)
+    rf = nu0 - 4 * 5e5 / 2. + 5e5 / 2. + np.arange(4) * 5e5
+    out = dict(meta=json.dumps(dict(params=scalar_params(jm.params), shape=[jm.nx, jm.ny, jm.nz])),
+               year=1.0, freqs=freqs, rrl_freqs=rf,
+               em=jm.emission_measure(), tau_ff=jm.optical_depth_ff(freqs),
+               flux_ff=jm.flux_ff(freqs), tau_rrl=jm.optical_depth_rrl("H66a", rf),
+               flux_rrl_total=jm.flux_rrl("H66a", rf, contsub=False),
+               n_jet_cells=np.array(int(np.isfinite(jm.fill_factor).sum())))
+    np.savez_compressed(os.path.join(HERE, "example_as_shipped.npz"), **out)
+    print("as shipped: grid %s, %d jet cells, %.0f s; sum flux %s" % (
+        (jm.nx, jm.ny, jm.nz), int(out["n_jet_cells"]), time.time() - t0,
+        np.nansum(out["flux_ff"], axis=(1, 2))))
+
+
 if __name__ == "__main__":
     if sys.argv[1:] == ["scalars"]:          # regenerate scalars.json only
         golden_scalars()
+        sys.exit(0)
+    if sys.argv[1:] == ["shipped"]:          # the 7 M-cell as-shipped example only (~4 min)
+        golden_as_shipped()
         sys.exit(0)
     golden_gff()
     golden_scalars()
@@ -312,3 +338,4 @@ if __name__ == "__main__":
     golden_model("tilted", tilted_params(), years=[0., 0.4, 0.9],
                  freqs=[5e9, 1.5e9, 4.3e10], rrl="H58a", rrl_nchan=6, rrl_cw=4e5)
     golden_pipeline(example_params())
+    golden_as_shipped()

@@ -62,6 +62,32 @@ def test_jetmodel_end_to_end_vs_reference(tmp_path, tag, params, storage, tol):
         jm.intensity_rrl(rrl, float(rf[0]), lte=False)
 
 
+def test_example_file_as_shipped(tmp_path):
+    """files/example-model-params.py exactly as the reference ships it: l_z = 2 arcsec turns
+    the grid into 108 x 110 x 588 (7 M cells, n_z not a multiple of any tile size, 15 % of the
+    cells inside the jet).  Geometry -> fields -> RT on the GPU vs the reference's maps."""
+    z = np.load(os.path.join(U.GOLDEN, "example_as_shipped.npz"))
+    p = json.loads(str(z["meta"]))["params"]
+    for k in ("t_0", "hl", "chi", "which"):
+        p["ejection"][k] = np.array(p["ejection"][k])
+    p["geometry"].pop("mod_r_0")
+    p["power_laws"].pop("q_n"), p["power_laws"].pop("q_tau"), p["properties"].pop("n_0")
+    p["grid"].update(n_x=50, n_y=400, n_z=50)            # as in the file; l_z overrides them
+    assert p["grid"]["l_z"] == 2.0
+    jm = classes.JetModel(p, log=logger.Log(str(tmp_path / "a.log"), verbose=False))
+    assert (jm.nx, jm.ny, jm.nz) == (108, 110, 588)
+    jm.time = float(z["year"]) * YEAR
+    np.testing.assert_allclose(jm.emission_measure(), z["em"], rtol=1e-9)
+    np.testing.assert_allclose(jm.optical_depth_ff(z["freqs"]), z["tau_ff"], rtol=1e-9)
+    flux = jm.flux_ff(z["freqs"])
+    assert np.array_equal(np.isnan(flux), np.isnan(z["flux_ff"]))
+    np.testing.assert_allclose(flux, z["flux_ff"], rtol=1e-9)
+    np.testing.assert_allclose(jm.optical_depth_rrl("H66a", z["rrl_freqs"]), z["tau_rrl"], rtol=1e-8)
+    np.testing.assert_allclose(jm.flux_rrl("H66a", z["rrl_freqs"], contsub=False),
+                               z["flux_rrl_total"], rtol=1e-8)
+    assert int(np.isfinite(jm.fill_factor).sum()) == int(z["n_jet_cells"])
+
+
 def test_jetmodel_setters_and_accessors(tmp_path):
     """Public setters of the reference (ts / ion_fraction / temperature) re-upload a field
     and invalidate cached scans; accessors return reference-shaped host grids."""

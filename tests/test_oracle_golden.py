@@ -132,3 +132,22 @@ def test_pipeline_flux_results():
         np.testing.assert_allclose(got, run["flux"], rtol=1e-13)
         if run["obs_type"] == "continuum":
             np.testing.assert_allclose(orc.chan_freqs(run["freq"], 4e8, 2e8), run["chan_freqs"])
+
+
+def test_oracle_on_the_example_as_shipped():
+    """Third pin: the reference's example file as shipped (l_z = 2 -> 108 x 110 x 588, 7 M
+    cells): oracle builder + RT vs the reference's maps (continuum and one RRL channel)."""
+    z = np.load(os.path.join(GOLDEN, "example_as_shipped.npz"))
+    meta = json.loads(str(z["meta"]))
+    p = params_from_meta(meta)
+    p["grid"]["l_z"] = None                    # the oracle restates the explicit-size branch;
+    assert [p["grid"][k] for k in ("n_x", "n_y", "n_z")] == meta["shape"]   # same grid
+    jet = orc.OracleJet(p)
+    jet.time = float(z["year"]) * orc.YEAR
+    assert int(np.isfinite(jet.fill_factor).sum()) == int(z["n_jet_cells"])
+    np.testing.assert_allclose(jet.emission_measure(), z["em"], rtol=1e-11)
+    np.testing.assert_allclose(jet.optical_depth_ff(float(z["freqs"][0])), z["tau_ff"][0], rtol=1e-11)
+    # thin columns: 1 - exp(-tau) amplifies last-bit differences of exp by 1/tau
+    np.testing.assert_allclose(jet.flux_ff(float(z["freqs"][1])), z["flux_ff"][1], rtol=1e-9)
+    np.testing.assert_allclose(jet.optical_depth_rrl("H66a", float(z["rrl_freqs"][1])),
+                               z["tau_rrl"][1], rtol=1e-10)
