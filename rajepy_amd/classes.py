@@ -505,6 +505,17 @@ class JetModel:
         arr = _to_host(out).reshape(len(freqs), self.nx, self.ny, self.nz)
         return arr[0] if scalar else arr
 
+    def flux_vs_time(self, times_s, freq):
+        """Light curves: total flux density [Jy] of the whole map at every (model time,
+        frequency) -> array (len(times), len(freq)).  The reference gets these numbers by
+        looping `time` and summing `flux_ff` maps (Pipeline results, classes.py:2461-2467);
+        here the maps are reduced on the device and up to 16 epochs share one pass over HBM.
+        Inside a torch.distributed group the epochs are shared out over the ranks."""
+        from . import parallel
+        rank, world, _ = _dist_info()
+        return parallel.sweep_flux_vs_time(self, np.atleast_1d(np.asarray(times_s, float)),
+                                           freq, rank=rank, world=world)
+
     # ------------------------------------------------------------------ RT methods ----
     def emission_measure(self, savefits=False):
         """Emission measure along y [pc cm^-6] (classes.py:1101-1128)."""

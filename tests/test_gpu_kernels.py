@@ -436,3 +436,45 @@ def test_uniform_epoch_sweeps_use_the_recurrence_correctly(eng, dtype, n_ep, t1)
     for e, yr in enumerate(years):
         jet.time = yr * orc.YEAR
         np.testing.assert_allclose(em_h[e], jet.emission_measure(), rtol=tol, err_msg=str(e))
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_field_builder_random_geometries_vs_oracle(eng, seed):
+    """K4 fuzz: random inclinations / position angles / opening angles / power laws / rotation
+    sense on a small grid.  The device jet mask must equal the oracle builder's exactly (the
+    oracle builder is itself pinned to the reference on three models) and every field agree."""
+    from rajepy_amd.classes import geometry_struct
+    rng = np.random.default_rng(1000 + seed)
+    p = copy.deepcopy(U.load_golden("tilted")[2])
+    g, pl, pr = p["geometry"], p["power_laws"], p["properties"]
+    g.update(inc=float(rng.uniform(20, 90)), pa=float(rng.uniform(-180, 180)),
+             opang=float(rng.uniform(10, 60)), epsilon=float(rng.uniform(0.4, 1.0)),
+             w_0=float(rng.uniform(0.8, 2.0)), r_0=float(rng.uniform(0.5, 3.0)),
+             rotation="CCW" if rng.random() < 0.5 else "CW")
+    pl.update({"q_v": float(rng.uniform(-0.3, 0.3)), "q_T": float(rng.uniform(-0.2, 0.1)),
+               "q_x": float(rng.uniform(-0.4, 0.2)), "q^d_n": float(rng.uniform(-1.2, 0.3)),
+               "q^d_T": float(rng.uniform(-0.3, 0.3)), "q^d_x": float(rng.uniform(-0.3, 0.3)),
+               "q^d_v": float(rng.choice([0.0, rng.uniform(-0.9, 0.6)]))})
+    for k in ("mod_r_0",):
+        g.pop(k, None)
+    pl.pop("q_n", None), pl.pop("q_tau", None), pr.pop("n_0", None)
+    p["grid"].update(n_x=20, n_y=26, n_z=30, c_size=float(rng.uniform(0.6, 1.5)))
+    jet = orc.OracleJet(p)
+    geom = geometry_struct(jet.params, jet.nx, jet.ny, jet.nz)
+    f = eng.build_fields(geom, 8, want_ts=True, want_vxz=True)
+    eng.synchronize()
+    ff = f.ff_raw.cpu().numpy().reshape(jet.nx, jet.ny, jet.nz)
+    assert np.array_equal(np.isnan(ff), np.isnan(jet.fill_factor))
+    assert np.array_equal(np.nan_to_num(ff), np.nan_to_num(jet.fill_factor))
+    jetm = np.isfinite(jet.fill_factor)
+    assert jetm.sum() > 50, "degenerate draw"
+    nd = f.nd.cpu().numpy().reshape(ff.shape)
+    with np.errstate(all="ignore"):
+        ref = dict(nd=jet.nd0, xi=jet.ion_fraction, temp=jet.temperature, vy=jet.vy, ts=jet.ts0)
+    np.testing.assert_allclose(np.abs(nd[jetm]), ref["nd"][jetm], rtol=1e-11)
+    assert np.array_equal(np.signbit(nd[jetm]), jet.rr[jetm] < 0)
+    for name in ("xi", "temp", "vy", "ts"):
+        got = getattr(f, name).cpu().numpy().reshape(ff.shape)
+        ok = jetm & np.isfinite(ref[name])
+        assert np.array_equal(np.isfinite(got[jetm]), np.isfinite(ref[name][jetm])), name
+        np.testing.assert_allclose(got[ok], ref[name][ok], rtol=1e-9, atol=1e-6, err_msg=name)

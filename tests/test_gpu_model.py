@@ -88,6 +88,21 @@ def test_example_file_as_shipped(tmp_path):
     assert int(np.isfinite(jm.fill_factor).sum()) == int(z["n_jet_cells"])
 
 
+def test_flux_vs_time_light_curves(tmp_path):
+    """Device-reduced light curves == sums of the reference's flux maps at the golden epochs,
+    and a dense uniform sweep (16-epoch tiles + ragged tail) == the same epochs one by one."""
+    z, meta, _ = U.load_golden("cfg1_example")
+    jm = classes.JetModel(example_params(), log=logger.Log(str(tmp_path / "a.log"), verbose=False))
+    lc = jm.flux_vs_time(z["years"] * YEAR, z["freqs"])
+    np.testing.assert_allclose(lc, np.nansum(z["flux_ff"], axis=(2, 3)), rtol=1e-9)
+    times = np.linspace(0., 5., 41) * YEAR
+    sweep = jm.flux_vs_time(times, [5e9, 2e10])
+    for i in (0, 7, 16, 33, 40):
+        jm.time = times[i]
+        one = np.nansum(jm.flux_ff(np.array([5e9, 2e10])), axis=(1, 2))
+        np.testing.assert_allclose(sweep[i], one, rtol=1e-10)
+
+
 def test_jetmodel_setters_and_accessors(tmp_path):
     """Public setters of the reference (ts / ion_fraction / temperature) re-upload a field
     and invalidate cached scans; accessors return reference-shaped host grids."""
