@@ -81,8 +81,10 @@ __device__ __forceinline__ double rcp_fast(double d) {
 // Shifted-lattice evaluation, used only for y < 0.03 (see voigt_rew): nodes (n + delta) h
 // with delta = 1/2 whenever x is within h/4 of a node of the plain lattice, so that the
 // trapezoid sum and the pole term never cancel, however small y is.
-__device__ __forceinline__ double voigt_core_shifted(double ax, double y, double q,
-                                                     double lnq) {
+// noinline: its six node tables would otherwise compete for scalar registers with the
+// common path inside the channel loop (the compiler spilled ~160 SGPRs per iteration).
+__device__ __attribute__((noinline)) double voigt_core_shifted(double ax, double y, double q,
+                                                              double lnq) {
   const double r2 = __builtin_fma(ax, ax, y * y);
   const double u = ax * (1.0 / kH);
   const double fr = u - __builtin_floor(u);
@@ -125,9 +127,28 @@ __device__ __forceinline__ double voigt_core_shifted(double ax, double y, double
   return s;
 }
 
+// Pole term of the plain lattice, P = Re[ 2 exp(-z^2) q / (q - exp(-i theta)) ] with
+// theta = 2 pi x / h = 2 pi fr (mod 2 pi), written without cancellation near a node
+// (1 - cos theta = 2 sin^2(theta/2), 1 - q from expm1).  Out of line: only the waves near the
+// line core need it.
+__device__ __attribute__((noinline)) double pole_term_plain(double ax, double y, double q,
+                                                           double omq) {
+  const double e = y * y - ax * ax;
+  const double u = ax * (1.0 / kH);
+  const double fr = u - __builtin_floor(u);
+  double sh, ch, s2, c2;
+  sincos_2pi(0.5 * fr, sh, ch);                       // half angle: theta/2 = pi fr
+  sincos_2pi(0.31830988618379067154 * ax * y, s2, c2);
+  const double omc = 2.0 * sh * sh;                   // 1 - cos(theta)
+  const double st = 2.0 * sh * ch;                    // sin(theta)
+  const double den = __builtin_fma(omq, omq, 2.0 * q * omc);   // |q - e^{-i theta}|^2
+  const double num = __builtin_fma(c2, omc - omq, -s2 * st);   // Re[e^{-2ixy} conj(q - e^{-i theta})]
+  return 2.0 * exp_any(e) * q * num * rcp_fast(den);
+}
+
 // Re w(x + i y) for one lane (x = ax >= 0 per lane, y > 0 THE SAME IN EVERY LANE: a wave
 // works on one cell).  Per-cell constants: q = exp(-2 pi y / h) (or -1 when y >= pi/h: no
-// pole term), omq = 1 - q (from expm1), cq = pole-term skip threshold.
+// pole term), omq = 1 - q (from expm1), cq = x^2 below which the pole term matters.
 __device__ __forceinline__ double voigt_rew(double ax, double y, double q, double omq,
                                             double cq) {
   const double r2 = __builtin_fma(ax, ax, y * y);
@@ -192,26 +213,9 @@ __device__ __forceinline__ double voigt_rew(double ax, double y, double q, doubl
   }
   s *= y * (kH / 3.14159265358979323846);
   // Pole term P = Re[ 2 exp(-z^2) q / (q - exp(-i theta)) ], theta = 2 pi x / h.
-  // |P| <= 6 exp(y^2-x^2) q / D with D = |q - e^{-i theta}|^2 >= max((1-q)^2, 16 q m^2),
-  // m = distance of x/h to the nearest integer; Re w >= y / (4 (|z|^2 + 1)).  The term is
-  // skipped when that bound is below 1e-13 Re w (cq = per-cell part of the comparison).
-  if (q >= 0.0) {
-    const double e = y * y - ax * ax;
-    const double u = ax * (1.0 / kH);
-    const double fr = u - __builtin_floor(u);
-    const float m = (float)fmin(fr, 1.0 - fr);
-    const float dmin = fmaxf((float)(omq * omq), 16.0f * (float)q * m * m);
-    if (e + cq + (double)(__logf((float)r2 + 1.0f) - __logf(dmin)) > 0.0) {
-      double sh, ch, s2, c2;
-      sincos_2pi(0.5 * fr, sh, ch);                       // half angle: theta/2 = pi fr
-      sincos_2pi(0.31830988618379067154 * ax * y, s2, c2);
-      const double omc = 2.0 * sh * sh;                   // 1 - cos(theta), no cancellation
-      const double st = 2.0 * sh * ch;                    // sin(theta)
-      const double den = __builtin_fma(omq, omq, 2.0 * q * omc);   // |q - e^{-i theta}|^2
-      const double num = __builtin_fma(c2, omc - omq, -s2 * st);   // Re[e^{-2ixy} conj(q - e^{-i theta})]
-      s += 2.0 * exp_any(e) * q * num * rcp_fast(den);
-    }
-  }
+  // |P| <= 6 exp(y^2 - x^2) q / (1 - q)^2 and Re w >= y / (4 (|z|^2 + 1)) with |z|^2 < 66 in
+  // this branch: P is below 1e-13 Re w, and skipped, once x^2 exceeds the per-cell bound cq.
+  if (q >= 0.0 && ax * ax < cq) s += pole_term_plain(ax, y, q, omq);
   return s;
 }
 
@@ -270,8 +274,10 @@ __device__ __forceinline__ CellLine cell_line(const RrlFields<T>& f, int64_t o,
   const double lnq = -2.0 * kPiOverH * c.y;
   c.q = (c.y < kPiOverH) ? exp(lnq) : -1.0;
   c.omq = -expm1(lnq);
-  // pole term needed iff e + ln(6 q / D) > ln(1e-13 * y / (4 (|z|^2+1)))
-  c.cq = lnq + 1.7917594692280550 - log(0.25 * c.y) + 29.9336062089226;
+  // pole term needed iff y^2 - x^2 + ln(6 q / (1-q)^2) > ln(1e-13 y / (4 * 67)), i.e. iff
+  // x^2 < cq
+  c.cq = c.y * c.y + lnq + 1.7917594692280550 - 2.0 * log(c.omq) - log(0.25 * c.y) +
+         29.9336062089226 + 4.2046926193909657;
   if (!(c.C == c.C) || c.C == 0.0 || !(c.y > 0.0)) c.C = 0.0;     // nansum drops NaN terms
   return c;
 }
