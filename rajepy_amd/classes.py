@@ -376,6 +376,62 @@ class JetModel:
     def _grid(self, tensor):
         return tensor.cpu().numpy().astype(np.float64).reshape(self.nx, self.ny, self.nz)
 
+    # ---- geometry accessors (host NumPy; plotting / inspection only, never on the RT path) --
+    @property
+    def indices(self):
+        """Cell index grids (classes.py:465-474)."""
+        return tuple(np.meshgrid(np.arange(self.nx), np.arange(self.ny), np.arange(self.nz),
+                                 indexing=self._arr_indexing))
+
+    ix = property(lambda self: self.indices[0])
+    iy = property(lambda self: self.indices[1])
+    iz = property(lambda self: self.indices[2])
+
+    @property
+    def grid(self):
+        """Bottom-left-front cell corners [au] (classes.py:488-501)."""
+        ix, iy, iz = self.indices
+        return (self.csize * (ix - self.nx // 2), self.csize * (iy - self.ny // 2),
+                self.csize * (iz - self.nz // 2))
+
+    xx = property(lambda self: self.grid[0])
+    yy = property(lambda self: self.grid[1])
+    zz = property(lambda self: self.grid[2])
+    xs = property(lambda self: self.csize * (np.arange(self.nx) - self.nx // 2))
+    ys = property(lambda self: self.csize * (np.arange(self.ny) - self.ny // 2))
+    zs = property(lambda self: self.csize * (np.arange(self.nz) - self.nz // 2))
+
+    @property
+    def grid_rwp(self):
+        """Jet coordinates (r, w, phi) of the cell centroids (classes.py:515-526)."""
+        xx, yy, zz = self.grid
+        h = self.csize / 2.
+        g = self.params["geometry"]
+        return mgeom.xyz_to_rwp(xx + h, yy + h, zz + h, g["inc"], g["pa"])
+
+    rr = property(lambda self: self.grid_rwp[0])
+    ww = property(lambda self: self.grid_rwp[1])
+    pp = property(lambda self: self.grid_rwp[2])
+
+    @property
+    def rreff(self):
+        """Effective launching radius in the disc [au] (classes.py:543-557)."""
+        g, t = self.params["geometry"], self.params["target"]
+        r, w, _ = self.grid_rwp
+        return mgeom.r_eff(w, t["R_1"], t["R_2"], g['w_0'], np.abs(r), g['mod_r_0'], g['r_0'],
+                           g["epsilon"])
+
+    @property
+    def mass_density(self):
+        """[g cm^-3] (classes.py:901-908)."""
+        return self.params['properties']['mu'] * mphys.atomic_mass("H") * 1e3 * \
+            self.number_density
+
+    @property
+    def pressure(self):
+        """[dyn cm^-2] (classes.py:1002-1007)."""
+        return self.number_density * self.temperature * con.k * 1e7
+
     # grids as host arrays (inspection / plotting / pickling; not on the RT path)
     @property
     def fill_factor(self):

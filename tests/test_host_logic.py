@@ -94,6 +94,23 @@ def test_jetmodel_derived_params_and_str(tmp_path, rec):
     assert jm.gff_mode == _lib.RJP_GFF_SCALAR
 
 
+@pytest.mark.parametrize("tag", ["cfg1_example", "tilted"])
+def test_geometry_accessors_match_reference(tmp_path, tag):
+    """rr / ww / pp / rreff grids (host side) against the reference's at the jet cells."""
+    z, meta, p = U.load_golden(tag)
+    p["geometry"].pop("mod_r_0", None)
+    p["power_laws"].pop("q_n", None), p["power_laws"].pop("q_tau", None)
+    p["properties"].pop("n_0", None)
+    jm = make_model(tmp_path, p)
+    idx = z["f_idx"]
+    with np.errstate(all="ignore"):
+        for name, key in (("rr", "rr"), ("ww", "ww"), ("pp", "pp"), ("rreff", "rreff")):
+            got = getattr(jm, name).ravel()[idx]
+            np.testing.assert_allclose(got, z["f_" + key], rtol=1e-12, atol=1e-12, err_msg=name)
+    assert jm.xx.shape == (jm.nx, jm.ny, jm.nz) and jm.xs[0] == -jm.csize * (jm.nx // 2)
+    assert np.array_equal(jm.zz[0, 0], jm.zs)
+
+
 def test_jetmodel_errors(tmp_path):
     with pytest.raises(TypeError):
         classes.JetModel(42)
