@@ -6,7 +6,7 @@ What is different underneath: the 3-D grids live in HBM as five/six packed field
 (`engine.DeviceFields`), are BUILT on the GPU (`rjp_build_fields`) and every line-of-sight
 reduction runs in librjprt's HIP kernels through the C-ABI of include/rjprt.h.  One grid pass
 serves every continuum channel of an epoch (the reference re-streams the grid per channel),
-and up to eight epochs share a pass.  There is no CPU fallback for any of it.
+and up to sixteen epochs share a pass.  There is no CPU fallback for any of it.
 """
 import os
 import pickle
@@ -496,7 +496,7 @@ class JetModel:
 
     # ------------------------------------------------------------------ K1 cache ----
     def prefetch_epochs(self, times_s):
-        """Scan the grid for several model times at once (eight epochs share one pass over
+        """Scan the grid for several model times at once (8-16 epochs share one pass over
         HBM); later RT calls at those times reuse the base maps."""
         todo = [t for t in dict.fromkeys(float(t) for t in times_s)
                 if t not in self._scan_cache]
@@ -997,7 +997,7 @@ class Pipeline:
         self._multi_rank = world > 1
 
         if not dryrun:
-            # one pass over HBM serves up to eight epochs
+            # one pass over HBM serves 8-16 epochs
             pending = [self.runs[i].year * con.year for i in mine
                        if self.runs[i].radiative_transfer and
                        not (self.runs[i].completed and resume and not clobber)]
