@@ -186,7 +186,6 @@ class JetModel:
         self._version = 0            # bumped whenever a field or the burst list changes
         self._scan_cache = {}        # time -> (sumA[P], em[P]) device tensors
         self._tavg = None
-        self._host_ts = None
         self._vxz = None
         self._rrl_cache = None
 
