@@ -276,8 +276,12 @@ def main():
         # lanes) or 4 (f32 lanes)
         tile = 16 if E_loc >= 16 else (8 if args.storage == "f64" else 4)
         npass = -(-E_loc // tile) if E_loc > 1 else 1
-        alg_bytes = npass * 5 * ncell_loc * int(dtype) + E_loc * P * 2 * 8
-        kname, extra = "ff_scan_kernel", {"grid_passes_per_launch": npass}
+        # fields K1 streams per cell: ne, temp, ts in the compact f64 layout (DESIGN.md
+        # "Data layout"), else nd, xi, temp, pf, ts
+        nfld = 3 if fields.ne is not None else 5
+        alg_bytes = npass * nfld * ncell_loc * int(dtype) + E_loc * P * 2 * 8
+        kname, extra = "ff_scan_kernel", {"grid_passes_per_launch": npass,
+                                          "fields_streamed_per_cell": nfld}
     achieved = alg_bytes / (k_ms * 1e-3) / 1e9
     traffic = None
     pmc = os.path.join(ROOT, "profiles", "r01_%s_%s_pmc.json" % (args.config, args.storage))
@@ -304,7 +308,10 @@ def main():
                                    "K3 RRL scan + K1/K2 continuum + line flux cube" if rrl else
                                    "K1 scan + K2 flux-vs-time" if n_ep_cfg else
                                    "K1 scan + K2 tau/flux cubes")),
-                   "storage": args.storage, "sharding": ("xslab" if xslab else "channels" if chsh else "epochs")
+                   "storage": args.storage,
+                   "layout": "compact (3 fields/cell)" if fields.ne is not None else
+                             "wide (5 fields/cell)",
+                   "sharding": ("xslab" if xslab else "channels" if chsh else "epochs")
                    if world > 1 else "none",
                    "gather": ("all_reduce of per-channel fluxes [E,F]" if xslab else
                               "all_gather of per-channel fluxes along F" if chsh else

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define RJP_VERSION 100          /* 0.1.0 */
+#define RJP_VERSION 101          /* 0.1.1 */
 #define RJP_MAX_BURSTS 8         /* per jet (red / blue) */
 #define RJP_MAX_EPOCH_TILE 16    /* most epochs evaluated per grid pass (uniformly spaced, f64 lanes; else 8) */
 
@@ -74,6 +74,18 @@ typedef struct rjp_fields {
    * range hold only cells that cannot contribute (NaN density / T <= 0) and are skipped. */
   const int32_t* d_ylo;
   const int32_t* d_yhi;
+  /* Optional compact scan layout (RJP_F64 storage only), written by rjp_compact_fields():
+   * one 64-bit word per cell that carries everything K1 needs from nd, xi and pf, so the
+   * free-free scan streams 3 fields (ne, temp, ts = 24 B/cell) instead of 5 (40 B/cell):
+   *   bits 63     red-jet flag (the sign bit of nd)
+   *   bits 62..2  |nd * xi|, the steady-state electron density [cm^-3], as an IEEE double
+   *               rounded to a multiple of 4 ulp (rel. error <= 4.4e-16; inf/NaN preserved)
+   *   bits 1..0   path-length factor code: 0 = NaN, 1 = 0.5, 2 = 1.0, 3 = 0.0 -- the only
+   *               values fill_factor / areas can produce (classes.py:657-669, 763-764)
+   * When non-NULL, rjp_ff_scan and rjp_y_bounds read d_ne and ignore d_nd / d_xi / d_pf
+   * (which may then be NULL for those two calls); the RRL and collapse=False entry points
+   * always read the wide fields. */
+  const void* d_ne;
 } rjp_fields;
 
 /* Ejection bursts (classes.py:399-463): mdot(t)/mdot_ss = 1 + sum_b amp_rel_b *
@@ -108,6 +120,14 @@ const char* rjp_last_error(const rjp_ctx* ctx);   /* ctx may be NULL: last creat
  * stores d_src[i]/d_den[i] -> the `pf` field from fill_factor and areas. */
 int rjp_pack_field(rjp_ctx* ctx, const double* d_src, const double* d_den,
                    const uint8_t* d_red, void* d_dst, int64_t n, int dtype, void* stream);
+
+/* Builds the compact electron-density words (see rjp_fields.d_ne) from the wide f64 fields
+ * nd, xi, pf: d_ne[i] for all n_x*n_y*n_z cells, one pass.  *d_n_general (a device int64,
+ * zeroed by the call) receives the number of cells whose path factor is none of NaN, 0, 0.5,
+ * 1; when it is non-zero the words are unusable and the caller keeps scanning the wide
+ * layout.  RJP_ERR_ARG for RJP_F32 storage. */
+int rjp_compact_fields(rjp_ctx* ctx, const rjp_fields* fields, void* d_ne,
+                       int64_t* d_n_general, void* stream);
 
 /* Per-sightline occupied y-range of a packed field set: d_ylo[p] = first row, d_yhi[p] = one
  * past the last row whose cell can contribute to any product of the path, i.e. T > 0 (counts

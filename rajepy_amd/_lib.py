@@ -27,7 +27,7 @@ class Fields(C.Structure):
                 ("d_pf", C.c_void_p), ("d_ts", C.c_void_p), ("d_vy", C.c_void_p),
                 ("nx", C.c_int32), ("ny", C.c_int32), ("nz", C.c_int32),
                 ("dtype", C.c_int32), ("csize_au", C.c_double),
-                ("d_ylo", C.c_void_p), ("d_yhi", C.c_void_p)]
+                ("d_ylo", C.c_void_p), ("d_yhi", C.c_void_p), ("d_ne", C.c_void_p)]
 
 
 class Bursts(C.Structure):
@@ -69,6 +69,7 @@ SIGNATURES = {
     "rjp_ctx_destroy": (C.c_int, [_P]),
     "rjp_last_error": (C.c_char_p, [_P]),
     "rjp_pack_field": (C.c_int, [_P, _P, _P, _P, _P, C.c_int64, C.c_int, _P]),
+    "rjp_compact_fields": (C.c_int, [_P, C.POINTER(Fields), _P, _P, _P]),
     "rjp_y_bounds": (C.c_int, [_P, C.POINTER(Fields), _P, _P, _P]),
     "rjp_ff_scan_workspace": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
     "rjp_ff_scan": (C.c_int, [_P, C.POINTER(Fields), C.POINTER(Bursts), _DP, C.c_int32,
@@ -114,7 +115,7 @@ def load():
         fn = getattr(lib, name)          # AttributeError if a declared symbol is missing
         fn.restype = res
         fn.argtypes = args
-    if lib.rjp_version() < 100:
+    if lib.rjp_version() < 101:
         raise RjprtError("librjprt.so is older than this binding")
     _lib = lib
     return lib

@@ -8,7 +8,9 @@
 // chi(t) for a tile of up to 16 epochs in registers and keeps FP64 accumulators.  The y-range is split
 // over gridDim.y so small maps still fill 256 CUs; partial sums go to a workspace and a tiny
 // second kernel reduces them in a fixed order (bitwise reproducible, no atomics).
-// HBM-bound: algorithmic bytes = 5 fields * sizeof(T) per cell per epoch tile.
+// HBM-bound: algorithmic bytes = 5 fields * sizeof(T) per cell per epoch tile in the wide
+// layout, 3 fields * 8 B in the compact layout (rjp_fields.d_ne: electron density, path-factor
+// code and jet flag in one word).
 #include <algorithm>
 #include <cmath>
 
@@ -25,7 +27,17 @@ struct FieldPtrs {
   const T* ts;
   const int32_t* ylo;      // optional occupied y-range per sightline (nullptr = all rows)
   const int32_t* yhi;
+  const T* ne;             // compact layout word (f64 only), replaces nd / xi / pf in K1
 };
+
+// compact word -> (steady-state electron density, path factor, red-jet flag)
+__device__ __forceinline__ void decode_ne(double w, double& n0, double& pf, bool& red) {
+  const long long bits = __double_as_longlong(w);
+  const int code = (int)(bits & 3);
+  red = bits < 0;
+  n0 = __longlong_as_double(bits & 0x7FFFFFFFFFFFFFFCll);
+  pf = code == 2 ? 1.0 : (code == 1 ? 0.5 : (code == 3 ? 0.0 : __builtin_nan("")));
+}
 
 template <int ET>
 struct EpochTile {
@@ -51,20 +63,46 @@ __host__ __device__ constexpr int nacc(int et) { return 2 * et + 2; }
 // then the burst factors of all U*VEC*ET (cell, epoch) pairs as ONE batch so their exp()
 // polynomial chains interleave (FP64 FMA latency is what limits a single chain), then the
 // accumulation.
-template <typename T, int VEC, int ET, int MODE, bool BURSTS, bool UNIF, int U>
+template <typename T, int VEC, int ET, int MODE, bool BURSTS, bool UNIF, bool CMP, int U>
 __device__ __forceinline__ void scan_rows(const FieldPtrs<T>& f, int64_t off, int64_t stride,
                                           const BurstsDev& b, const EpochTile<ET>& ep,
                                           double (&accA)[ET][VEC], double (&accE)[ET][VEC],
                                           double (&accT)[VEC], double (&cnt)[VEC]) {
-  double nd[U][VEC], xi[U][VEC], tp[U][VEC], pf[U][VEC], ts[U][VEC];
+  // n0 = |nd| xi (steady-state electron density), pf, jet flag: from three wide fields or
+  // from the one compact word
+  double n0[U][VEC], tp[U][VEC], pf[U][VEC], ts[U][VEC];
+  bool rj[U][VEC];
+  if constexpr (CMP) {
+    double w[U][VEC];
 #pragma unroll
-  for (int u = 0; u < U; ++u) {
-    const int64_t o = off + u * stride;
-    load_vec(f.nd + o, nd[u]);
-    load_vec(f.xi + o, xi[u]);
-    load_vec(f.temp + o, tp[u]);
-    load_vec(f.pf + o, pf[u]);
-    if (BURSTS) load_vec(f.ts + o, ts[u]);
+    for (int u = 0; u < U; ++u) {
+      const int64_t o = off + u * stride;
+      load_vec(f.ne + o, w[u]);
+      load_vec(f.temp + o, tp[u]);
+      if (BURSTS) load_vec(f.ts + o, ts[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) decode_ne(w[u][v], n0[u][v], pf[u][v], rj[u][v]);
+  } else {
+    double nd[U][VEC], xi[U][VEC];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t o = off + u * stride;
+      load_vec(f.nd + o, nd[u]);
+      load_vec(f.xi + o, xi[u]);
+      load_vec(f.temp + o, tp[u]);
+      load_vec(f.pf + o, pf[u]);
+      if (BURSTS) load_vec(f.ts + o, ts[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) {
+        n0[u][v] = fabs(nd[u][v]) * xi[u][v];
+        rj[u][v] = signbit_d(nd[u][v]);
+      }
   }
 
   constexpr int NB = ET * U * VEC;
@@ -78,7 +116,7 @@ __device__ __forceinline__ void scan_rows(const FieldPtrs<T>& f, int64_t off, in
 #pragma unroll
       for (int v = 0; v < VEC; ++v) {
         tlm[u * VEC + v] = ep.t[ET / 2] - (ts[u][v] == ts[u][v] ? ts[u][v] : 0.0);
-        red[u * VEC + v] = signbit_d(nd[u][v]);
+        red[u * VEC + v] = rj[u][v];
       }
     chi_batch_uniform<ET, U * VEC>(b, ep.un, red, tlm, chi);
   } else if (BURSTS) {
@@ -92,7 +130,7 @@ __device__ __forceinline__ void scan_rows(const FieldPtrs<T>& f, int64_t off, in
         for (int v = 0; v < VEC; ++v) {
           const int k = (e * U + u) * VEC + v;
           tl[k] = ep.t[e] - (ts[u][v] == ts[u][v] ? ts[u][v] : 0.0);
-          red[k] = signbit_d(nd[u][v]);
+          red[k] = rj[u][v];
         }
     chi_batch<NB, sizeof(T) == 4>(b, red, tl, chi);
   }
@@ -105,8 +143,7 @@ __device__ __forceinline__ void scan_rows(const FieldPtrs<T>& f, int64_t off, in
       // temperature power: T^-1.5 (scalar Gaunt) or T^-1.35 = T^-1.5 * T^0.15 (power law)
       double tpow = pow_m1p5(Tk);
       if (MODE == RJP_GFF_POWERLAW) tpow *= pow(Tk, 0.15);
-      const double n0 = fabs(nd[u][v]) * xi[u][v];   // steady-state electron density
-      const double g = n0 * n0 * pf[u][v];           // (n x)^2 * ff/areas at chi = 1
+      const double g = n0[u][v] * n0[u][v] * pf[u][v];   // (n x)^2 * ff/areas at chi = 1
       const double a = g * tpow;
       if (Tk > 0.0) { accT[v] += Tk; cnt[v] += 1.0; }
       if (BURSTS) {
@@ -131,7 +168,7 @@ __device__ __forceinline__ void scan_rows(const FieldPtrs<T>& f, int64_t off, in
   }
 }
 
-template <typename T, int VEC, int ET, int MODE, bool BURSTS, bool UNIF>
+template <typename T, int VEC, int ET, int MODE, bool BURSTS, bool UNIF, bool CMP>
 __global__ __launch_bounds__(kBlock) void ff_scan_kernel(
     FieldPtrs<T> f, int ny, int nz, int64_t nchunks, int64_t npix, int ylen, BurstsDev b,
     EpochTile<ET> ep, double* __restrict__ ws) {
@@ -173,11 +210,11 @@ __global__ __launch_bounds__(kBlock) void ff_scan_kernel(
 
   int y = y0;
   for (; y + kUnroll <= y1; y += kUnroll) {
-    scan_rows<T, VEC, ET, MODE, BURSTS, UNIF, kUnroll>(f, off, stride, b, ep, accA, accE, accT, cnt);
+    scan_rows<T, VEC, ET, MODE, BURSTS, UNIF, CMP, kUnroll>(f, off, stride, b, ep, accA, accE, accT, cnt);
     off += kUnroll * stride;
   }
   for (; y < y1; ++y) {
-    scan_rows<T, VEC, ET, MODE, BURSTS, UNIF, 1>(f, off, stride, b, ep, accA, accE, accT, cnt);
+    scan_rows<T, VEC, ET, MODE, BURSTS, UNIF, CMP, 1>(f, off, stride, b, ep, accA, accE, accT, cnt);
     off += stride;
   }
 
@@ -284,7 +321,7 @@ __global__ __launch_bounds__(kBlock) void sum_partials_kernel(const double* __re
 }
 
 // Occupied y-range per sightline: one lane per sightline, lanes adjacent along z.
-template <typename T>
+template <typename T, bool CMP>
 __global__ __launch_bounds__(kBlock) void y_bounds_kernel(FieldPtrs<T> f, int ny, int nz,
                                                           int64_t npix, int32_t* __restrict__ ylo,
                                                           int32_t* __restrict__ yhi) {
@@ -295,9 +332,18 @@ __global__ __launch_bounds__(kBlock) void y_bounds_kernel(FieldPtrs<T> f, int ny
   int64_t off = x * ny * (int64_t)nz + z;
   int lo = ny, hi = 0;
   for (int y = 0; y < ny; ++y, off += nz) {
-    const double nd = (double)f.nd[off], xi = (double)f.xi[off], pf = (double)f.pf[off],
-                 tk = (double)f.temp[off];
-    const bool matters = (tk > 0.0) || (nd == nd && xi == xi && pf == pf);
+    const double tk = (double)f.temp[off];
+    bool dense;                                   // n, x and ff/areas all non-NaN
+    if constexpr (CMP) {
+      double n0, pf;
+      bool red;
+      decode_ne((double)f.ne[off], n0, pf, red);
+      dense = n0 == n0 && pf == pf;
+    } else {
+      const double nd = (double)f.nd[off], xi = (double)f.xi[off], pf = (double)f.pf[off];
+      dense = nd == nd && xi == xi && pf == pf;
+    }
+    const bool matters = (tk > 0.0) || dense;
     if (matters) { lo = min(lo, y); hi = y + 1; }
   }
   ylo[p] = lo;
@@ -310,12 +356,15 @@ hipError_t y_bounds_launch(const rjp_fields* fl, int32_t* ylo, int32_t* yhi, hip
   if (fl->dtype == RJP_F64) {
     FieldPtrs<double> f{(const double*)fl->d_nd, (const double*)fl->d_xi,
                         (const double*)fl->d_temp, (const double*)fl->d_pf, nullptr, nullptr,
-                        nullptr};
-    hipLaunchKernelGGL(y_bounds_kernel<double>, grid, blk, 0, st, f, fl->ny, fl->nz, npix, ylo, yhi);
+                        nullptr, (const double*)fl->d_ne};
+    if (fl->d_ne)
+      hipLaunchKernelGGL((y_bounds_kernel<double, true>), grid, blk, 0, st, f, fl->ny, fl->nz, npix, ylo, yhi);
+    else
+      hipLaunchKernelGGL((y_bounds_kernel<double, false>), grid, blk, 0, st, f, fl->ny, fl->nz, npix, ylo, yhi);
   } else {
     FieldPtrs<float> f{(const float*)fl->d_nd, (const float*)fl->d_xi, (const float*)fl->d_temp,
-                       (const float*)fl->d_pf, nullptr, nullptr, nullptr};
-    hipLaunchKernelGGL(y_bounds_kernel<float>, grid, blk, 0, st, f, fl->ny, fl->nz, npix, ylo, yhi);
+                       (const float*)fl->d_pf, nullptr, nullptr, nullptr, nullptr};
+    hipLaunchKernelGGL((y_bounds_kernel<float, false>), grid, blk, 0, st, f, fl->ny, fl->nz, npix, ylo, yhi);
   }
   return hipGetLastError();
 }
@@ -349,7 +398,7 @@ hipError_t ff_cells_launch(const rjp_fields* fl, const rjp_bursts* hb, double ti
   auto go = [&](auto tag) {
     using T = decltype(tag);
     FieldPtrs<T> f{(const T*)fl->d_nd, (const T*)fl->d_xi, (const T*)fl->d_temp,
-                   (const T*)fl->d_pf, (const T*)fl->d_ts, nullptr, nullptr};
+                   (const T*)fl->d_pf, (const T*)fl->d_ts, nullptr, nullptr, nullptr};
     if (mode == RJP_GFF_SCALAR) {
       if (bursts) hipLaunchKernelGGL((ff_cells_kernel<T, 0, true>), grid, blk, 0, st, f, n, b, time_s, d_ctau, nchan, out);
       else hipLaunchKernelGGL((ff_cells_kernel<T, 0, false>), grid, blk, 0, st, f, n, b, time_s, d_ctau, nchan, out);
@@ -383,7 +432,7 @@ int ff_scan_vec(const rjp_fields* fl) {
   const int full = fl->dtype == RJP_F64 ? 2 : 4;
   const size_t esz = (size_t)fl->dtype;
   bool ok = (fl->nz % full) == 0;
-  const void* ptrs[5] = {fl->d_nd, fl->d_xi, fl->d_temp, fl->d_pf, fl->d_ts};
+  const void* ptrs[6] = {fl->d_nd, fl->d_xi, fl->d_temp, fl->d_pf, fl->d_ts, fl->d_ne};
   for (const void* p : ptrs)
     if (p && ((uintptr_t)p % 16) != 0) ok = false;
   (void)esz;
@@ -436,11 +485,12 @@ static void uniform_tile(const double* t, int et, const BurstsDev& b, UnifDev& u
   un.dt = dt;
 }
 
-template <typename T, int VEC, int ET, int MODE, bool BURSTS>
+template <typename T, int VEC, int ET, int MODE, bool BURSTS, bool CMP>
 static hipError_t launch_tile(const rjp_fields* fl, const BurstsDev& b, const double* t,
                               int nsplit, int ylen, double* ws, hipStream_t st) {
   FieldPtrs<T> f{(const T*)fl->d_nd, (const T*)fl->d_xi, (const T*)fl->d_temp,
-                 (const T*)fl->d_pf, (const T*)fl->d_ts, fl->d_ylo, fl->d_yhi};
+                 (const T*)fl->d_pf, (const T*)fl->d_ts, fl->d_ylo, fl->d_yhi,
+                 (const T*)fl->d_ne};
   EpochTile<ET> ep;
   for (int e = 0; e < ET; ++e) ep.t[e] = t[e];
   uniform_tile(t, ET, b, ep.un);
@@ -451,37 +501,37 @@ static hipError_t launch_tile(const rjp_fields* fl, const BurstsDev& b, const do
   // their 9-instruction float-accuracy exp instead
   if constexpr (BURSTS && ET >= 4 && (sizeof(T) == 8 || ET == 16)) {
     if (ep.un.on) {
-      hipLaunchKernelGGL((ff_scan_kernel<T, VEC, ET, MODE, true, true>), grid, dim3(kBlock), 0,
+      hipLaunchKernelGGL((ff_scan_kernel<T, VEC, ET, MODE, true, true, CMP>), grid, dim3(kBlock), 0,
                          st, f, fl->ny, fl->nz, nchunks, npix, ylen, b, ep, ws);
       return hipGetLastError();
     }
   }
   if constexpr (ET <= 8) {
-    hipLaunchKernelGGL((ff_scan_kernel<T, VEC, ET, MODE, BURSTS, false>), grid, dim3(kBlock), 0,
+    hipLaunchKernelGGL((ff_scan_kernel<T, VEC, ET, MODE, BURSTS, false, CMP>), grid, dim3(kBlock), 0,
                        st, f, fl->ny, fl->nz, nchunks, npix, ylen, b, ep, ws);
     return hipGetLastError();
   }
   return hipErrorInvalidValue;       // a 16-epoch tile that is not uniform: launcher bug
 }
 
-template <typename T, int VEC, int MODE>
+template <typename T, int VEC, int MODE, bool CMP>
 static hipError_t dispatch_et(const rjp_fields* fl, const BurstsDev& b, bool bursts,
                               const double* t, int et, int nsplit, int ylen, double* ws,
                               hipStream_t st) {
-  if (!bursts) return launch_tile<T, VEC, 1, MODE, false>(fl, b, t, nsplit, ylen, ws, st);
+  if (!bursts) return launch_tile<T, VEC, 1, MODE, false, CMP>(fl, b, t, nsplit, ylen, ws, st);
   switch (et) {
-    case 1: return launch_tile<T, VEC, 1, MODE, true>(fl, b, t, nsplit, ylen, ws, st);
-    case 2: return launch_tile<T, VEC, 2, MODE, true>(fl, b, t, nsplit, ylen, ws, st);
-    case 4: return launch_tile<T, VEC, 4, MODE, true>(fl, b, t, nsplit, ylen, ws, st);
+    case 1: return launch_tile<T, VEC, 1, MODE, true, CMP>(fl, b, t, nsplit, ylen, ws, st);
+    case 2: return launch_tile<T, VEC, 2, MODE, true, CMP>(fl, b, t, nsplit, ylen, ws, st);
+    case 4: return launch_tile<T, VEC, 4, MODE, true, CMP>(fl, b, t, nsplit, ylen, ws, st);
     case 8:
       // 4 sightlines x 8 epochs x 2 sums does not fit 256 VGPRs: the launcher caps the
       // epoch tile at 4 for 4-wide (f32) lanes
       if constexpr (VEC == 4) return hipErrorInvalidValue;
-      else return launch_tile<T, VEC, 8, MODE, true>(fl, b, t, nsplit, ylen, ws, st);
+      else return launch_tile<T, VEC, 8, MODE, true, CMP>(fl, b, t, nsplit, ylen, ws, st);
     case 16:
       // only the uniform-epoch recurrence keeps 16 epochs of state in registers
       if constexpr (VEC == 1)
-        return launch_tile<T, VEC, 16, MODE, true>(fl, b, t, nsplit, ylen, ws, st);
+        return launch_tile<T, VEC, 16, MODE, true, CMP>(fl, b, t, nsplit, ylen, ws, st);
       else return hipErrorInvalidValue;
   }
   return hipErrorInvalidValue;
@@ -491,9 +541,17 @@ template <typename T, int VEC>
 static hipError_t dispatch_mode(const rjp_fields* fl, const BurstsDev& b, bool bursts,
                                 int mode, const double* t, int et, int nsplit, int ylen,
                                 double* ws, hipStream_t st) {
+  // the compact word layout exists for f64 storage only
+  if constexpr (sizeof(T) == 8) {
+    if (fl->d_ne) {
+      if (mode == RJP_GFF_SCALAR)
+        return dispatch_et<T, VEC, RJP_GFF_SCALAR, true>(fl, b, bursts, t, et, nsplit, ylen, ws, st);
+      return dispatch_et<T, VEC, RJP_GFF_POWERLAW, true>(fl, b, bursts, t, et, nsplit, ylen, ws, st);
+    }
+  }
   if (mode == RJP_GFF_SCALAR)
-    return dispatch_et<T, VEC, RJP_GFF_SCALAR>(fl, b, bursts, t, et, nsplit, ylen, ws, st);
-  return dispatch_et<T, VEC, RJP_GFF_POWERLAW>(fl, b, bursts, t, et, nsplit, ylen, ws, st);
+    return dispatch_et<T, VEC, RJP_GFF_SCALAR, false>(fl, b, bursts, t, et, nsplit, ylen, ws, st);
+  return dispatch_et<T, VEC, RJP_GFF_POWERLAW, false>(fl, b, bursts, t, et, nsplit, ylen, ws, st);
 }
 
 // Enqueue the whole scan for n_epochs epochs.  Returns hipSuccess or the first error.

@@ -89,14 +89,20 @@ static int release_tables(rjp_ctx* ctx, hipStream_t st) {
   return RJP_OK;
 }
 
-static int check_fields(rjp_ctx* ctx, const rjp_fields* f, bool need_vy) {
+// `compact_ok`: the entry point can run from the compact word layout alone (d_ne + d_temp)
+static int check_fields(rjp_ctx* ctx, const rjp_fields* f, bool need_vy, bool compact_ok = false) {
   if (!f) return fail(ctx, RJP_ERR_ARG, "fields is NULL");
   if (f->dtype != RJP_F32 && f->dtype != RJP_F64)
     return fail(ctx, RJP_ERR_ARG, "fields.dtype must be RJP_F32 (4) or RJP_F64 (8)");
   if (f->nx <= 0 || f->ny <= 0 || f->nz <= 0)
     return fail(ctx, RJP_ERR_ARG, "grid dimensions must be positive");
-  if (!f->d_nd || !f->d_xi || !f->d_temp || !f->d_pf)
+  if (f->d_ne && f->dtype != RJP_F64)
+    return fail(ctx, RJP_ERR_ARG, "fields.d_ne (compact layout) requires RJP_F64 storage");
+  if (compact_ok && f->d_ne) {
+    if (!f->d_temp) return fail(ctx, RJP_ERR_ARG, "fields.d_temp must be a device pointer");
+  } else if (!f->d_nd || !f->d_xi || !f->d_temp || !f->d_pf) {
     return fail(ctx, RJP_ERR_ARG, "fields nd/xi/temp/pf must be device pointers");
+  }
   if (need_vy && !f->d_vy) return fail(ctx, RJP_ERR_ARG, "fields.d_vy required for RRL");
   if (!(f->csize_au > 0.0)) return fail(ctx, RJP_ERR_ARG, "fields.csize_au must be > 0");
   if ((f->d_ylo == nullptr) != (f->d_yhi == nullptr))
@@ -183,10 +189,21 @@ int rjp_pack_field(rjp_ctx* ctx, const double* d_src, const double* d_den,
   return RJP_OK;
 }
 
+int rjp_compact_fields(rjp_ctx* ctx, const rjp_fields* fields, void* d_ne, int64_t* d_n_general,
+                       void* stream) {
+  if (int r = bind(ctx)) return r;
+  if (int r = check_fields(ctx, fields, false)) return r;
+  if (fields->dtype != RJP_F64)
+    return fail(ctx, RJP_ERR_ARG, "rjp_compact_fields: the compact layout is for RJP_F64 storage");
+  if (!d_ne || !d_n_general) return fail(ctx, RJP_ERR_ARG, "rjp_compact_fields: NULL output");
+  RJP_HIP(ctx, rjp::compact_fields_launch(fields, d_ne, d_n_general, (hipStream_t)stream));
+  return RJP_OK;
+}
+
 int rjp_y_bounds(rjp_ctx* ctx, const rjp_fields* fields, int32_t* d_ylo, int32_t* d_yhi,
                  void* stream) {
   if (int r = bind(ctx)) return r;
-  if (int r = check_fields(ctx, fields, false)) return r;
+  if (int r = check_fields(ctx, fields, false, true)) return r;
   if (!d_ylo || !d_yhi) return fail(ctx, RJP_ERR_ARG, "rjp_y_bounds: NULL output");
   RJP_HIP(ctx, rjp::y_bounds_launch(fields, d_ylo, d_yhi, (hipStream_t)stream));
   return RJP_OK;
@@ -201,7 +218,7 @@ int rjp_ff_scan(rjp_ctx* ctx, const rjp_fields* fields, const rjp_bursts* bursts
                 const double* h_epochs_s, int32_t n_epochs, int32_t gff_mode, double* d_sumA,
                 double* d_em, double* d_tavg, void* d_work, size_t work_bytes, void* stream) {
   if (int r = bind(ctx)) return r;
-  if (int r = check_fields(ctx, fields, false)) return r;
+  if (int r = check_fields(ctx, fields, false, true)) return r;
   if (int r = check_bursts(ctx, bursts, fields)) return r;
   if (!h_epochs_s || n_epochs < 1) return fail(ctx, RJP_ERR_ARG, "need >= 1 epoch");
   if (gff_mode != RJP_GFF_SCALAR && gff_mode != RJP_GFF_POWERLAW)

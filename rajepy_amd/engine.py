@@ -5,6 +5,7 @@ arithmetic on the RT path happens inside librjprt's HIP kernels.  Nothing here f
 the CPU: without a GPU or without the built library, construction raises.
 """
 import ctypes as C
+import os
 
 import numpy as np
 
@@ -29,6 +30,7 @@ class DeviceFields:
         self.nd, self.xi, self.temp, self.pf, self.ts, self.vy = nd, xi, temp, pf, ts, vy
         self.ff_raw, self.areas_raw = ff_raw, areas_raw
         self.ylo = self.yhi = None          # optional occupied y-range per sightline (int32)
+        self.ne = None                      # optional compact scan words (rjp_fields.d_ne)
 
     @property
     def ncells(self):
@@ -40,8 +42,9 @@ class DeviceFields:
 
     def struct(self):
         f = _lib.Fields()
-        f.d_nd, f.d_xi, f.d_temp, f.d_pf = (t.data_ptr() for t in
+        f.d_nd, f.d_xi, f.d_temp, f.d_pf = (t.data_ptr() if t is not None else None for t in
                                             (self.nd, self.xi, self.temp, self.pf))
+        f.d_ne = self.ne.data_ptr() if self.ne is not None else None
         f.d_ts = self.ts.data_ptr() if self.ts is not None else None
         f.d_vy = self.vy.data_ptr() if self.vy is not None else None
         f.nx, f.ny, f.nz = self.shape
@@ -52,8 +55,17 @@ class DeviceFields:
         return f
 
     def nbytes(self, rrl=False):
-        n = 5 + (1 if rrl else 0)
+        """Bytes one grid pass streams: the RRL scan reads the six wide fields; the continuum
+        scan the three of the compact layout when it is attached, else the five wide ones."""
+        n = 6 if rrl else (3 if self.ne is not None else 5)
         return n * self.ncells * self.dtype
+
+    def drop_wide(self):
+        """Free nd / xi / pf once the compact words are attached (continuum-only sweeps of
+        grids that would not otherwise fit; the RRL and collapse=False calls need them)."""
+        if self.ne is None:
+            raise ValueError("no compact layout attached")
+        self.nd = self.xi = self.pf = None
 
 
 def make_bursts(red, blue):
@@ -153,7 +165,27 @@ class RTEngine:
         d_ts = pack(up(ts)) if ts is not None else None
         d_vy = pack(up(vy)) if vy is not None else None
         self.synchronize()
-        return DeviceFields(shape, dtype, csize_au, d_nd, d_xi, d_t, d_pf, d_ts, d_vy)
+        return self.compact(DeviceFields(shape, dtype, csize_au, d_nd, d_xi, d_t, d_pf, d_ts,
+                                         d_vy))
+
+    def compact(self, fields):
+        """Attach the compact scan layout (rjp_compact_fields) to f64 fields: K1 then streams
+        3 fields instead of 5.  Fields whose path factors are not all in {NaN, 0, 0.5, 1}
+        (nothing the reference's fill_factor / areas can produce) keep the wide layout.
+        RJP_NO_COMPACT=1 disables it (A/B runs)."""
+        torch = _torch()
+        fields.ne = None
+        if fields.dtype != RJP_F64 or os.environ.get("RJP_NO_COMPACT"):
+            return fields
+        ne = self._f64(fields.ncells)
+        bad = torch.empty(1, dtype=torch.int64, device=self.device)
+        fs = fields.struct()
+        _lib.check(self.lib.rjp_compact_fields(self.ctx, C.byref(fs), ne.data_ptr(),
+                                               bad.data_ptr(), self._stream()), self.ctx,
+                   "rjp_compact_fields")
+        if int(bad.item()) == 0:
+            fields.ne = ne
+        return fields
 
     def compute_y_bounds(self, fields):
         """Attach the per-sightline occupied y-range to `fields` (rjp_y_bounds): later scans
@@ -183,6 +215,8 @@ class RTEngine:
                                            self._stream()), self.ctx, "rjp_pack_field")
         self.synchronize()
         setattr(fields, name, dst)
+        if name == "xi" and fields.ne is not None:
+            self.compact(fields)                # the words hold nd * xi
         if fields.ylo is not None and name in ("xi", "temp"):
             self.compute_y_bounds(fields)       # the occupied range depends on these fields
 
@@ -207,7 +241,7 @@ class RTEngine:
         out = DeviceFields((geom.nx, geom.ny, geom.nz), dtype, geom.csize, nd, xi, temp, pf,
                            ts, vy, ffr, arr)
         out.vx_raw, out.vz_raw = vxr, vzr
-        return out
+        return self.compact(out)
 
     def synth_fields(self, shape, seed, temp_mode=0, dtype=RJP_F64, csize_au=0.5,
                      with_vy=False, cell0=0):
@@ -223,7 +257,7 @@ class RTEngine:
             nd.data_ptr(), xi.data_ptr(), temp.data_ptr(), pf.data_ptr(), ts.data_ptr(),
             vy.data_ptr() if with_vy else None, self._stream()), self.ctx,
             "rjp_synth_fields")
-        return DeviceFields(shape, dtype, csize_au, nd, xi, temp, pf, ts, vy)
+        return self.compact(DeviceFields(shape, dtype, csize_au, nd, xi, temp, pf, ts, vy))
 
     # -- K1 / K2 -----------------------------------------------------------------------------
     def ff_scan(self, fields, bursts, epochs_s, gff_mode, want_em=True, out=None):

@@ -21,6 +21,23 @@ def eng():
     e.close()
 
 
+STORES = ["f64", "f64-wide", "f32"]     # f64 = compact scan words attached (the default)
+
+
+def _store(store):
+    return 4 if store == "f32" else 8
+
+
+def _layout(fields, store):
+    """f64 fields come with the compact words attached; "f64-wide" detaches them so the
+    5-field path of K1 stays covered."""
+    if store == "f64":
+        assert fields.ne is not None
+    else:
+        fields.ne = None
+    return fields
+
+
 def _upload(eng, g, csize, dtype):
     return eng.upload_fields(g["nd"], g["xi"], g["temp"], g["ff"], g["areas"], g["ts"],
                              g["rr"] < 0, g["vy"], csize_au=csize, dtype=dtype)
@@ -43,12 +60,13 @@ def _run_ff(eng, fields, bursts, jet, years, freqs):
 
 
 @pytest.mark.parametrize("tag", ["cfg1_example", "tilted"])
-@pytest.mark.parametrize("dtype", [8, 4])
-def test_ff_against_reference_golden(eng, tag, dtype):
+@pytest.mark.parametrize("store", STORES)
+def test_ff_against_reference_golden(eng, tag, store):
     """K1+K2 on the reference's own fields vs the reference's own maps (tau, flux, EM) at
     every golden epoch and frequency."""
     z, meta, p, g, jet = U.golden_dense(tag)
-    fields = _upload(eng, g, jet.csize, dtype)
+    dtype = _store(store)
+    fields = _layout(_upload(eng, g, jet.csize, dtype), store)
     em, tau, flux, ftot, _ = _run_ff(eng, fields, U.bursts_from_oracle(jet), jet,
                                      z["years"], z["freqs"])
     tol = 1e-11 if dtype == 8 else RTOL
@@ -61,13 +79,15 @@ def test_ff_against_reference_golden(eng, tag, dtype):
 
 
 @pytest.mark.parametrize("temp_mode", [0, 1])
-@pytest.mark.parametrize("dtype", [8, 4])
+@pytest.mark.parametrize("store", STORES)
 @pytest.mark.parametrize("shape", [(6, 37, 10), (4, 64, 128), (3, 50, 7)])
-def test_ff_dense_synthetic_vs_oracle(eng, shape, dtype, temp_mode):
+def test_ff_dense_synthetic_vs_oracle(eng, shape, store, temp_mode):
     """Dense synthetic fields (device generator) vs the oracle on the host restatement of the
     same hash; exercises odd n_y tails, the scalar (VEC=1) path (n_z=7) and y-splitting."""
     seed = 20240501
-    fields = eng.synth_fields(shape, seed, temp_mode, dtype, csize_au=0.5, with_vy=True)
+    dtype = _store(store)
+    fields = _layout(eng.synth_fields(shape, seed, temp_mode, dtype, csize_au=0.5,
+                                      with_vy=True), store)
     g = U.synth_host(shape, seed, temp_mode)
     if dtype == 8:    # generator itself must be bit-identical to the host restatement
         eng.synchronize()
@@ -478,3 +498,91 @@ def test_field_builder_random_geometries_vs_oracle(eng, seed):
         ok = jetm & np.isfinite(ref[name])
         assert np.array_equal(np.isfinite(got[jetm]), np.isfinite(ref[name][jetm])), name
         np.testing.assert_allclose(got[ok], ref[name][ok], rtol=1e-9, atol=1e-6, err_msg=name)
+
+
+def _decode_words(words):
+    """Host reading of the compact words (include/rjprt.h, rjp_fields.d_ne)."""
+    bits = words.view(np.uint64)
+    code = (bits & np.uint64(3)).astype(int)
+    red = (bits >> np.uint64(63)).astype(bool)
+    n0 = (bits & np.uint64(0x7FFFFFFFFFFFFFFC)).view(np.float64)
+    pf = np.array([np.nan, 0.5, 1.0, 0.0])[code]
+    return n0, pf, red
+
+
+def test_compact_words_encode_every_special_value(eng):
+    """rjp_compact_fields: |nd * xi| to 4 ulp, inf / NaN / 0 / denormals preserved, the four
+    path-factor codes and the jet flag recovered exactly."""
+    nd = np.array([1e5, 3.3e7, np.nan, 2e6, np.inf, 0.0, 5e-324, 1.7976931348623157e308,
+                   4.4e6, 7.7e5, 1.0, 1.0 + 2 ** -52])
+    xi = np.array([0.3, np.nan, 0.2, 1.0, 0.5, 0.4, 1.0, 1.0, 0.123456789, 0.9, 1.0, 1.0])
+    ff = np.array([1.0, 1.0, 0.5, np.nan, 1.0, 0.5, 1.0, 0.5, 0.0, -0.0, 0.5, 1.0])
+    red = np.arange(nd.size) % 2 == 0
+    shape = (1, nd.size // 2, 2)
+    r = lambda a: np.asarray(a).reshape(shape)
+    f = eng.upload_fields(r(nd), r(xi), r(np.full(nd.size, 1e4)), r(ff), r(np.ones(nd.size)),
+                          r(np.zeros(nd.size)), r(red), csize_au=1.0, dtype=8)
+    assert f.ne is not None
+    n0, pf, rflag = _decode_words(f.ne.cpu().numpy())
+    want = np.abs(nd * xi)
+    assert np.array_equal(np.isnan(n0), np.isnan(want))
+    assert np.array_equal(np.isinf(n0), np.isinf(want))
+    ok = np.isfinite(want) & (want > 1e-300)
+    np.testing.assert_allclose(n0[ok], want[ok], rtol=4.5e-16)
+    assert np.all(n0[want == 0.0] == 0.0) and np.all(n0[(want > 0) & (want < 1e-300)] < 1e-322)
+    np.testing.assert_array_equal(pf, np.abs(ff))            # NaN == NaN here; -0.0 -> code 0.0
+    assert np.array_equal(rflag, red)
+
+
+@pytest.mark.parametrize("temp_mode", [0, 1])
+@pytest.mark.parametrize("n_ep", [1, 3, 8, 16])
+def test_compact_layout_agrees_with_the_wide_one(eng, temp_mode, n_ep):
+    """K1 from the 3-field compact layout vs the 5-field wide layout of the same model: the
+    base maps differ only by the 4-ulp rounding of the electron-density word."""
+    from rajepy_amd import engine as E
+    shape = (8, 96, 64)
+    f = eng.synth_fields(shape, 20240509, temp_mode, 8, csize_au=0.5)
+    assert f.ne is not None
+    p = copy.deepcopy(U.load_golden("cfg1_example")[2])
+    p["ejection"] = U.example_bursts_params()
+    g = U.synth_host((1, 2, 2), 1, 0)
+    jet = orc.OracleJet.from_fields(dict(p, grid=dict(p["grid"], n_x=1, n_y=2, n_z=2)), g["nd"],
+                                    g["xi"], g["temp"], g["ff"], g["areas"], g["ts"], g["rr"],
+                                    g["vy"])
+    bursts = U.bursts_from_oracle(jet)
+    ep = list(np.linspace(0.2, 3.4, n_ep) * orc.YEAR) if n_ep > 1 else [1.3 * orc.YEAR]
+    mode = E.RJP_GFF_SCALAR if temp_mode == 0 else E.RJP_GFF_POWERLAW
+    a1, e1, t1 = (x.clone() for x in eng.ff_scan(f, bursts, ep, mode))
+    words = f.ne
+    f.ne = None
+    a0, e0, t0 = eng.ff_scan(f, bursts, ep, mode)
+    eng.synchronize()
+    np.testing.assert_allclose(a1.cpu().numpy(), a0.cpu().numpy(), rtol=2e-14)
+    np.testing.assert_allclose(e1.cpu().numpy(), e0.cpu().numpy(), rtol=2e-14)
+    assert np.array_equal(t1.cpu().numpy(), t0.cpu().numpy())        # T_avg never sees the words
+    # continuum-only sweeps may free the wide fields; the RRL scan then refuses loudly
+    f.ne = words
+    f.drop_wide()
+    a2, _, _ = eng.ff_scan(f, bursts, ep, mode)
+    assert np.array_equal(a2.cpu().numpy(), a1.cpu().numpy())
+    from rajepy_amd._lib import RjprtError
+    with pytest.raises(RjprtError, match="nd/xi/temp/pf"):
+        eng.ff_cells(f, bursts, ep[0], mode, [1.0])
+
+
+def test_uncodable_path_factors_keep_the_wide_layout(eng):
+    """A path factor outside {NaN, 0, 0.5, 1} cannot be coded in two bits: the engine keeps
+    the wide layout and the maps still follow the oracle."""
+    shape = (3, 20, 8)
+    g = U.synth_host(shape, 5, 0)
+    g["ff"] = np.where(g["ff"] == 0.5, 0.37, 1.0)
+    p = copy.deepcopy(U.load_golden("cfg1_example")[2])
+    p["grid"].update(n_x=shape[0], n_y=shape[1], n_z=shape[2])
+    jet = orc.OracleJet.from_fields(p, g["nd"], g["xi"], g["temp"], g["ff"], g["areas"],
+                                    g["ts"], g["rr"], g["vy"])
+    f = _upload(eng, g, jet.csize, 8)
+    assert f.ne is None
+    em, tau, flux, _, _ = _run_ff(eng, f, U.bursts_from_oracle(jet), jet, [0.9], [5e9])
+    jet.time = 0.9 * orc.YEAR
+    np.testing.assert_allclose(em[0], jet.emission_measure(), rtol=1e-11)
+    np.testing.assert_allclose(tau[0, 0], jet.optical_depth_ff(5e9), rtol=1e-11)

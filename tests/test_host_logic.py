@@ -45,13 +45,13 @@ def test_abi_exports_every_declared_symbol():
     declared = set(re.findall(r"\b(rjp_[a-z0-9_]+)\s*\(", hdr))
     assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
     lib = _lib.load()                       # raises if the .so or any symbol is missing
-    assert lib.rjp_version() == 100
+    assert lib.rjp_version() == 101
     for name in declared:
         assert hasattr(lib, name)
 
 
 def test_abi_struct_layouts_match_header():
-    assert ctypes.sizeof(_lib.Fields) == 6 * 8 + 4 * 4 + 8 + 2 * 8
+    assert ctypes.sizeof(_lib.Fields) == 6 * 8 + 4 * 4 + 8 + 3 * 8
     assert ctypes.sizeof(_lib.Bursts) == 8 + 3 * 2 * 8 * 8
     assert ctypes.sizeof(_lib.Line) == 6 * 8
     assert ctypes.sizeof(_lib.Geometry) == 4 * 4 + 24 * 8 + 2 * 4
