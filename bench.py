@@ -276,9 +276,9 @@ def main():
         # lanes) or 4 (f32 lanes)
         tile = 16 if E_loc >= 16 else (8 if args.storage == "f64" else 4)
         npass = -(-E_loc // tile) if E_loc > 1 else 1
-        # fields K1 streams per cell: ne, temp, ts in the compact f64 layout (DESIGN.md
+        # fields K1 streams per cell: em0, temp, ts in the compact f64 layout (DESIGN.md
         # "Data layout"), else nd, xi, temp, pf, ts
-        nfld = 3 if fields.ne is not None else 5
+        nfld = 3 if fields.em0 is not None else 5
         alg_bytes = npass * nfld * ncell_loc * int(dtype) + E_loc * P * 2 * 8
         kname, extra = "ff_scan_kernel", {"grid_passes_per_launch": npass,
                                           "fields_streamed_per_cell": nfld}
@@ -309,7 +309,7 @@ def main():
                                    "K1 scan + K2 flux-vs-time" if n_ep_cfg else
                                    "K1 scan + K2 tau/flux cubes")),
                    "storage": args.storage,
-                   "layout": "compact (3 fields/cell)" if fields.ne is not None else
+                   "layout": "compact (3 fields/cell)" if fields.em0 is not None else
                              "wide (5 fields/cell)",
                    "sharding": ("xslab" if xslab else "channels" if chsh else "epochs")
                    if world > 1 else "none",

@@ -75,17 +75,14 @@ typedef struct rjp_fields {
   const int32_t* d_ylo;
   const int32_t* d_yhi;
   /* Optional compact scan layout (RJP_F64 storage only), written by rjp_compact_fields():
-   * one 64-bit word per cell that carries everything K1 needs from nd, xi and pf, so the
-   * free-free scan streams 3 fields (ne, temp, ts = 24 B/cell) instead of 5 (40 B/cell):
-   *   bits 63     red-jet flag (the sign bit of nd)
-   *   bits 62..2  |nd * xi|, the steady-state electron density [cm^-3], as an IEEE double
-   *               rounded to a multiple of 4 ulp (rel. error <= 4.4e-16; inf/NaN preserved)
-   *   bits 1..0   path-length factor code: 0 = NaN, 1 = 0.5, 2 = 1.0, 3 = 0.0 -- the only
-   *               values fill_factor / areas can produce (classes.py:657-669, 763-764)
-   * When non-NULL, rjp_ff_scan and rjp_y_bounds read d_ne and ignore d_nd / d_xi / d_pf
-   * (which may then be NULL for those two calls); the RRL and collapse=False entry points
-   * always read the wide fields. */
-  const void* d_ne;
+   * d_em0[cell] = (|nd| * xi)^2 * pf, the emission-measure density of the steady-state jet
+   * [cm^-6] -- the only combination of nd, xi and pf that emission_measure / optical_depth_ff
+   * use (classes.py:1116-1118, 1395-1397) -- with the red-jet flag of nd in its SIGN BIT.
+   * The free-free scan then streams 3 fields (em0, temp, ts = 24 B/cell) instead of 5
+   * (40 B/cell) and returns bit-identical maps.  When non-NULL, rjp_ff_scan and rjp_y_bounds
+   * read d_em0 and ignore d_nd / d_xi / d_pf (which may then be NULL for those two calls);
+   * the RRL and collapse=False entry points always read the wide fields. */
+  const void* d_em0;
 } rjp_fields;
 
 /* Ejection bursts (classes.py:399-463): mdot(t)/mdot_ss = 1 + sum_b amp_rel_b *
@@ -121,13 +118,14 @@ const char* rjp_last_error(const rjp_ctx* ctx);   /* ctx may be NULL: last creat
 int rjp_pack_field(rjp_ctx* ctx, const double* d_src, const double* d_den,
                    const uint8_t* d_red, void* d_dst, int64_t n, int dtype, void* stream);
 
-/* Builds the compact electron-density words (see rjp_fields.d_ne) from the wide f64 fields
- * nd, xi, pf: d_ne[i] for all n_x*n_y*n_z cells, one pass.  *d_n_general (a device int64,
- * zeroed by the call) receives the number of cells whose path factor is none of NaN, 0, 0.5,
- * 1; when it is non-zero the words are unusable and the caller keeps scanning the wide
- * layout.  RJP_ERR_ARG for RJP_F32 storage. */
-int rjp_compact_fields(rjp_ctx* ctx, const rjp_fields* fields, void* d_ne,
-                       int64_t* d_n_general, void* stream);
+/* Builds the compact scan field (see rjp_fields.d_em0) from the wide f64 fields nd, xi, pf in
+ * one pass over all n_x*n_y*n_z cells.  *d_n_negative (a device int64, zeroed by the call)
+ * receives the number of cells with a NEGATIVE path factor, whose sign would collide with the
+ * jet flag; when it is non-zero the field is unusable and the caller keeps scanning the wide
+ * layout (fill_factor / areas never produce one, classes.py:657-669, 763-764).
+ * RJP_ERR_ARG for RJP_F32 storage. */
+int rjp_compact_fields(rjp_ctx* ctx, const rjp_fields* fields, void* d_em0,
+                       int64_t* d_n_negative, void* stream);
 
 /* Per-sightline occupied y-range of a packed field set: d_ylo[p] = first row, d_yhi[p] = one
  * past the last row whose cell can contribute to any product of the path, i.e. T > 0 (counts

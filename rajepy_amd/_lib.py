@@ -27,7 +27,7 @@ class Fields(C.Structure):
                 ("d_pf", C.c_void_p), ("d_ts", C.c_void_p), ("d_vy", C.c_void_p),
                 ("nx", C.c_int32), ("ny", C.c_int32), ("nz", C.c_int32),
                 ("dtype", C.c_int32), ("csize_au", C.c_double),
-                ("d_ylo", C.c_void_p), ("d_yhi", C.c_void_p), ("d_ne", C.c_void_p)]
+                ("d_ylo", C.c_void_p), ("d_yhi", C.c_void_p), ("d_em0", C.c_void_p)]
 
 
 class Bursts(C.Structure):

@@ -9,8 +9,8 @@
 // over gridDim.y so small maps still fill 256 CUs; partial sums go to a workspace and a tiny
 // second kernel reduces them in a fixed order (bitwise reproducible, no atomics).
 // HBM-bound: algorithmic bytes = 5 fields * sizeof(T) per cell per epoch tile in the wide
-// layout, 3 fields * 8 B in the compact layout (rjp_fields.d_ne: electron density, path-factor
-// code and jet flag in one word).
+// layout, 3 fields * 8 B in the compact layout (rjp_fields.d_em0 = (n x)^2 pf with the jet flag
+// in its sign bit, temp, ts).
 #include <algorithm>
 #include <cmath>
 
@@ -27,17 +27,8 @@ struct FieldPtrs {
   const T* ts;
   const int32_t* ylo;      // optional occupied y-range per sightline (nullptr = all rows)
   const int32_t* yhi;
-  const T* ne;             // compact layout word (f64 only), replaces nd / xi / pf in K1
+  const T* em0;            // compact layout (f64 only): (|nd| xi)^2 pf, sign bit = red jet
 };
-
-// compact word -> (steady-state electron density, path factor, red-jet flag)
-__device__ __forceinline__ void decode_ne(double w, double& n0, double& pf, bool& red) {
-  const long long bits = __double_as_longlong(w);
-  const int code = (int)(bits & 3);
-  red = bits < 0;
-  n0 = __longlong_as_double(bits & 0x7FFFFFFFFFFFFFFCll);
-  pf = code == 2 ? 1.0 : (code == 1 ? 0.5 : (code == 3 ? 0.0 : __builtin_nan("")));
-}
 
 template <int ET>
 struct EpochTile {
@@ -68,25 +59,27 @@ __device__ __forceinline__ void scan_rows(const FieldPtrs<T>& f, int64_t off, in
                                           const BurstsDev& b, const EpochTile<ET>& ep,
                                           double (&accA)[ET][VEC], double (&accE)[ET][VEC],
                                           double (&accT)[VEC], double (&cnt)[VEC]) {
-  // n0 = |nd| xi (steady-state electron density), pf, jet flag: from three wide fields or
-  // from the one compact word
-  double n0[U][VEC], tp[U][VEC], pf[U][VEC], ts[U][VEC];
+  // g = (n x)^2 * ff/areas at chi = 1 and the jet flag: from three wide fields or from the
+  // one compact field
+  double g0[U][VEC], tp[U][VEC], ts[U][VEC];
   bool rj[U][VEC];
   if constexpr (CMP) {
-    double w[U][VEC];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const int64_t o = off + u * stride;
-      load_vec(f.ne + o, w[u]);
+      load_vec(f.em0 + o, g0[u]);
       load_vec(f.temp + o, tp[u]);
       if (BURSTS) load_vec(f.ts + o, ts[u]);
     }
 #pragma unroll
     for (int u = 0; u < U; ++u)
 #pragma unroll
-      for (int v = 0; v < VEC; ++v) decode_ne(w[u][v], n0[u][v], pf[u][v], rj[u][v]);
+      for (int v = 0; v < VEC; ++v) {
+        rj[u][v] = signbit_d(g0[u][v]);
+        g0[u][v] = fabs(g0[u][v]);
+      }
   } else {
-    double nd[U][VEC], xi[U][VEC];
+    double nd[U][VEC], xi[U][VEC], pf[U][VEC];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const int64_t o = off + u * stride;
@@ -100,7 +93,8 @@ __device__ __forceinline__ void scan_rows(const FieldPtrs<T>& f, int64_t off, in
     for (int u = 0; u < U; ++u)
 #pragma unroll
       for (int v = 0; v < VEC; ++v) {
-        n0[u][v] = fabs(nd[u][v]) * xi[u][v];
+        const double n0 = fabs(nd[u][v]) * xi[u][v];   // steady-state electron density
+        g0[u][v] = n0 * n0 * pf[u][v];
         rj[u][v] = signbit_d(nd[u][v]);
       }
   }
@@ -135,15 +129,20 @@ __device__ __forceinline__ void scan_rows(const FieldPtrs<T>& f, int64_t off, in
     chi_batch<NB, sizeof(T) == 4>(b, red, tl, chi);
   }
 
+  // temperature powers of the whole batch: T^-1.5 (scalar Gaunt) or T^-1.35 = T^-1.5 * T^0.15
+  // (power law)
+  double tpw[U][VEC];
+  pow_m1p5_batch<U * VEC>(reinterpret_cast<const double (&)[U * VEC]>(tp),
+                          reinterpret_cast<double (&)[U * VEC]>(tpw));
+
 #pragma unroll
   for (int u = 0; u < U; ++u) {
 #pragma unroll
     for (int v = 0; v < VEC; ++v) {
       const double Tk = tp[u][v];
-      // temperature power: T^-1.5 (scalar Gaunt) or T^-1.35 = T^-1.5 * T^0.15 (power law)
-      double tpow = pow_m1p5(Tk);
+      double tpow = tpw[u][v];
       if (MODE == RJP_GFF_POWERLAW) tpow *= pow(Tk, 0.15);
-      const double g = n0[u][v] * n0[u][v] * pf[u][v];   // (n x)^2 * ff/areas at chi = 1
+      const double g = g0[u][v];
       const double a = g * tpow;
       if (Tk > 0.0) { accT[v] += Tk; cnt[v] += 1.0; }
       if (BURSTS) {
@@ -335,10 +334,8 @@ __global__ __launch_bounds__(kBlock) void y_bounds_kernel(FieldPtrs<T> f, int ny
     const double tk = (double)f.temp[off];
     bool dense;                                   // n, x and ff/areas all non-NaN
     if constexpr (CMP) {
-      double n0, pf;
-      bool red;
-      decode_ne((double)f.ne[off], n0, pf, red);
-      dense = n0 == n0 && pf == pf;
+      const double g = (double)f.em0[off];
+      dense = g == g;
     } else {
       const double nd = (double)f.nd[off], xi = (double)f.xi[off], pf = (double)f.pf[off];
       dense = nd == nd && xi == xi && pf == pf;
@@ -356,8 +353,8 @@ hipError_t y_bounds_launch(const rjp_fields* fl, int32_t* ylo, int32_t* yhi, hip
   if (fl->dtype == RJP_F64) {
     FieldPtrs<double> f{(const double*)fl->d_nd, (const double*)fl->d_xi,
                         (const double*)fl->d_temp, (const double*)fl->d_pf, nullptr, nullptr,
-                        nullptr, (const double*)fl->d_ne};
-    if (fl->d_ne)
+                        nullptr, (const double*)fl->d_em0};
+    if (fl->d_em0)
       hipLaunchKernelGGL((y_bounds_kernel<double, true>), grid, blk, 0, st, f, fl->ny, fl->nz, npix, ylo, yhi);
     else
       hipLaunchKernelGGL((y_bounds_kernel<double, false>), grid, blk, 0, st, f, fl->ny, fl->nz, npix, ylo, yhi);
@@ -432,7 +429,7 @@ int ff_scan_vec(const rjp_fields* fl) {
   const int full = fl->dtype == RJP_F64 ? 2 : 4;
   const size_t esz = (size_t)fl->dtype;
   bool ok = (fl->nz % full) == 0;
-  const void* ptrs[6] = {fl->d_nd, fl->d_xi, fl->d_temp, fl->d_pf, fl->d_ts, fl->d_ne};
+  const void* ptrs[6] = {fl->d_nd, fl->d_xi, fl->d_temp, fl->d_pf, fl->d_ts, fl->d_em0};
   for (const void* p : ptrs)
     if (p && ((uintptr_t)p % 16) != 0) ok = false;
   (void)esz;
@@ -490,7 +487,7 @@ static hipError_t launch_tile(const rjp_fields* fl, const BurstsDev& b, const do
                               int nsplit, int ylen, double* ws, hipStream_t st) {
   FieldPtrs<T> f{(const T*)fl->d_nd, (const T*)fl->d_xi, (const T*)fl->d_temp,
                  (const T*)fl->d_pf, (const T*)fl->d_ts, fl->d_ylo, fl->d_yhi,
-                 (const T*)fl->d_ne};
+                 (const T*)fl->d_em0};
   EpochTile<ET> ep;
   for (int e = 0; e < ET; ++e) ep.t[e] = t[e];
   uniform_tile(t, ET, b, ep.un);
@@ -543,7 +540,7 @@ static hipError_t dispatch_mode(const rjp_fields* fl, const BurstsDev& b, bool b
                                 double* ws, hipStream_t st) {
   // the compact word layout exists for f64 storage only
   if constexpr (sizeof(T) == 8) {
-    if (fl->d_ne) {
+    if (fl->d_em0) {
       if (mode == RJP_GFF_SCALAR)
         return dispatch_et<T, VEC, RJP_GFF_SCALAR, true>(fl, b, bursts, t, et, nsplit, ylen, ws, st);
       return dispatch_et<T, VEC, RJP_GFF_POWERLAW, true>(fl, b, bursts, t, et, nsplit, ylen, ws, st);

@@ -43,45 +43,34 @@ hipError_t pack_field_launch(const double* src, const double* den, const uint8_t
 }
 
 // ---- compact scan layout ------------------------------------------------------------------
-// One word per cell for K1 (rjp_fields.d_ne): |nd * xi| rounded to a multiple of 4 ulp, the
-// 2-bit path-factor code in the two lowest mantissa bits, the red-jet flag in the sign bit.
+// One field for K1 instead of three (rjp_fields.d_em0): (|nd| xi)^2 pf, evaluated in the very
+// order K1 uses on the wide layout (so both layouts give bit-identical maps), with the
+// red-jet flag in the sign bit.
 __global__ __launch_bounds__(kFB) void compact_fields_kernel(
     const double* __restrict__ nd, const double* __restrict__ xi, const double* __restrict__ pf,
-    unsigned long long* __restrict__ ne, int64_t n, unsigned long long* __restrict__ n_general) {
+    double* __restrict__ em0, int64_t n, unsigned long long* __restrict__ n_negative) {
   int64_t i = (int64_t)blockIdx.x * kFB + threadIdx.x;
   const int64_t step = (int64_t)gridDim.x * kFB;
   unsigned bad = 0;
   for (; i < n; i += step) {
     const double d = nd[i], p = pf[i];
-    const double v = fabs(d) * xi[i];
-    unsigned long long b = (unsigned long long)__double_as_longlong(v) & 0x7FFFFFFFFFFFFFFFull;
-    if ((b >> 52) == 0x7FFull) {
-      if (b & 0x000FFFFFFFFFFFFFull) b = 0x7FF8000000000000ull;     // NaN -> canonical quiet NaN
-    } else {
-      const unsigned long long r = (b + 2ull) & ~3ull;               // nearest multiple of 4 ulp
-      b = (r >> 52) == 0x7FFull ? (b & ~3ull) : r;                   // never round up to inf
-    }
-    unsigned code = 0;
-    if (p == 1.0) code = 2;
-    else if (p == 0.5) code = 1;
-    else if (p == 0.0) code = 3;
-    else if (p == p) bad++;                                          // finite but not codable
-    b |= code;
-    if (signbit_d(d)) b |= 0x8000000000000000ull;
-    ne[i] = b;
+    const double n0 = fabs(d) * xi[i];
+    const double g = n0 * n0 * p;
+    if (p < 0.0) bad++;                    // the sign bit is taken: such a field stays wide
+    em0[i] = with_sign(g, signbit_d(d));   // NaN keeps its payload; only bit 63 changes
   }
-  if (bad) atomicAdd(n_general, (unsigned long long)bad);     // rare: uncodable cells only
+  if (bad) atomicAdd(n_negative, (unsigned long long)bad);
 }
 
-hipError_t compact_fields_launch(const rjp_fields* fl, void* d_ne, int64_t* d_n_general,
+hipError_t compact_fields_launch(const rjp_fields* fl, void* d_em0, int64_t* d_n_negative,
                                  hipStream_t st) {
   const int64_t n = (int64_t)fl->nx * fl->ny * fl->nz;
-  hipError_t e = hipMemsetAsync(d_n_general, 0, sizeof(int64_t), st);
+  hipError_t e = hipMemsetAsync(d_n_negative, 0, sizeof(int64_t), st);
   if (e != hipSuccess) return e;
   const unsigned blocks = (unsigned)std::min<int64_t>((n + kFB - 1) / kFB, 256 * 32);
   hipLaunchKernelGGL(compact_fields_kernel, dim3(blocks), dim3(kFB), 0, st,
                      (const double*)fl->d_nd, (const double*)fl->d_xi, (const double*)fl->d_pf,
-                     (unsigned long long*)d_ne, n, (unsigned long long*)d_n_general);
+                     (double*)d_em0, n, (unsigned long long*)d_n_negative);
   return hipGetLastError();
 }
 

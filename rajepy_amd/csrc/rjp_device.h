@@ -272,6 +272,27 @@ __device__ __forceinline__ double pow_m1p5(double T) {
   return pow_m1p5_slow(T);
 }
 
+// The same for N independent values without per-value branches: the Newton chains interleave
+// and the (rare) out-of-range fix-up costs one wave-uniform test.  NaN and negative T come
+// out of the fast path as NaN, which is what T^-1.5 is for them.
+template <int N>
+__device__ __forceinline__ void pow_m1p5_batch(const double (&T)[N], double (&out)[N]) {
+  bool odd = false;
+#pragma unroll
+  for (int k = 0; k < N; ++k) {
+    double y = (double)__builtin_amdgcn_rsqf((float)T[k]);
+    const double h = 0.5 * T[k];
+    y = y * __builtin_fma(-h * y, y, 1.5);
+    out[k] = y * y * y;
+    odd |= (T[k] >= 0.0 && T[k] <= 1e-30) || T[k] >= 1e30;
+  }
+  if (__builtin_amdgcn_ballot_w64(odd) != 0) {
+#pragma unroll
+    for (int k = 0; k < N; ++k)
+      if ((T[k] >= 0.0 && T[k] <= 1e-30) || T[k] >= 1e30) out[k] = pow_m1p5_slow(T[k]);
+  }
+}
+
 __device__ __forceinline__ bool signbit_d(double v) {
   return (__double_as_longlong(v) < 0);
 }

@@ -30,7 +30,7 @@ class DeviceFields:
         self.nd, self.xi, self.temp, self.pf, self.ts, self.vy = nd, xi, temp, pf, ts, vy
         self.ff_raw, self.areas_raw = ff_raw, areas_raw
         self.ylo = self.yhi = None          # optional occupied y-range per sightline (int32)
-        self.ne = None                      # optional compact scan words (rjp_fields.d_ne)
+        self.em0 = None                     # optional compact scan field (rjp_fields.d_em0)
 
     @property
     def ncells(self):
@@ -44,7 +44,7 @@ class DeviceFields:
         f = _lib.Fields()
         f.d_nd, f.d_xi, f.d_temp, f.d_pf = (t.data_ptr() if t is not None else None for t in
                                             (self.nd, self.xi, self.temp, self.pf))
-        f.d_ne = self.ne.data_ptr() if self.ne is not None else None
+        f.d_em0 = self.em0.data_ptr() if self.em0 is not None else None
         f.d_ts = self.ts.data_ptr() if self.ts is not None else None
         f.d_vy = self.vy.data_ptr() if self.vy is not None else None
         f.nx, f.ny, f.nz = self.shape
@@ -57,13 +57,13 @@ class DeviceFields:
     def nbytes(self, rrl=False):
         """Bytes one grid pass streams: the RRL scan reads the six wide fields; the continuum
         scan the three of the compact layout when it is attached, else the five wide ones."""
-        n = 6 if rrl else (3 if self.ne is not None else 5)
+        n = 6 if rrl else (3 if self.em0 is not None else 5)
         return n * self.ncells * self.dtype
 
     def drop_wide(self):
-        """Free nd / xi / pf once the compact words are attached (continuum-only sweeps of
+        """Free nd / xi / pf once the compact field is attached (continuum-only sweeps of
         grids that would not otherwise fit; the RRL and collapse=False calls need them)."""
-        if self.ne is None:
+        if self.em0 is None:
             raise ValueError("no compact layout attached")
         self.nd = self.xi = self.pf = None
 
@@ -170,21 +170,21 @@ class RTEngine:
 
     def compact(self, fields):
         """Attach the compact scan layout (rjp_compact_fields) to f64 fields: K1 then streams
-        3 fields instead of 5.  Fields whose path factors are not all in {NaN, 0, 0.5, 1}
-        (nothing the reference's fill_factor / areas can produce) keep the wide layout.
-        RJP_NO_COMPACT=1 disables it (A/B runs)."""
+        3 fields (em0, temp, ts) instead of 5, with bit-identical results.  Fields with a
+        negative path factor (nothing the reference's fill_factor / areas can produce) keep
+        the wide layout.  RJP_NO_COMPACT=1 disables it (A/B runs)."""
         torch = _torch()
-        fields.ne = None
+        fields.em0 = None
         if fields.dtype != RJP_F64 or os.environ.get("RJP_NO_COMPACT"):
             return fields
-        ne = self._f64(fields.ncells)
+        em0 = self._f64(fields.ncells)
         bad = torch.empty(1, dtype=torch.int64, device=self.device)
         fs = fields.struct()
-        _lib.check(self.lib.rjp_compact_fields(self.ctx, C.byref(fs), ne.data_ptr(),
+        _lib.check(self.lib.rjp_compact_fields(self.ctx, C.byref(fs), em0.data_ptr(),
                                                bad.data_ptr(), self._stream()), self.ctx,
                    "rjp_compact_fields")
         if int(bad.item()) == 0:
-            fields.ne = ne
+            fields.em0 = em0
         return fields
 
     def compute_y_bounds(self, fields):
@@ -215,8 +215,8 @@ class RTEngine:
                                            self._stream()), self.ctx, "rjp_pack_field")
         self.synchronize()
         setattr(fields, name, dst)
-        if name == "xi" and fields.ne is not None:
-            self.compact(fields)                # the words hold nd * xi
+        if name == "xi" and fields.em0 is not None:
+            self.compact(fields)                # em0 holds (nd xi)^2 pf
         if fields.ylo is not None and name in ("xi", "temp"):
             self.compute_y_bounds(fields)       # the occupied range depends on these fields
 

@@ -21,7 +21,7 @@ def eng():
     e.close()
 
 
-STORES = ["f64", "f64-wide", "f32"]     # f64 = compact scan words attached (the default)
+STORES = ["f64", "f64-wide", "f32"]     # f64 = compact scan field attached (the default)
 
 
 def _store(store):
@@ -29,12 +29,12 @@ def _store(store):
 
 
 def _layout(fields, store):
-    """f64 fields come with the compact words attached; "f64-wide" detaches them so the
+    """f64 fields come with the compact field attached; "f64-wide" detaches it so the
     5-field path of K1 stays covered."""
     if store == "f64":
-        assert fields.ne is not None
+        assert fields.em0 is not None
     else:
-        fields.ne = None
+        fields.em0 = None
     return fields
 
 
@@ -500,49 +500,37 @@ def test_field_builder_random_geometries_vs_oracle(eng, seed):
         np.testing.assert_allclose(got[ok], ref[name][ok], rtol=1e-9, atol=1e-6, err_msg=name)
 
 
-def _decode_words(words):
-    """Host reading of the compact words (include/rjprt.h, rjp_fields.d_ne)."""
-    bits = words.view(np.uint64)
-    code = (bits & np.uint64(3)).astype(int)
-    red = (bits >> np.uint64(63)).astype(bool)
-    n0 = (bits & np.uint64(0x7FFFFFFFFFFFFFFC)).view(np.float64)
-    pf = np.array([np.nan, 0.5, 1.0, 0.0])[code]
-    return n0, pf, red
-
-
-def test_compact_words_encode_every_special_value(eng):
-    """rjp_compact_fields: |nd * xi| to 4 ulp, inf / NaN / 0 / denormals preserved, the four
-    path-factor codes and the jet flag recovered exactly."""
+def test_compact_field_is_the_steady_state_em_density_with_the_jet_flag(eng):
+    """rjp_compact_fields: em0 = (|nd| xi)^2 pf in exactly that order (IEEE-exact against
+    NumPy), NaN / inf / 0 / denormal / overflow behave as the wide kernel's arithmetic does,
+    the sign bit carries the red-jet flag also on NaN and zero cells."""
     nd = np.array([1e5, 3.3e7, np.nan, 2e6, np.inf, 0.0, 5e-324, 1.7976931348623157e308,
-                   4.4e6, 7.7e5, 1.0, 1.0 + 2 ** -52])
-    xi = np.array([0.3, np.nan, 0.2, 1.0, 0.5, 0.4, 1.0, 1.0, 0.123456789, 0.9, 1.0, 1.0])
-    ff = np.array([1.0, 1.0, 0.5, np.nan, 1.0, 0.5, 1.0, 0.5, 0.0, -0.0, 0.5, 1.0])
+                   4.4e6, 7.7e5, 1.0, 1.0 + 2 ** -52, 1e-170, 2.5e8])
+    xi = np.array([0.3, np.nan, 0.2, 1.0, 0.5, 0.4, 1.0, 1.0, 0.123456789, 0.9, 1.0, 1.0, 1.0,
+                   0.37])
+    ff = np.array([1.0, 1.0, 0.5, np.nan, 1.0, 0.5, 1.0, 0.5, 0.0, -0.0, 0.5, 1.0, 1.0, 0.37])
     red = np.arange(nd.size) % 2 == 0
     shape = (1, nd.size // 2, 2)
     r = lambda a: np.asarray(a).reshape(shape)
     f = eng.upload_fields(r(nd), r(xi), r(np.full(nd.size, 1e4)), r(ff), r(np.ones(nd.size)),
                           r(np.zeros(nd.size)), r(red), csize_au=1.0, dtype=8)
-    assert f.ne is not None
-    n0, pf, rflag = _decode_words(f.ne.cpu().numpy())
-    want = np.abs(nd * xi)
-    assert np.array_equal(np.isnan(n0), np.isnan(want))
-    assert np.array_equal(np.isinf(n0), np.isinf(want))
-    ok = np.isfinite(want) & (want > 1e-300)
-    np.testing.assert_allclose(n0[ok], want[ok], rtol=4.5e-16)
-    assert np.all(n0[want == 0.0] == 0.0) and np.all(n0[(want > 0) & (want < 1e-300)] < 1e-322)
-    np.testing.assert_array_equal(pf, np.abs(ff))            # NaN == NaN here; -0.0 -> code 0.0
-    assert np.array_equal(rflag, red)
+    assert f.em0 is not None
+    got = f.em0.cpu().numpy()
+    with np.errstate(all="ignore"):
+        n0 = np.abs(nd) * xi
+        want = n0 * n0 * ff
+    assert np.array_equal(np.abs(got), np.abs(want), equal_nan=True)
+    assert np.array_equal(np.signbit(got), red)
 
 
 @pytest.mark.parametrize("temp_mode", [0, 1])
 @pytest.mark.parametrize("n_ep", [1, 3, 8, 16])
-def test_compact_layout_agrees_with_the_wide_one(eng, temp_mode, n_ep):
-    """K1 from the 3-field compact layout vs the 5-field wide layout of the same model: the
-    base maps differ only by the 4-ulp rounding of the electron-density word."""
+def test_compact_layout_is_bit_identical_to_the_wide_one(eng, temp_mode, n_ep):
+    """K1 from the 3-field compact layout vs the 5-field wide layout of the same model."""
     from rajepy_amd import engine as E
     shape = (8, 96, 64)
     f = eng.synth_fields(shape, 20240509, temp_mode, 8, csize_au=0.5)
-    assert f.ne is not None
+    assert f.em0 is not None
     p = copy.deepcopy(U.load_golden("cfg1_example")[2])
     p["ejection"] = U.example_bursts_params()
     g = U.synth_host((1, 2, 2), 1, 0)
@@ -553,15 +541,17 @@ def test_compact_layout_agrees_with_the_wide_one(eng, temp_mode, n_ep):
     ep = list(np.linspace(0.2, 3.4, n_ep) * orc.YEAR) if n_ep > 1 else [1.3 * orc.YEAR]
     mode = E.RJP_GFF_SCALAR if temp_mode == 0 else E.RJP_GFF_POWERLAW
     a1, e1, t1 = (x.clone() for x in eng.ff_scan(f, bursts, ep, mode))
-    words = f.ne
-    f.ne = None
+    lo1, hi1 = (x.clone() for x in eng.compute_y_bounds(f))
+    em0 = f.em0
+    f.em0 = f.ylo = f.yhi = None
     a0, e0, t0 = eng.ff_scan(f, bursts, ep, mode)
+    lo0, hi0 = eng.compute_y_bounds(f)
     eng.synchronize()
-    np.testing.assert_allclose(a1.cpu().numpy(), a0.cpu().numpy(), rtol=2e-14)
-    np.testing.assert_allclose(e1.cpu().numpy(), e0.cpu().numpy(), rtol=2e-14)
-    assert np.array_equal(t1.cpu().numpy(), t0.cpu().numpy())        # T_avg never sees the words
-    # continuum-only sweeps may free the wide fields; the RRL scan then refuses loudly
-    f.ne = words
+    for got, ref in ((a1, a0), (e1, e0), (t1, t0), (lo1, lo0), (hi1, hi0)):
+        assert np.array_equal(got.cpu().numpy(), ref.cpu().numpy())
+    # continuum-only sweeps may free the wide fields; calls that need them refuse loudly
+    f.em0 = em0
+    f.ylo = f.yhi = None
     f.drop_wide()
     a2, _, _ = eng.ff_scan(f, bursts, ep, mode)
     assert np.array_equal(a2.cpu().numpy(), a1.cpu().numpy())
@@ -570,18 +560,18 @@ def test_compact_layout_agrees_with_the_wide_one(eng, temp_mode, n_ep):
         eng.ff_cells(f, bursts, ep[0], mode, [1.0])
 
 
-def test_uncodable_path_factors_keep_the_wide_layout(eng):
-    """A path factor outside {NaN, 0, 0.5, 1} cannot be coded in two bits: the engine keeps
-    the wide layout and the maps still follow the oracle."""
+def test_negative_path_factors_keep_the_wide_layout(eng):
+    """A negative path factor would collide with the jet flag in the sign bit of em0: the
+    engine keeps the wide layout and the maps still follow the oracle."""
     shape = (3, 20, 8)
     g = U.synth_host(shape, 5, 0)
-    g["ff"] = np.where(g["ff"] == 0.5, 0.37, 1.0)
+    g["ff"] = np.where(g["ff"] == 0.5, -0.37, 1.0)
     p = copy.deepcopy(U.load_golden("cfg1_example")[2])
     p["grid"].update(n_x=shape[0], n_y=shape[1], n_z=shape[2])
     jet = orc.OracleJet.from_fields(p, g["nd"], g["xi"], g["temp"], g["ff"], g["areas"],
                                     g["ts"], g["rr"], g["vy"])
     f = _upload(eng, g, jet.csize, 8)
-    assert f.ne is None
+    assert f.em0 is None
     em, tau, flux, _, _ = _run_ff(eng, f, U.bursts_from_oracle(jet), jet, [0.9], [5e9])
     jet.time = 0.9 * orc.YEAR
     np.testing.assert_allclose(em[0], jet.emission_measure(), rtol=1e-11)

@@ -26,7 +26,7 @@ eng.time_ff_scan(fields, bursts, ep, E.RJP_GFF_SCALAR, reps=2)
 ms = min(eng.time_ff_scan(fields, bursts, ep, E.RJP_GFF_SCALAR, reps=5) for _ in range(3))
 n = shape[0] * shape[1] * shape[2]
 npass = -(-nep // 8) if nep > 1 else 1
-gb = npass * 5 * n * int(dtype) / 1e9
-print("%s %s E=%d lib=%s ysplit=%s: %.3f ms  %.0f GB/s (alg)  %.3f ms/epoch" % (
-    cfg, storage, nep, os.path.basename(os.environ.get("RJP_LIB", "default")),
+gb = npass * fields.nbytes() / 1e9
+print("%s %s %s E=%d lib=%s ysplit=%s: %.3f ms  %.0f GB/s (alg)  %.3f ms/epoch" % (
+    cfg, storage, "compact" if fields.em0 is not None else "wide", nep, os.path.basename(os.environ.get("RJP_LIB", "default")),
     os.environ.get("RJP_YSPLIT", "auto"), ms, gb / ms * 1e3, ms / nep))
