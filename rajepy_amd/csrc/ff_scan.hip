@@ -30,6 +30,27 @@ struct FieldPtrs {
   const T* em0;            // compact layout (f64 only): (|nd| xi)^2 pf, sign bit = red jet
 };
 
+// A NaN launch time never reaches the jet: its cell is given chi = 1 here (a launch at
+// -1e300 s is > 700 sigma from every burst) and masked when it is accumulated.
+__device__ __forceinline__ double launch_or_never(double ts) { return __builtin_fmax(ts, -1e300); }
+
+// x, or NaN when !keep: only the high dword is touched
+__device__ __forceinline__ double poison_unless(double x, bool keep) {
+  const long long b = __double_as_longlong(x);
+  const unsigned hi = keep ? (unsigned)((unsigned long long)b >> 32) : 0x7FF80000u;
+  return __longlong_as_double((long long)(((unsigned long long)hi << 32) |
+                                          ((unsigned long long)b & 0xFFFFFFFFull)));
+}
+
+// nansum: NaN -> 0.  A compact-layout term is never negative ((n x)^2 pf with pf >= 0 times a
+// temperature power), so max(x, 0) does it in one instruction; the wide layout admits any
+// sign of pf and selects.
+template <bool NONNEG>
+__device__ __forceinline__ double nan_to_zero(double x) {
+  if (NONNEG) return __builtin_fmax(x, 0.0);
+  return x == x ? x : 0.0;
+}
+
 template <int ET>
 struct EpochTile {
   double t[ET];
@@ -58,7 +79,7 @@ template <typename T, int VEC, int ET, int MODE, bool BURSTS, bool UNIF, bool CM
 __device__ __forceinline__ void scan_rows(const FieldPtrs<T>& f, int64_t off, int64_t stride,
                                           const BurstsDev& b, const EpochTile<ET>& ep,
                                           double (&accA)[ET][VEC], double (&accE)[ET][VEC],
-                                          double (&accT)[VEC], double (&cnt)[VEC]) {
+                                          double (&accT)[VEC], int (&cnt)[VEC]) {
   // g = (n x)^2 * ff/areas at chi = 1 and the jet flag: from three wide fields or from the
   // one compact field
   double g0[U][VEC], tp[U][VEC], ts[U][VEC];
@@ -109,7 +130,7 @@ __device__ __forceinline__ void scan_rows(const FieldPtrs<T>& f, int64_t off, in
     for (int u = 0; u < U; ++u)
 #pragma unroll
       for (int v = 0; v < VEC; ++v) {
-        tlm[u * VEC + v] = ep.t[ET / 2] - (ts[u][v] == ts[u][v] ? ts[u][v] : 0.0);
+        tlm[u * VEC + v] = ep.t[ET / 2] - launch_or_never(ts[u][v]);
         red[u * VEC + v] = rj[u][v];
       }
     chi_batch_uniform<ET, U * VEC>(b, ep.un, red, tlm, chi);
@@ -123,7 +144,7 @@ __device__ __forceinline__ void scan_rows(const FieldPtrs<T>& f, int64_t off, in
 #pragma unroll
         for (int v = 0; v < VEC; ++v) {
           const int k = (e * U + u) * VEC + v;
-          tl[k] = ep.t[e] - (ts[u][v] == ts[u][v] ? ts[u][v] : 0.0);
+          tl[k] = ep.t[e] - launch_or_never(ts[u][v]);
           red[k] = rj[u][v];
         }
     chi_batch<NB, sizeof(T) == 4>(b, red, tl, chi);
@@ -142,16 +163,17 @@ __device__ __forceinline__ void scan_rows(const FieldPtrs<T>& f, int64_t off, in
       const double Tk = tp[u][v];
       double tpow = tpw[u][v];
       if (MODE == RJP_GFF_POWERLAW) tpow *= pow(Tk, 0.15);
-      const double g = g0[u][v];
-      const double a = g * tpow;
-      if (Tk > 0.0) { accT[v] += Tk; cnt[v] += 1.0; }
+      // nanmean over T > 0 (classes.py:1471): max(T, 0) adds T, or an exact zero for
+      // T <= 0 and NaN
+      accT[v] += __builtin_fmax(Tk, 0.0);
+      cnt[v] += Tk > 0.0 ? 1 : 0;
       if (BURSTS) {
         // nansum semantics hoisted out of the epoch loop: g chi^2 is NaN iff g is NaN or
         // chi is (chi is NaN iff the launch time is -- such cells were given chi = 1 above);
         // a masked cell contributes an exact zero at every epoch
-        const bool tsok = ts[u][v] == ts[u][v];
-        const double gm = (g == g && tsok) ? g : 0.0;
-        const double am = (a == a && tsok) ? a : 0.0;
+        const double g = poison_unless(g0[u][v], ts[u][v] == ts[u][v]);
+        const double gm = nan_to_zero<CMP>(g);
+        const double am = nan_to_zero<CMP>(g * tpow);
 #pragma unroll
         for (int e = 0; e < ET; ++e) {
           const double c = chi[(e * U + u) * VEC + v];
@@ -160,8 +182,8 @@ __device__ __forceinline__ void scan_rows(const FieldPtrs<T>& f, int64_t off, in
           accA[e][v] = __builtin_fma(am, c2, accA[e][v]);
         }
       } else {
-        if (g == g) accE[0][v] += g;
-        if (a == a) accA[0][v] += a;
+        accE[0][v] += nan_to_zero<CMP>(g0[u][v]);
+        accA[0][v] += nan_to_zero<CMP>(g0[u][v] * tpow);
       }
     }
   }
@@ -196,10 +218,11 @@ __global__ __launch_bounds__(kBlock) void ff_scan_kernel(
   const int64_t x = p0 / nz;
   const int z = (int)(p0 - x * nz);
 
-  double accA[ET][VEC], accE[ET][VEC], accT[VEC], cnt[VEC];
+  double accA[ET][VEC], accE[ET][VEC], accT[VEC];
+  int cnt[VEC];
 #pragma unroll
   for (int v = 0; v < VEC; ++v) {
-    accT[v] = 0.0; cnt[v] = 0.0;
+    accT[v] = 0.0; cnt[v] = 0;
 #pragma unroll
     for (int e = 0; e < ET; ++e) { accA[e][v] = 0.0; accE[e][v] = 0.0; }
   }
@@ -230,7 +253,7 @@ __global__ __launch_bounds__(kBlock) void ff_scan_kernel(
 #pragma unroll
   for (int v = 0; v < VEC; ++v) {
     w[(int64_t)(2 * ET) * npix + v] = accT[v];
-    w[(int64_t)(2 * ET + 1) * npix + v] = cnt[v];
+    w[(int64_t)(2 * ET + 1) * npix + v] = (double)cnt[v];
   }
 }
 
