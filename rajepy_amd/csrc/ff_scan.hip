@@ -432,20 +432,31 @@ hipError_t ff_cells_launch(const rjp_fields* fl, const rjp_bursts* hb, double ti
 }
 
 // ---- launch helpers ---------------------------------------------------------------------
-static int choose_ysplit(int64_t nchunks, int ny) {
-  static int forced = -1;
-  if (forced < 0) {
-    const char* s = getenv("RJP_YSPLIT");
-    forced = s ? atoi(s) : 0;
-  }
-  if (forced > 0) return std::min(forced, ny);
+// y-splits for a map of `nchunks` lanes: enough workgroups for ~16 waves per SIMD chip-wide
+// (measured optimum on cfg4: 8 splits, 6.2 TB/s vs 5.8 at 3), at least 16 rows per split, and
+// at least 64 rows once every CU already has a wave without splitting.
+static int ysplit_rule(int64_t nchunks, int ny) {
   const int64_t waves = (nchunks + RJP_WAVE - 1) / RJP_WAVE;
-  const int64_t target = 256 * 24;                 // ~6 waves per SIMD chip-wide
+  const int64_t target = 256 * 64;
   int64_t s = (target + waves - 1) / waves;
-  const int64_t smax = std::max(1, ny / 16);
+  const int64_t smax = std::max(1, waves >= 256 ? ny / 64 : ny / 16);
   if (s > smax) s = smax;
   if (s < 1) s = 1;
   return (int)s;
+}
+
+static int forced_ysplit() {
+  static int forced = -1;
+  if (forced < 0) {
+    const char* s = getenv("RJP_YSPLIT");           // experiments only
+    forced = s ? atoi(s) : 0;
+  }
+  return forced;
+}
+
+static int choose_ysplit(int64_t nchunks, int ny) {
+  if (forced_ysplit() > 0) return std::min(forced_ysplit(), ny);
+  return ysplit_rule(nchunks, ny);
 }
 
 int ff_scan_vec(const rjp_fields* fl) {
@@ -464,13 +475,10 @@ int ff_scan_vec(const rjp_fields* fl) {
 size_t ff_scan_workspace_bytes(int nx, int ny, int nz, int n_epochs) {
   const int64_t npix = (int64_t)nx * nz;
   const int et = n_epochs < kMaxTile ? (n_epochs < 1 ? 1 : n_epochs) : kMaxTile;
-  // worst case split count is bounded by choose_ysplit's target / (npix/4/64) and ny/16
-  int64_t smax = std::max(1, ny / 16);
-  const int64_t waves_min = std::max<int64_t>(1, (npix / 4 + RJP_WAVE - 1) / RJP_WAVE);
-  int64_t s = (256 * 24 + waves_min - 1) / waves_min;
-  if (const char* f = getenv("RJP_YSPLIT")) s = std::max<int64_t>(s, atoi(f));
-  s = std::min(s, smax);
-  s = std::max<int64_t>(s, 1);
+  // worst case over the lane widths the launcher may pick (1, 2 or 4 sightlines per lane)
+  int64_t s = 1;
+  for (int vec : {1, 2, 4}) s = std::max<int64_t>(s, ysplit_rule(std::max<int64_t>(1, npix / vec), ny));
+  if (forced_ysplit() > 0) s = std::max<int64_t>(s, std::min(forced_ysplit(), ny));
   return (size_t)s * nacc(et) * npix * sizeof(double) + 256;
 }
 
