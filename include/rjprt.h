@@ -74,12 +74,13 @@ typedef struct rjp_fields {
    * range hold only cells that cannot contribute (NaN density / T <= 0) and are skipped. */
   const int32_t* d_ylo;
   const int32_t* d_yhi;
-  /* Optional compact scan layout (RJP_F64 storage only), written by rjp_compact_fields():
+  /* Optional compact scan layout, written by rjp_compact_fields() in the storage dtype:
    * d_em0[cell] = (|nd| * xi)^2 * pf, the emission-measure density of the steady-state jet
    * [cm^-6] -- the only combination of nd, xi and pf that emission_measure / optical_depth_ff
    * use (classes.py:1116-1118, 1395-1397) -- with the red-jet flag of nd in its SIGN BIT.
-   * The free-free scan then streams 3 fields (em0, temp, ts = 24 B/cell) instead of 5
-   * (40 B/cell) and returns bit-identical maps.  When non-NULL, rjp_ff_scan and rjp_y_bounds
+   * The free-free scan then streams 3 fields (em0, temp, ts = 24 B/cell in f64) instead of 5
+   * (40 B/cell) and, for f64 storage, returns bit-identical maps (f32 storage rounds the
+   * product once more, 6e-8).  When non-NULL, rjp_ff_scan and rjp_y_bounds
    * read d_em0 and ignore d_nd / d_xi / d_pf (which may then be NULL for those two calls);
    * the RRL and collapse=False entry points always read the wide fields. */
   const void* d_em0;
@@ -118,14 +119,14 @@ const char* rjp_last_error(const rjp_ctx* ctx);   /* ctx may be NULL: last creat
 int rjp_pack_field(rjp_ctx* ctx, const double* d_src, const double* d_den,
                    const uint8_t* d_red, void* d_dst, int64_t n, int dtype, void* stream);
 
-/* Builds the compact scan field (see rjp_fields.d_em0) from the wide f64 fields nd, xi, pf in
- * one pass over all n_x*n_y*n_z cells.  *d_n_negative (a device int64, zeroed by the call)
- * receives the number of cells with a NEGATIVE path factor, whose sign would collide with the
- * jet flag; when it is non-zero the field is unusable and the caller keeps scanning the wide
- * layout (fill_factor / areas never produce one, classes.py:657-669, 763-764).
- * RJP_ERR_ARG for RJP_F32 storage. */
+/* Builds the compact scan field (see rjp_fields.d_em0) from the wide fields nd, xi, pf in one
+ * pass over all n_x*n_y*n_z cells, in the fields' storage dtype.  *d_n_bad (a device int64,
+ * zeroed by the call) receives the number of cells the field cannot represent: a NEGATIVE
+ * path factor (its sign would collide with the jet flag; fill_factor / areas never produce
+ * one, classes.py:657-669, 763-764) or, for RJP_F32, a product outside the float range.
+ * When it is non-zero the field is unusable and the caller keeps scanning the wide layout. */
 int rjp_compact_fields(rjp_ctx* ctx, const rjp_fields* fields, void* d_em0,
-                       int64_t* d_n_negative, void* stream);
+                       int64_t* d_n_bad, void* stream);
 
 /* Per-sightline occupied y-range of a packed field set: d_ylo[p] = first row, d_yhi[p] = one
  * past the last row whose cell can contribute to any product of the path, i.e. T > 0 (counts

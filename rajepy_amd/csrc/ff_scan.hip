@@ -9,7 +9,7 @@
 // over gridDim.y so small maps still fill 256 CUs; partial sums go to a workspace and a tiny
 // second kernel reduces them in a fixed order (bitwise reproducible, no atomics).
 // HBM-bound: algorithmic bytes = 5 fields * sizeof(T) per cell per epoch tile in the wide
-// layout, 3 fields * 8 B in the compact layout (rjp_fields.d_em0 = (n x)^2 pf with the jet flag
+// layout, 3 fields * sizeof(T) in the compact layout (rjp_fields.d_em0 = (n x)^2 pf with the jet flag
 // in its sign bit, temp, ts).
 #include <algorithm>
 #include <cmath>
@@ -27,7 +27,7 @@ struct FieldPtrs {
   const T* ts;
   const int32_t* ylo;      // optional occupied y-range per sightline (nullptr = all rows)
   const int32_t* yhi;
-  const T* em0;            // compact layout (f64 only): (|nd| xi)^2 pf, sign bit = red jet
+  const T* em0;            // compact layout: (|nd| xi)^2 pf, sign bit = red jet
 };
 
 // A NaN launch time never reaches the jet: its cell is given chi = 1 here (a launch at
@@ -64,8 +64,10 @@ constexpr int kMaxTile = 16;     // largest epoch tile (uniformly spaced epochs,
 #ifndef RJP_UNROLL_BASE
 #define RJP_UNROLL_BASE 4
 #endif
-__host__ __device__ constexpr int unroll_for(int vec, int et) {
-  return vec * et >= 16 ? 1 : (vec * et >= 8 ? 2 : RJP_UNROLL_BASE);
+// 4-wide (f32) lanes on the wide layout: 2 rows (8 cells per batch, 166 VGPRs; 4 rows need
+// 256 + AGPR spills); on the compact layout 4 rows still fit 3 waves/SIMD and are 3 % faster
+__host__ __device__ constexpr int unroll_for(int vec, int et, bool compact) {
+  return vec * et >= 16 ? 1 : (vec * et >= 8 ? 2 : (vec == 4 && !compact ? 2 : RJP_UNROLL_BASE));
 }
 
 // number of accumulator planes a tile of ET epochs writes per y-split
@@ -193,7 +195,7 @@ template <typename T, int VEC, int ET, int MODE, bool BURSTS, bool UNIF, bool CM
 __global__ __launch_bounds__(kBlock) void ff_scan_kernel(
     FieldPtrs<T> f, int ny, int nz, int64_t nchunks, int64_t npix, int ylen, BurstsDev b,
     EpochTile<ET> ep, double* __restrict__ ws) {
-  constexpr int kUnroll = unroll_for(VEC, ET);
+  constexpr int kUnroll = unroll_for(VEC, ET, CMP);
   const int64_t c = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   const bool lane_live = c < nchunks;
   const int64_t p0 = c * VEC;              // first sightline (pixel) of this lane
@@ -383,8 +385,11 @@ hipError_t y_bounds_launch(const rjp_fields* fl, int32_t* ylo, int32_t* yhi, hip
       hipLaunchKernelGGL((y_bounds_kernel<double, false>), grid, blk, 0, st, f, fl->ny, fl->nz, npix, ylo, yhi);
   } else {
     FieldPtrs<float> f{(const float*)fl->d_nd, (const float*)fl->d_xi, (const float*)fl->d_temp,
-                       (const float*)fl->d_pf, nullptr, nullptr, nullptr, nullptr};
-    hipLaunchKernelGGL((y_bounds_kernel<float, false>), grid, blk, 0, st, f, fl->ny, fl->nz, npix, ylo, yhi);
+                       (const float*)fl->d_pf, nullptr, nullptr, nullptr, (const float*)fl->d_em0};
+    if (fl->d_em0)
+      hipLaunchKernelGGL((y_bounds_kernel<float, true>), grid, blk, 0, st, f, fl->ny, fl->nz, npix, ylo, yhi);
+    else
+      hipLaunchKernelGGL((y_bounds_kernel<float, false>), grid, blk, 0, st, f, fl->ny, fl->nz, npix, ylo, yhi);
   }
   return hipGetLastError();
 }
@@ -569,13 +574,10 @@ template <typename T, int VEC>
 static hipError_t dispatch_mode(const rjp_fields* fl, const BurstsDev& b, bool bursts,
                                 int mode, const double* t, int et, int nsplit, int ylen,
                                 double* ws, hipStream_t st) {
-  // the compact word layout exists for f64 storage only
-  if constexpr (sizeof(T) == 8) {
-    if (fl->d_em0) {
-      if (mode == RJP_GFF_SCALAR)
-        return dispatch_et<T, VEC, RJP_GFF_SCALAR, true>(fl, b, bursts, t, et, nsplit, ylen, ws, st);
-      return dispatch_et<T, VEC, RJP_GFF_POWERLAW, true>(fl, b, bursts, t, et, nsplit, ylen, ws, st);
-    }
+  if (fl->d_em0) {                                  // compact layout attached
+    if (mode == RJP_GFF_SCALAR)
+      return dispatch_et<T, VEC, RJP_GFF_SCALAR, true>(fl, b, bursts, t, et, nsplit, ylen, ws, st);
+    return dispatch_et<T, VEC, RJP_GFF_POWERLAW, true>(fl, b, bursts, t, et, nsplit, ylen, ws, st);
   }
   if (mode == RJP_GFF_SCALAR)
     return dispatch_et<T, VEC, RJP_GFF_SCALAR, false>(fl, b, bursts, t, et, nsplit, ylen, ws, st);

@@ -46,31 +46,50 @@ hipError_t pack_field_launch(const double* src, const double* den, const uint8_t
 // One field for K1 instead of three (rjp_fields.d_em0): (|nd| xi)^2 pf, evaluated in the very
 // order K1 uses on the wide layout (so both layouts give bit-identical maps), with the
 // red-jet flag in the sign bit.
+template <typename T>
 __global__ __launch_bounds__(kFB) void compact_fields_kernel(
-    const double* __restrict__ nd, const double* __restrict__ xi, const double* __restrict__ pf,
-    double* __restrict__ em0, int64_t n, unsigned long long* __restrict__ n_negative) {
+    const T* __restrict__ nd, const T* __restrict__ xi, const T* __restrict__ pf,
+    T* __restrict__ em0, int64_t n, unsigned long long* __restrict__ n_bad) {
   int64_t i = (int64_t)blockIdx.x * kFB + threadIdx.x;
   const int64_t step = (int64_t)gridDim.x * kFB;
   unsigned bad = 0;
   for (; i < n; i += step) {
-    const double d = nd[i], p = pf[i];
-    const double n0 = fabs(d) * xi[i];
+    const double d = (double)nd[i], p = (double)pf[i];
+    const double n0 = fabs(d) * (double)xi[i];
     const double g = n0 * n0 * p;
     if (p < 0.0) bad++;                    // the sign bit is taken: such a field stays wide
-    em0[i] = with_sign(g, signbit_d(d));   // NaN keeps its payload; only bit 63 changes
+    const T out = (T)g;
+    if (sizeof(T) == 4) {
+      // float storage must hold the product: no overflow, no flush of a non-zero term
+      const double back = fabs((double)out);
+      if (g == g && fabs(g) <= 1.7e308 && (back > 3.4e38 || (g != 0.0 && back < 1.2e-38))) bad++;
+    }
+    // NaN keeps its payload; only the sign bit changes
+    if (sizeof(T) == 8) {
+      em0[i] = (T)with_sign(g, signbit_d(d));
+    } else {
+      unsigned u = __float_as_uint((float)out) & 0x7FFFFFFFu;
+      if (signbit_d(d)) u |= 0x80000000u;
+      em0[i] = (T)__uint_as_float(u);
+    }
   }
-  if (bad) atomicAdd(n_negative, (unsigned long long)bad);
+  if (bad) atomicAdd(n_bad, (unsigned long long)bad);
 }
 
-hipError_t compact_fields_launch(const rjp_fields* fl, void* d_em0, int64_t* d_n_negative,
+hipError_t compact_fields_launch(const rjp_fields* fl, void* d_em0, int64_t* d_n_bad,
                                  hipStream_t st) {
   const int64_t n = (int64_t)fl->nx * fl->ny * fl->nz;
-  hipError_t e = hipMemsetAsync(d_n_negative, 0, sizeof(int64_t), st);
+  hipError_t e = hipMemsetAsync(d_n_bad, 0, sizeof(int64_t), st);
   if (e != hipSuccess) return e;
   const unsigned blocks = (unsigned)std::min<int64_t>((n + kFB - 1) / kFB, 256 * 32);
-  hipLaunchKernelGGL(compact_fields_kernel, dim3(blocks), dim3(kFB), 0, st,
-                     (const double*)fl->d_nd, (const double*)fl->d_xi, (const double*)fl->d_pf,
-                     (double*)d_em0, n, (unsigned long long*)d_n_negative);
+  if (fl->dtype == RJP_F64)
+    hipLaunchKernelGGL(compact_fields_kernel<double>, dim3(blocks), dim3(kFB), 0, st,
+                       (const double*)fl->d_nd, (const double*)fl->d_xi, (const double*)fl->d_pf,
+                       (double*)d_em0, n, (unsigned long long*)d_n_bad);
+  else
+    hipLaunchKernelGGL(compact_fields_kernel<float>, dim3(blocks), dim3(kFB), 0, st,
+                       (const float*)fl->d_nd, (const float*)fl->d_xi, (const float*)fl->d_pf,
+                       (float*)d_em0, n, (unsigned long long*)d_n_bad);
   return hipGetLastError();
 }
 

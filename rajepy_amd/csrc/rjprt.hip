@@ -96,8 +96,6 @@ static int check_fields(rjp_ctx* ctx, const rjp_fields* f, bool need_vy, bool co
     return fail(ctx, RJP_ERR_ARG, "fields.dtype must be RJP_F32 (4) or RJP_F64 (8)");
   if (f->nx <= 0 || f->ny <= 0 || f->nz <= 0)
     return fail(ctx, RJP_ERR_ARG, "grid dimensions must be positive");
-  if (f->d_em0 && f->dtype != RJP_F64)
-    return fail(ctx, RJP_ERR_ARG, "fields.d_em0 (compact layout) requires RJP_F64 storage");
   if (compact_ok && f->d_em0) {
     if (!f->d_temp) return fail(ctx, RJP_ERR_ARG, "fields.d_temp must be a device pointer");
   } else if (!f->d_nd || !f->d_xi || !f->d_temp || !f->d_pf) {
@@ -189,14 +187,12 @@ int rjp_pack_field(rjp_ctx* ctx, const double* d_src, const double* d_den,
   return RJP_OK;
 }
 
-int rjp_compact_fields(rjp_ctx* ctx, const rjp_fields* fields, void* d_em0, int64_t* d_n_negative,
+int rjp_compact_fields(rjp_ctx* ctx, const rjp_fields* fields, void* d_em0, int64_t* d_n_bad,
                        void* stream) {
   if (int r = bind(ctx)) return r;
   if (int r = check_fields(ctx, fields, false)) return r;
-  if (fields->dtype != RJP_F64)
-    return fail(ctx, RJP_ERR_ARG, "rjp_compact_fields: the compact layout is for RJP_F64 storage");
-  if (!d_em0 || !d_n_negative) return fail(ctx, RJP_ERR_ARG, "rjp_compact_fields: NULL output");
-  RJP_HIP(ctx, rjp::compact_fields_launch(fields, d_em0, d_n_negative, (hipStream_t)stream));
+  if (!d_em0 || !d_n_bad) return fail(ctx, RJP_ERR_ARG, "rjp_compact_fields: NULL output");
+  RJP_HIP(ctx, rjp::compact_fields_launch(fields, d_em0, d_n_bad, (hipStream_t)stream));
   return RJP_OK;
 }
 

@@ -169,15 +169,16 @@ class RTEngine:
                                          d_vy))
 
     def compact(self, fields):
-        """Attach the compact scan layout (rjp_compact_fields) to f64 fields: K1 then streams
-        3 fields (em0, temp, ts) instead of 5, with bit-identical results.  Fields with a
-        negative path factor (nothing the reference's fill_factor / areas can produce) keep
-        the wide layout.  RJP_NO_COMPACT=1 disables it (A/B runs)."""
+        """Attach the compact scan layout (rjp_compact_fields): K1 then streams 3 fields
+        (em0, temp, ts) instead of 5 -- bit-identical maps for f64 storage.  Fields with a
+        negative path factor (nothing the reference's fill_factor / areas can produce) or,
+        in f32 storage, a product outside the float range keep the wide layout.
+        RJP_NO_COMPACT=1 disables it (A/B runs)."""
         torch = _torch()
         fields.em0 = None
-        if fields.dtype != RJP_F64 or os.environ.get("RJP_NO_COMPACT"):
+        if os.environ.get("RJP_NO_COMPACT"):
             return fields
-        em0 = self._f64(fields.ncells)
+        em0 = self._empty(fields.ncells, fields.dtype)
         bad = torch.empty(1, dtype=torch.int64, device=self.device)
         fs = fields.struct()
         _lib.check(self.lib.rjp_compact_fields(self.ctx, C.byref(fs), em0.data_ptr(),

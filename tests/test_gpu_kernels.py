@@ -21,17 +21,17 @@ def eng():
     e.close()
 
 
-STORES = ["f64", "f64-wide", "f32"]     # f64 = compact scan field attached (the default)
+STORES = ["f64", "f64-wide", "f32", "f32-wide"]   # default = compact scan field attached
 
 
 def _store(store):
-    return 4 if store == "f32" else 8
+    return 4 if store.startswith("f32") else 8
 
 
 def _layout(fields, store):
-    """f64 fields come with the compact field attached; "f64-wide" detaches it so the
-    5-field path of K1 stays covered."""
-    if store == "f64":
+    """Fields come with the compact field attached; "*-wide" detaches it so the 5-field path
+    of K1 stays covered."""
+    if not store.endswith("-wide"):
         assert fields.em0 is not None
     else:
         fields.em0 = None
@@ -525,11 +525,13 @@ def test_compact_field_is_the_steady_state_em_density_with_the_jet_flag(eng):
 
 @pytest.mark.parametrize("temp_mode", [0, 1])
 @pytest.mark.parametrize("n_ep", [1, 3, 8, 16])
-def test_compact_layout_is_bit_identical_to_the_wide_one(eng, temp_mode, n_ep):
-    """K1 from the 3-field compact layout vs the 5-field wide layout of the same model."""
+@pytest.mark.parametrize("dtype", [8, 4])
+def test_compact_layout_is_bit_identical_to_the_wide_one(eng, temp_mode, n_ep, dtype):
+    """K1 from the 3-field compact layout vs the 5-field wide layout of the same model:
+    bit-identical for f64 storage; f32 storage rounds the product once more (6e-8)."""
     from rajepy_amd import engine as E
     shape = (8, 96, 64)
-    f = eng.synth_fields(shape, 20240509, temp_mode, 8, csize_au=0.5)
+    f = eng.synth_fields(shape, 20240509, temp_mode, dtype, csize_au=0.5)
     assert f.em0 is not None
     p = copy.deepcopy(U.load_golden("cfg1_example")[2])
     p["ejection"] = U.example_bursts_params()
@@ -548,7 +550,10 @@ def test_compact_layout_is_bit_identical_to_the_wide_one(eng, temp_mode, n_ep):
     lo0, hi0 = eng.compute_y_bounds(f)
     eng.synchronize()
     for got, ref in ((a1, a0), (e1, e0), (t1, t0), (lo1, lo0), (hi1, hi0)):
-        assert np.array_equal(got.cpu().numpy(), ref.cpu().numpy())
+        if dtype == 8 or got is t1 or got.dtype != a1.dtype:
+            assert np.array_equal(got.cpu().numpy(), ref.cpu().numpy())
+        else:
+            np.testing.assert_allclose(got.cpu().numpy(), ref.cpu().numpy(), rtol=2e-7)
     # continuum-only sweeps may free the wide fields; calls that need them refuse loudly
     f.em0 = em0
     f.ylo = f.yhi = None
@@ -558,6 +563,27 @@ def test_compact_layout_is_bit_identical_to_the_wide_one(eng, temp_mode, n_ep):
     from rajepy_amd._lib import RjprtError
     with pytest.raises(RjprtError, match="nd/xi/temp/pf"):
         eng.ff_cells(f, bursts, ep[0], mode, [1.0])
+
+
+def test_f32_compact_field_and_its_range_guard(eng):
+    """f32 storage: em0 is the float rounding of the f64 product of the float-rounded fields;
+    a product beyond the float range keeps the model on the wide layout."""
+    shape = (2, 6, 4)
+    g = U.synth_host(shape, 77, 1)
+    up = lambda gg: eng.upload_fields(gg["nd"], gg["xi"], gg["temp"], gg["ff"], gg["areas"],
+                                      gg["ts"], gg["rr"] < 0, csize_au=1.0, dtype=4)
+    f = up(g)
+    assert f.em0 is not None and f.em0.dtype == f.temp.dtype
+    f32 = lambda a: a.astype(np.float32).astype(np.float64)
+    n0 = f32(g["nd"]) * f32(g["xi"])
+    want = (n0 * n0 * f32(g["ff"] / g["areas"])).astype(np.float32)
+    got = f.em0.cpu().numpy().reshape(shape)
+    assert np.array_equal(np.abs(got), want)
+    assert np.array_equal(np.signbit(got), g["rr"] < 0)
+    big = dict(g, nd=g["nd"] * 1e17)                    # (n x)^2 ~ 1e43 > FLT_MAX
+    assert up(big).em0 is None
+    tiny = dict(g, nd=g["nd"] * 1e-27)                  # (n x)^2 ~ 1e-45: would flush to zero
+    assert up(tiny).em0 is None
 
 
 def test_negative_path_factors_keep_the_wide_layout(eng):
