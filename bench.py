@@ -205,7 +205,8 @@ def main():
     E_loc = len(my_epochs)
 
     sumA = eng._f64(E_loc, P)
-    em = eng._f64(E_loc, P)
+    # flux-vs-time sweeps (cfg5) ask for no emission-measure maps, as parallel.sweep_flux_vs_time
+    em = None if n_ep_cfg else eng._f64(E_loc, P)
     tavg = eng._f64(P)
     ftot = eng._f64(E_loc, nchan)
     if n_ep_cfg:
@@ -271,7 +272,8 @@ def main():
         alg_bytes = 6 * ncell_loc * int(dtype) + nchan * P * 8
         kname, extra = "rrl_scan_kernel", {"voigt_evals_per_s": ncell_loc * nchan / (k_ms * 1e-3)}
     else:
-        k_ms = eng.time_ff_scan(fields, bursts, my_epochs, E.RJP_GFF_SCALAR, reps=5)
+        k_ms = eng.time_ff_scan(fields, bursts, my_epochs, E.RJP_GFF_SCALAR, reps=5,
+                                want_em=em is not None)
         # epoch tiles share a pass over the grid: 16 uniformly spaced epochs, else 8 (f64
         # lanes) or 4 (f32 lanes)
         tile = 16 if E_loc >= 16 else (8 if args.storage == "f64" else 4)

@@ -77,10 +77,11 @@ __host__ __device__ constexpr int nacc(int et) { return 2 * et + 2; }
 // then the burst factors of all U*VEC*ET (cell, epoch) pairs as ONE batch so their exp()
 // polynomial chains interleave (FP64 FMA latency is what limits a single chain), then the
 // accumulation.
-template <typename T, int VEC, int ET, int MODE, bool BURSTS, bool UNIF, bool CMP, int U>
+template <typename T, int VEC, int ET, int MODE, bool BURSTS, bool UNIF, bool CMP, bool EM, int U>
 __device__ __forceinline__ void scan_rows(const FieldPtrs<T>& f, int64_t off, int64_t stride,
                                           const BurstsDev& b, const EpochTile<ET>& ep,
-                                          double (&accA)[ET][VEC], double (&accE)[ET][VEC],
+                                          double (&accA)[ET][VEC],
+                                          double (&accE)[EM ? ET : 1][VEC],
                                           double (&accT)[VEC], int (&cnt)[VEC]) {
   // g = (n x)^2 * ff/areas at chi = 1 and the jet flag: from three wide fields or from the
   // one compact field
@@ -180,18 +181,20 @@ __device__ __forceinline__ void scan_rows(const FieldPtrs<T>& f, int64_t off, in
         for (int e = 0; e < ET; ++e) {
           const double c = chi[(e * U + u) * VEC + v];
           const double c2 = c * c;
-          accE[e][v] = __builtin_fma(gm, c2, accE[e][v]);
+          if (EM) accE[e][v] = __builtin_fma(gm, c2, accE[e][v]);
           accA[e][v] = __builtin_fma(am, c2, accA[e][v]);
         }
       } else {
-        accE[0][v] += nan_to_zero<CMP>(g0[u][v]);
+        if (EM) accE[0][v] += nan_to_zero<CMP>(g0[u][v]);
         accA[0][v] += nan_to_zero<CMP>(g0[u][v] * tpow);
       }
     }
   }
 }
 
-template <typename T, int VEC, int ET, int MODE, bool BURSTS, bool UNIF, bool CMP>
+// EM = false (flux-vs-time sweeps: no emission-measure maps wanted) drops the second
+// accumulator set: fewer registers, one more wave per SIMD on the 16-epoch tiles.
+template <typename T, int VEC, int ET, int MODE, bool BURSTS, bool UNIF, bool CMP, bool EM>
 __global__ __launch_bounds__(kBlock) void ff_scan_kernel(
     FieldPtrs<T> f, int ny, int nz, int64_t nchunks, int64_t npix, int ylen, BurstsDev b,
     EpochTile<ET> ep, double* __restrict__ ws) {
@@ -220,13 +223,13 @@ __global__ __launch_bounds__(kBlock) void ff_scan_kernel(
   const int64_t x = p0 / nz;
   const int z = (int)(p0 - x * nz);
 
-  double accA[ET][VEC], accE[ET][VEC], accT[VEC];
+  double accA[ET][VEC], accE[EM ? ET : 1][VEC], accT[VEC];
   int cnt[VEC];
 #pragma unroll
   for (int v = 0; v < VEC; ++v) {
     accT[v] = 0.0; cnt[v] = 0;
 #pragma unroll
-    for (int e = 0; e < ET; ++e) { accA[e][v] = 0.0; accE[e][v] = 0.0; }
+    for (int e = 0; e < ET; ++e) { accA[e][v] = 0.0; if (EM) accE[e][v] = 0.0; }
   }
 
   int64_t off = (x * ny + y0) * (int64_t)nz + z;
@@ -234,11 +237,11 @@ __global__ __launch_bounds__(kBlock) void ff_scan_kernel(
 
   int y = y0;
   for (; y + kUnroll <= y1; y += kUnroll) {
-    scan_rows<T, VEC, ET, MODE, BURSTS, UNIF, CMP, kUnroll>(f, off, stride, b, ep, accA, accE, accT, cnt);
+    scan_rows<T, VEC, ET, MODE, BURSTS, UNIF, CMP, EM, kUnroll>(f, off, stride, b, ep, accA, accE, accT, cnt);
     off += kUnroll * stride;
   }
   for (; y < y1; ++y) {
-    scan_rows<T, VEC, ET, MODE, BURSTS, UNIF, CMP, 1>(f, off, stride, b, ep, accA, accE, accT, cnt);
+    scan_rows<T, VEC, ET, MODE, BURSTS, UNIF, CMP, EM, 1>(f, off, stride, b, ep, accA, accE, accT, cnt);
     off += stride;
   }
 
@@ -249,7 +252,7 @@ __global__ __launch_bounds__(kBlock) void ff_scan_kernel(
 #pragma unroll
     for (int v = 0; v < VEC; ++v) {
       w[(int64_t)e * npix + v] = accA[e][v];
-      w[(int64_t)(ET + e) * npix + v] = accE[e][v];
+      if (EM) w[(int64_t)(ET + e) * npix + v] = accE[e][v];
     }
   }
 #pragma unroll
@@ -520,7 +523,7 @@ static void uniform_tile(const double* t, int et, const BurstsDev& b, UnifDev& u
 
 template <typename T, int VEC, int ET, int MODE, bool BURSTS, bool CMP>
 static hipError_t launch_tile(const rjp_fields* fl, const BurstsDev& b, const double* t,
-                              int nsplit, int ylen, double* ws, hipStream_t st) {
+                              int nsplit, int ylen, double* ws, bool want_em, hipStream_t st) {
   FieldPtrs<T> f{(const T*)fl->d_nd, (const T*)fl->d_xi, (const T*)fl->d_temp,
                  (const T*)fl->d_pf, (const T*)fl->d_ts, fl->d_ylo, fl->d_yhi,
                  (const T*)fl->d_em0};
@@ -534,14 +537,23 @@ static hipError_t launch_tile(const rjp_fields* fl, const BurstsDev& b, const do
   // their 9-instruction float-accuracy exp instead
   if constexpr (BURSTS && ET >= 4 && (sizeof(T) == 8 || ET == 16)) {
     if (ep.un.on) {
-      hipLaunchKernelGGL((ff_scan_kernel<T, VEC, ET, MODE, true, true, CMP>), grid, dim3(kBlock), 0,
-                         st, f, fl->ny, fl->nz, nchunks, npix, ylen, b, ep, ws);
+      if (want_em)
+        hipLaunchKernelGGL((ff_scan_kernel<T, VEC, ET, MODE, true, true, CMP, true>), grid,
+                           dim3(kBlock), 0, st, f, fl->ny, fl->nz, nchunks, npix, ylen, b, ep, ws);
+      else
+        hipLaunchKernelGGL((ff_scan_kernel<T, VEC, ET, MODE, true, true, CMP, false>), grid,
+                           dim3(kBlock), 0, st, f, fl->ny, fl->nz, nchunks, npix, ylen, b, ep, ws);
       return hipGetLastError();
     }
   }
   if constexpr (ET <= 8) {
-    hipLaunchKernelGGL((ff_scan_kernel<T, VEC, ET, MODE, BURSTS, false, CMP>), grid, dim3(kBlock), 0,
-                       st, f, fl->ny, fl->nz, nchunks, npix, ylen, b, ep, ws);
+    // single-epoch and generic tiles always carry the emission measure (cheap there)
+    if (want_em || ET < 4)
+      hipLaunchKernelGGL((ff_scan_kernel<T, VEC, ET, MODE, BURSTS, false, CMP, true>), grid,
+                         dim3(kBlock), 0, st, f, fl->ny, fl->nz, nchunks, npix, ylen, b, ep, ws);
+    else
+      hipLaunchKernelGGL((ff_scan_kernel<T, VEC, ET, MODE, BURSTS, false, CMP, false>), grid,
+                         dim3(kBlock), 0, st, f, fl->ny, fl->nz, nchunks, npix, ylen, b, ep, ws);
     return hipGetLastError();
   }
   return hipErrorInvalidValue;       // a 16-epoch tile that is not uniform: launcher bug
@@ -550,21 +562,21 @@ static hipError_t launch_tile(const rjp_fields* fl, const BurstsDev& b, const do
 template <typename T, int VEC, int MODE, bool CMP>
 static hipError_t dispatch_et(const rjp_fields* fl, const BurstsDev& b, bool bursts,
                               const double* t, int et, int nsplit, int ylen, double* ws,
-                              hipStream_t st) {
-  if (!bursts) return launch_tile<T, VEC, 1, MODE, false, CMP>(fl, b, t, nsplit, ylen, ws, st);
+                              bool want_em, hipStream_t st) {
+  if (!bursts) return launch_tile<T, VEC, 1, MODE, false, CMP>(fl, b, t, nsplit, ylen, ws, want_em, st);
   switch (et) {
-    case 1: return launch_tile<T, VEC, 1, MODE, true, CMP>(fl, b, t, nsplit, ylen, ws, st);
-    case 2: return launch_tile<T, VEC, 2, MODE, true, CMP>(fl, b, t, nsplit, ylen, ws, st);
-    case 4: return launch_tile<T, VEC, 4, MODE, true, CMP>(fl, b, t, nsplit, ylen, ws, st);
+    case 1: return launch_tile<T, VEC, 1, MODE, true, CMP>(fl, b, t, nsplit, ylen, ws, want_em, st);
+    case 2: return launch_tile<T, VEC, 2, MODE, true, CMP>(fl, b, t, nsplit, ylen, ws, want_em, st);
+    case 4: return launch_tile<T, VEC, 4, MODE, true, CMP>(fl, b, t, nsplit, ylen, ws, want_em, st);
     case 8:
       // 4 sightlines x 8 epochs x 2 sums does not fit 256 VGPRs: the launcher caps the
       // epoch tile at 4 for 4-wide (f32) lanes
       if constexpr (VEC == 4) return hipErrorInvalidValue;
-      else return launch_tile<T, VEC, 8, MODE, true, CMP>(fl, b, t, nsplit, ylen, ws, st);
+      else return launch_tile<T, VEC, 8, MODE, true, CMP>(fl, b, t, nsplit, ylen, ws, want_em, st);
     case 16:
       // only the uniform-epoch recurrence keeps 16 epochs of state in registers
       if constexpr (VEC == 1)
-        return launch_tile<T, VEC, 16, MODE, true, CMP>(fl, b, t, nsplit, ylen, ws, st);
+        return launch_tile<T, VEC, 16, MODE, true, CMP>(fl, b, t, nsplit, ylen, ws, want_em, st);
       else return hipErrorInvalidValue;
   }
   return hipErrorInvalidValue;
@@ -573,15 +585,15 @@ static hipError_t dispatch_et(const rjp_fields* fl, const BurstsDev& b, bool bur
 template <typename T, int VEC>
 static hipError_t dispatch_mode(const rjp_fields* fl, const BurstsDev& b, bool bursts,
                                 int mode, const double* t, int et, int nsplit, int ylen,
-                                double* ws, hipStream_t st) {
+                                double* ws, bool want_em, hipStream_t st) {
   if (fl->d_em0) {                                  // compact layout attached
     if (mode == RJP_GFF_SCALAR)
-      return dispatch_et<T, VEC, RJP_GFF_SCALAR, true>(fl, b, bursts, t, et, nsplit, ylen, ws, st);
-    return dispatch_et<T, VEC, RJP_GFF_POWERLAW, true>(fl, b, bursts, t, et, nsplit, ylen, ws, st);
+      return dispatch_et<T, VEC, RJP_GFF_SCALAR, true>(fl, b, bursts, t, et, nsplit, ylen, ws, want_em, st);
+    return dispatch_et<T, VEC, RJP_GFF_POWERLAW, true>(fl, b, bursts, t, et, nsplit, ylen, ws, want_em, st);
   }
   if (mode == RJP_GFF_SCALAR)
-    return dispatch_et<T, VEC, RJP_GFF_SCALAR, false>(fl, b, bursts, t, et, nsplit, ylen, ws, st);
-  return dispatch_et<T, VEC, RJP_GFF_POWERLAW, false>(fl, b, bursts, t, et, nsplit, ylen, ws, st);
+    return dispatch_et<T, VEC, RJP_GFF_SCALAR, false>(fl, b, bursts, t, et, nsplit, ylen, ws, want_em, st);
+  return dispatch_et<T, VEC, RJP_GFF_POWERLAW, false>(fl, b, bursts, t, et, nsplit, ylen, ws, want_em, st);
 }
 
 // Enqueue the whole scan for n_epochs epochs.  Returns hipSuccess or the first error.
@@ -617,12 +629,12 @@ hipError_t ff_scan_launch(const rjp_fields* fl, const rjp_bursts* hb, const doub
       // 16-epoch tiles are ALU-bound and register-hungry: one sightline per lane (160 VGPRs,
       // 3 waves/SIMD) beats two (256 VGPRs, 1 wave/SIMD) by 15 %
       err = (vec == 2 && et != 16)
-                ? dispatch_mode<double, 2>(fl, b, bursts, mode, t, et, nsplit, ylen, ws, st)
-                : dispatch_mode<double, 1>(fl, b, bursts, mode, t, et, nsplit, ylen, ws, st);
+                ? dispatch_mode<double, 2>(fl, b, bursts, mode, t, et, nsplit, ylen, ws, em != nullptr, st)
+                : dispatch_mode<double, 1>(fl, b, bursts, mode, t, et, nsplit, ylen, ws, em != nullptr, st);
     } else {
       err = (vec == 4 && et != 16)
-                ? dispatch_mode<float, 4>(fl, b, bursts, mode, t, et, nsplit, ylen, ws, st)
-                : dispatch_mode<float, 1>(fl, b, bursts, mode, t, et, nsplit, ylen, ws, st);
+                ? dispatch_mode<float, 4>(fl, b, bursts, mode, t, et, nsplit, ylen, ws, em != nullptr, st)
+                : dispatch_mode<float, 1>(fl, b, bursts, mode, t, et, nsplit, ylen, ws, em != nullptr, st);
     }
     if (err != hipSuccess) return err;
     hipLaunchKernelGGL(ff_reduce_kernel, dim3(rblocks), dim3(kBlock), 0, st, ws, nsplit, et,

@@ -283,12 +283,12 @@ class RTEngine:
             "rjp_ff_scan")
         return sumA, em, tavg
 
-    def time_ff_scan(self, fields, bursts, epochs_s, gff_mode, reps=5):
+    def time_ff_scan(self, fields, bursts, epochs_s, gff_mode, reps=5, want_em=True):
         """Average device time [ms] of one rjp_ff_scan (HIP events on the launch stream)."""
         E = len(epochs_s)
         P = fields.npix
         nx, ny, nz = fields.shape
-        sumA, em, tavg = self._f64(E, P), self._f64(E, P), self._f64(P)
+        sumA, em, tavg = self._f64(E, P), (self._f64(E, P) if want_em else None), self._f64(P)
         wb = self.lib.rjp_ff_scan_workspace(nx, ny, nz, E)
         work = self._workspace(wb)
         fs = fields.struct()
@@ -296,8 +296,8 @@ class RTEngine:
         ms = C.c_double()
         _lib.check(self.lib.rjp_time_ff_scan(
             self.ctx, C.byref(fs), C.byref(bursts) if bursts is not None else None, ep, E,
-            int(gff_mode), sumA.data_ptr(), em.data_ptr(), tavg.data_ptr(), work.data_ptr(),
-            work.numel(), self._stream(), int(reps), C.byref(ms)), self.ctx,
+            int(gff_mode), sumA.data_ptr(), em.data_ptr() if want_em else None, tavg.data_ptr(),
+            work.data_ptr(), work.numel(), self._stream(), int(reps), C.byref(ms)), self.ctx,
             "rjp_time_ff_scan")
         return ms.value
 

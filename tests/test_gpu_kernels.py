@@ -602,3 +602,29 @@ def test_negative_path_factors_keep_the_wide_layout(eng):
     jet.time = 0.9 * orc.YEAR
     np.testing.assert_allclose(em[0], jet.emission_measure(), rtol=1e-11)
     np.testing.assert_allclose(tau[0, 0], jet.optical_depth_ff(5e9), rtol=1e-11)
+
+
+@pytest.mark.parametrize("store", STORES)
+@pytest.mark.parametrize("epochs", [[0.3, 0.9, 1.0, 2.2], list(np.linspace(0.1, 3.1, 8)),
+                                    list(np.linspace(0., 5., 16)),
+                                    [0.2, 0.25, 0.4, 0.8, 1.3, 1.35, 2.0, 2.9, 3.3]])
+def test_scans_without_emission_measure_give_the_same_tau_sums(eng, store, epochs):
+    """Flux-vs-time sweeps pass d_em = NULL and get kernels without the EM accumulators (tiles
+    of 4, 8 and 16 epochs, uniform and not): sumA and T_avg must not change by a bit."""
+    from rajepy_amd import engine as E
+    shape = (5, 70, 32)
+    f = _layout(eng.synth_fields(shape, 31337, 1, _store(store), csize_au=0.5), store)
+    p = copy.deepcopy(U.load_golden("cfg1_example")[2])
+    p["ejection"] = U.example_bursts_params()
+    g = U.synth_host((1, 2, 2), 1, 0)
+    jet = orc.OracleJet.from_fields(dict(p, grid=dict(p["grid"], n_x=1, n_y=2, n_z=2)), g["nd"],
+                                    g["xi"], g["temp"], g["ff"], g["areas"], g["ts"], g["rr"],
+                                    g["vy"])
+    bursts = U.bursts_from_oracle(jet)
+    ep = [y * orc.YEAR for y in epochs]
+    a1, e1, t1 = (x.clone() for x in eng.ff_scan(f, bursts, ep, E.RJP_GFF_POWERLAW))
+    a0, e0, t0 = eng.ff_scan(f, bursts, ep, E.RJP_GFF_POWERLAW, want_em=False)
+    eng.synchronize()
+    assert e0 is None and e1 is not None
+    assert np.array_equal(a0.cpu().numpy(), a1.cpu().numpy())
+    assert np.array_equal(t0.cpu().numpy(), t1.cpu().numpy())

@@ -1,0 +1,46 @@
+#!/usr/bin/env python3
+"""Runs the secondary bench configurations one after another (one process each) and writes
+profiles/<round>_other_configs.md: python tools/other_configs.py r01 [--no-cpu-baseline]"""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+RUNS = [("cfg2", "f64", {}), ("cfg5", "f64", {}), ("cfg3", "f64", {}), ("cfg4", "f32", {}),
+        ("cfg5", "f32", {}), ("cfg4", "f64", {"RJP_NO_COMPACT": "1"}),
+        ("cfg4", "f32", {"RJP_NO_COMPACT": "1"})]
+
+
+def main():
+    tag = sys.argv[1]
+    extra = sys.argv[2:]
+    rows, lines = [], []
+    for cfg, storage, env in RUNS:
+        cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--config", cfg, "--storage",
+               storage, "--steps", "5", "--warmup", "2"] + extra
+        out = subprocess.run(cmd, env=dict(os.environ, **env), capture_output=True, text=True,
+                             timeout=900)
+        line = [l for l in out.stdout.splitlines() if l.startswith("{")]
+        if out.returncode or not line:
+            sys.stderr.write(out.stderr)
+            raise SystemExit("bench %s %s failed" % (cfg, storage))
+        r = json.loads(line[-1])
+        lines.append(line[-1])
+        rf, cb = r["roofline"], r.get("cpu_baseline", {})
+        rows.append("| %s_%s%s | %s | %s | %.3f | %.3e | %s | %.3f | %.0f | %.3f | %s |" % (
+            cfg, storage, "_wide" if env else "", r["config"]["workload"], r["config"]["layout"],
+            r["ms_per_step"], r["value"], rf["kernel"], rf["ms_per_launch"], rf["achieved"],
+            rf["frac"], ("%.2f" % cb["value"]) if cb else "-"))
+        print(rows[-1], flush=True)
+    with open(os.path.join(ROOT, "profiles", tag + "_other_configs_table.md"), "w") as f:
+        f.write("| config | workload | layout | ms/step | Mvoxel-freq/s | dominant kernel | "
+                "ms/launch | alg. GB/s | frac of 8 TB/s | CPU oracle (1 core) Mvoxel-freq/s |\n")
+        f.write("|---|---|---|---|---|---|---|---|---|---|\n")
+        f.write("\n".join(rows) + "\n\n")
+        for l in lines:
+            f.write("```json\n" + l + "\n```\n")
+
+
+if __name__ == "__main__":
+    main()
