@@ -71,6 +71,8 @@ def parse():
                     help="rehearsal only: all ranks use cuda:0")
     ap.add_argument("--cpu-seconds", type=float, default=20.0,
                     help="target CPU time of the bounded cpu_baseline sample")
+    ap.add_argument("--no-cpu-all-cores", action="store_true",
+                    help="skip the one-process-per-core leg of cpu_baseline")
     return ap.parse_args()
 
 
@@ -87,7 +89,7 @@ def _oracle_jet(sub, seed):
     return jet
 
 
-def cpu_baseline(shape, freqs, seed, target_s, rrl=None):
+def cpu_baseline(shape, freqs, seed, target_s, rrl=None, all_cores=True):
     """The CPU oracle (oracle/rt_oracle.py, a literal NumPy restatement of the reference's
     per-channel re-streaming path) timed on a y-truncated block with the same n_x, n_z and a
     subset of the same channels: what Pipeline.execute issues per run -- optical_depth_ff +
@@ -116,10 +118,66 @@ def cpu_baseline(shape, freqs, seed, target_s, rrl=None):
         nyb = int(min(ny, max(nyb + 1, nyb * min(target_s / dt, 64.0))))
     ncell = nx * nyb * nz
     what = "optical_depth_rrl+flux_rrl(contsub=False)" if rrl else "optical_depth_ff+flux_ff"
-    return {"value": ncell * nch / dt / 1e6, "unit": "Mvoxel-freq/s", "cores": 1,
-            "kind": "port",
-            "sample": "oracle %s on a %dx%dx%d y-truncated block of the same synthetic grid x "
-                      "%d of the channels (%.1f s)" % (what, nx, nyb, nz, nch, dt)}
+    out = {"value": ncell * nch / dt / 1e6, "unit": "Mvoxel-freq/s", "cores": 1,
+           "kind": "port",
+           "sample": "oracle %s on a %dx%dx%d y-truncated block of the same synthetic grid x "
+                     "%d of the channels (%.1f s)" % (what, nx, nyb, nz, nch, dt)}
+    if all_cores:
+        out["all_cores"] = cpu_baseline_all_cores((nx, max(2, nyb // 4), nz), sel, seed, rrl)
+    return out
+
+
+_CHILD = """
+import sys, time, json
+sys.path.insert(0, %(root)r)
+import numpy as np
+import bench
+sub, seed, sel, rrl, t_start = %(sub)r, %(seed)r, np.array(%(sel)r), %(rrl)r, %(t_start)r
+jet = bench._oracle_jet(sub, seed)
+ready = time.time()
+time.sleep(max(0.0, t_start - ready))
+if rrl:
+    jet.optical_depth_rrl(rrl, sel); jet.flux_rrl(rrl, sel, contsub=False)
+else:
+    jet.optical_depth_ff(sel); jet.flux_ff(sel)
+print(json.dumps({"late": ready > t_start, "end": time.time() - t_start}))
+"""
+
+
+def cpu_baseline_all_cores(sub, sel, seed, rrl):
+    """The same oracle calls in one process per host core of this job's CPU share, each on its
+    own copy of a (smaller) block, started together: aggregate rate = what a channel-sharded
+    process pool of the reference path would reach on this host."""
+    import subprocess
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    cores = max(1, min(cores, 16))           # one GPU's share of the box
+    t_start = time.time() + 25.0             # children import, build their block, then wait
+    code = _CHILD % {"root": ROOT, "sub": tuple(sub), "seed": seed, "sel": [float(x) for x in sel],
+                     "rrl": rrl, "t_start": t_start}
+    env = dict(os.environ, OMP_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1", MKL_NUM_THREADS="1")
+    procs = [subprocess.Popen([sys.executable, "-c", code], stdout=subprocess.PIPE,
+                              stderr=subprocess.DEVNULL, text=True, env=env)
+             for _ in range(cores)]
+    ends, late = [], False
+    for pr in procs:
+        try:
+            o, _ = pr.communicate(timeout=300)
+            r = json.loads(o.strip().splitlines()[-1])
+            ends.append(r["end"])
+            late |= r["late"]
+        except Exception as exc:                      # a failed child voids the sample
+            for q in procs:
+                q.kill()
+            return {"error": "%s: %s" % (type(exc).__name__, exc)}
+    ncell = sub[0] * sub[1] * sub[2]
+    return {"value": cores * ncell * len(sel) / max(ends) / 1e6, "unit": "Mvoxel-freq/s",
+            "cores": cores, "late_start": late,
+            "sample": "%d processes, each the same calls on its own %dx%dx%d block x %d "
+                      "channels, started together (%.1f s)" % (cores, sub[0], sub[1], sub[2],
+                                                               len(sel), max(ends))}
 
 
 def main():
@@ -322,7 +380,8 @@ def main():
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(shape, freqs, seed, args.cpu_seconds,
-                                              rrl="H66a" if rrl else None)
+                                              rrl="H66a" if rrl else None,
+                                              all_cores=not args.no_cpu_all_cores)
     if rank == 0:
         chk = float(out.sum().item())
         result["checksum_flux_total_jy"] = chk
