@@ -18,7 +18,9 @@ REQUIRED = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step
 def test_bench_prints_one_contract_line(config):
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1",
                           "--steps", "3", "--warmup", "1", "--config", config,
-                          "--cpu-seconds", "0.5"], capture_output=True, text=True, timeout=600)
+                          "--cpu-seconds", "0.5"] +
+                         (["--no-cpu-all-cores"] if config == "tiny_rrl" else []),
+                         capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.strip()]
     assert len(lines) == 1, lines
@@ -37,6 +39,12 @@ def test_bench_prints_one_contract_line(config):
     cb = r["cpu_baseline"]
     assert {"value", "unit", "cores", "kind", "sample"} <= set(cb)
     assert cb["kind"] == "port" and cb["cores"] == 1 and cb["value"] > 0
+    if config == "tiny":          # the one-process-per-core leg
+        ac = cb["all_cores"]
+        assert "error" not in ac, ac
+        assert ac["cores"] >= 1 and ac["value"] > 0 and ac["late_start"] is False
+    else:
+        assert "all_cores" not in cb
 
 
 def test_bench_refuses_mismatched_world_size():
