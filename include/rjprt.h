@@ -131,7 +131,7 @@ int rjp_compact_fields(rjp_ctx* ctx, const rjp_fields* fields, void* d_em0,
 /* Per-sightline occupied y-range of a packed field set: d_ylo[p] = first row, d_yhi[p] = one
  * past the last row whose cell can contribute to any product of the path, i.e. T > 0 (counts
  * in the nanmean of intensity_ff, classes.py:1471) or n, x and ff/areas all non-NaN (emission
- * measure, classes.py:1116-1118); empty sightlines get [ny, 0).  One pass over 4 fields,
+ * measure, classes.py:1116-1118); empty sightlines get [ny, 0).  One pass over 2 (compact layout) or 4 fields,
  * amortised over every later scan of the same model. */
 int rjp_y_bounds(rjp_ctx* ctx, const rjp_fields* fields, int32_t* d_ylo, int32_t* d_yhi,
                  void* stream);

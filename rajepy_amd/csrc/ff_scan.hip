@@ -2,15 +2,16 @@
 //
 // K1 replaces the three y-reductions the reference performs per channel with ~15 full-grid
 // NumPy temporaries each (classes.py:1116-1120, 1375-1432, 1471-1472) by ONE streaming pass
-// over the five device-resident fields: one lane owns VEC adjacent (x,z) sightlines (16 B of
-// every field per load, 1 KiB per wave-instruction, lanes adjacent along the contiguous
-// z-axis), walks y serially with UNROLL rows of loads in flight, evaluates the burst factor
-// chi(t) for a tile of up to 16 epochs in registers and keeps FP64 accumulators.  The y-range is split
-// over gridDim.y so small maps still fill 256 CUs; partial sums go to a workspace and a tiny
-// second kernel reduces them in a fixed order (bitwise reproducible, no atomics).
+// over the device-resident fields (three in the compact layout, five in the wide one): one
+// lane owns VEC adjacent (x,z) sightlines (16 B of every field per load, 1 KiB per
+// wave-instruction, lanes adjacent along the contiguous z-axis), walks y serially with UNROLL
+// rows of loads in flight, evaluates the burst factor chi(t) for a tile of up to 16 epochs in
+// registers and keeps FP64 accumulators.  The y-range is split over gridDim.y so small maps
+// still fill 256 CUs; partial sums go to a workspace and a tiny second kernel reduces them in
+// a fixed order (bitwise reproducible, no atomics).
 // HBM-bound: algorithmic bytes = 5 fields * sizeof(T) per cell per epoch tile in the wide
-// layout, 3 fields * sizeof(T) in the compact layout (rjp_fields.d_em0 = (n x)^2 pf with the jet flag
-// in its sign bit, temp, ts).
+// layout, 3 fields * sizeof(T) in the compact layout (rjp_fields.d_em0 = (n x)^2 pf with the
+// jet flag in its sign bit, temp, ts).
 #include <algorithm>
 #include <cmath>
 
