@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""K1 without bursts (4 fields streamed, no exp): the pure streaming rate of the scan."""
+"""K1 without bursts (no launch times read, no exp): the pure streaming rate of the scan --
+2 fields in the compact layout, 4 in the wide one (RJP_NO_COMPACT=1)."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -13,4 +14,5 @@ fields = eng.synth_fields(shape, 20240504, 0, dtype, csize_au=0.5)
 eng.time_ff_scan(fields, None, [0.0], E.RJP_GFF_SCALAR, reps=2)
 ms = min(eng.time_ff_scan(fields, None, [0.0], E.RJP_GFF_SCALAR, reps=5) for _ in range(3))
 n = shape[0] * shape[1] * shape[2]
-print("%s %s no bursts: %.3f ms  %.0f GB/s (4 fields)" % (cfg, storage, ms, 4 * n * int(dtype) / ms / 1e6))
+nf = 2 if fields.em0 is not None else 4
+print("%s %s no bursts: %.3f ms  %.0f GB/s (%d fields)" % (cfg, storage, ms, nf * n * int(dtype) / ms / 1e6, nf))
