@@ -3,7 +3,8 @@ RRL).  The oracle cannot run a billion cells, so parity is checked (a) EXACTLY o
 sample of sightlines -- sightlines are independent, so the sampled columns are regenerated on
 the host from the counter hash, stacked as a (k, n_y, 1) grid and run through the oracle --
 and (b) through size-independent properties: an 8-epoch fused pass equals eight single-epoch
-passes bit for bit, the on-device flux-vs-time reduction equals the sum of the flux cube."""
+passes bit for bit, the compact scan layout equals the wide one bit for bit, the on-device
+flux-vs-time reduction equals the sum of the flux cube."""
 import copy
 
 import numpy as np
@@ -61,6 +62,20 @@ def test_cfg4_continuum_full_size(eng, dtype, tol):
         s1, e1, _ = eng.ff_scan(fields, bursts, [ep[e]], E.RJP_GFF_SCALAR)
         eng.synchronize()
         assert bool((s1[0] == sumA8[e]).all()) and bool((e1[0] == em8[e]).all())
+
+    # (b1') the compact 3-field layout == the wide 5-field layout over all 1.07e9 cells: bit
+    # for bit in f64, to the extra float rounding of the product in f32
+    assert fields.em0 is not None
+    em0, fields.em0 = fields.em0, None
+    sw, ew, tw = eng.ff_scan(fields, bursts, ep[:2], E.RJP_GFF_SCALAR)
+    eng.synchronize()
+    fields.em0 = em0
+    if dtype == 8:
+        assert bool((sw == sumA8[:2]).all()) and bool((ew == em8[:2]).all())
+    else:
+        assert float(((sw - sumA8[:2]).abs() / sumA8[:2]).max().item()) < 2e-7
+    assert bool((tw == tavg).all())
+    del sw, ew, tw
 
     # (b2) device flux-vs-time reduction == sum of the flux cube
     tau, flux, ftot = eng.ff_maps(sumA8[:2].contiguous(), tavg, ctau, cflux)
