@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define RJP_VERSION 101          /* 0.1.1 */
+#define RJP_VERSION 102          /* 0.1.2 */
 #define RJP_MAX_BURSTS 8         /* per jet (red / blue) */
 #define RJP_MAX_EPOCH_TILE 16    /* most epochs evaluated per grid pass (uniformly spaced, f64 lanes; else 8) */
 
@@ -223,26 +223,31 @@ typedef struct rjp_geometry {
   int32_t ix0, nx_total;
 } rjp_geometry;
 
-/* d_vy / d_ts may be NULL to skip them; d_ff_raw / d_areas_raw (float64, optional) receive
+/* Any output may be NULL to skip it (d_vy / d_ts typically); d_ff_raw / d_areas_raw (float64, optional) receive
  * the un-packed fill factors / areas that JetModel.save pickles (classes.py:1704-1709);
  * d_vx_raw / d_vz_raw (float64, optional) the transverse components of JetModel.vel.
  * Launch times: closed form for q^d_v = 0, otherwise Gauss' 2F1(a, b; b+1; -A) of
  * maths/geometry.py:166-171 evaluated on the device (Pfaff + 1/z connection formula);
- * RJP_ERR_ARG if a-b or b is a non-positive integer (logarithmic cases) and d_ts != NULL. */
+ * RJP_ERR_ARG if a-b or b is a non-positive integer (logarithmic cases) and d_ts != NULL.
+ * d_em0 (optional, RJP_F64 only): the compact scan field of rjp_fields.d_em0 written in the
+ * same pass, bit-identical to what rjp_compact_fields derives from nd, xi, pf -- with d_nd,
+ * d_xi, d_pf NULL a continuum-only model occupies 24 B/cell (12e9 cells per 288 GB GPU). */
 int rjp_build_fields(rjp_ctx* ctx, const rjp_geometry* geom, int dtype,
                      void* d_nd, void* d_xi, void* d_temp, void* d_pf, void* d_ts,
                      void* d_vy, double* d_ff_raw, double* d_areas_raw,
-                     double* d_vx_raw, double* d_vz_raw, void* stream);
+                     double* d_vx_raw, double* d_vz_raw, void* d_em0, void* stream);
 
 /* ---- measurement harness: synthetic dense fields ---------------------
  * Counter-based: u = splitmix64(seed ^ field_id<<60 ^ linear_cell_index) -> [0,1).
  *   n = 10^(5+2.5u), x = 0.05+0.45u, T = 1e4 (temp_mode 0) or 5e3+1.5e4u (temp_mode 1),
  *   pf = 0.5 w.p. 0.25 else 1, ts = 5u yr, red = i_z < n_z/2, vy = 6.2+60(u-0.5) km/s.
  * Generates cells [cell0, cell0+n) of the flattened grid so a host restatement can
- * regenerate any sub-block. */
+ * regenerate any sub-block.  Any output may be NULL; d_em0 (optional, RJP_F64 only) receives
+ * the compact scan field of the same cells, as for rjp_build_fields. */
 int rjp_synth_fields(rjp_ctx* ctx, uint64_t seed, int32_t temp_mode, int32_t nz,
                      int64_t cell0, int64_t n, int dtype, void* d_nd, void* d_xi,
-                     void* d_temp, void* d_pf, void* d_ts, void* d_vy, void* stream);
+                     void* d_temp, void* d_pf, void* d_ts, void* d_vy, void* d_em0,
+                     void* stream);
 
 /* Device-time probe used by bench.py: average duration [ms] of `reps` back-to-back
  * rjp_ff_scan launches measured with HIP events on `stream`. */

@@ -86,9 +86,9 @@ SIGNATURES = {
     "rjp_rrl_maps": (C.c_int, [_P, _P, _P, _P, _P, C.c_int64, _DP, _DP, C.c_int32,
                                _P, _P, _P, C.c_size_t, _P]),
     "rjp_build_fields": (C.c_int, [_P, C.POINTER(Geometry), C.c_int, _P, _P, _P, _P, _P,
-                                   _P, _P, _P, _P, _P, _P]),
+                                   _P, _P, _P, _P, _P, _P, _P]),
     "rjp_synth_fields": (C.c_int, [_P, C.c_uint64, C.c_int32, C.c_int32, C.c_int64,
-                                   C.c_int64, C.c_int, _P, _P, _P, _P, _P, _P, _P]),
+                                   C.c_int64, C.c_int, _P, _P, _P, _P, _P, _P, _P, _P]),
     "rjp_time_ff_scan": (C.c_int, [_P, C.POINTER(Fields), C.POINTER(Bursts), _DP,
                                    C.c_int32, C.c_int32, _P, _P, _P, _P, C.c_size_t, _P,
                                    C.c_int32, _DP]),
@@ -115,7 +115,7 @@ def load():
         fn = getattr(lib, name)          # AttributeError if a declared symbol is missing
         fn.restype = res
         fn.argtypes = args
-    if lib.rjp_version() < 101:
+    if lib.rjp_version() < 102:
         raise RjprtError("librjprt.so is older than this binding")
     _lib = lib
     return lib

@@ -100,7 +100,7 @@ hipError_t compact_fields_launch(const rjp_fields* fl, void* d_em0, int64_t* d_n
 template <typename T>
 __global__ __launch_bounds__(kFB) void synth_kernel(uint64_t seed, int temp_mode, int nz,
                                                     int64_t cell0, int64_t n, T* nd, T* xi,
-                                                    T* temp, T* pf, T* ts, T* vy) {
+                                                    T* temp, T* pf, T* ts, T* vy, T* em0) {
   int64_t i = (int64_t)blockIdx.x * kFB + threadIdx.x;
   const int64_t step = (int64_t)gridDim.x * kFB;
   for (; i < n; i += step) {
@@ -115,6 +115,10 @@ __global__ __launch_bounds__(kFB) void synth_kernel(uint64_t seed, int temp_mode
     if (xi) xi[i] = (T)(0.05 + 0.45 * ux);
     if (temp) temp[i] = (T)(temp_mode == 0 ? 1e4 : 5e3 + 1.5e4 * ut);
     if (pf) pf[i] = (T)(up < 0.25 ? 0.5 : 1.0);
+    if (em0) {     // the compact scan field straight from the generator (f64): as compact_fields_kernel
+      const double e0 = n0 * (0.05 + 0.45 * ux);
+      em0[i] = (T)with_sign(e0 * e0 * (up < 0.25 ? 0.5 : 1.0), red);
+    }
     if (ts) ts[i] = (T)(5.0 * us * 31536000.0);
     if (vy) vy[i] = (T)(6.2 + 60.0 * (uv - 0.5));
   }
@@ -122,16 +126,16 @@ __global__ __launch_bounds__(kFB) void synth_kernel(uint64_t seed, int temp_mode
 
 hipError_t synth_launch(uint64_t seed, int temp_mode, int nz, int64_t cell0, int64_t n,
                         int dtype, void* nd, void* xi, void* temp, void* pf, void* ts, void* vy,
-                        hipStream_t st) {
+                        void* em0, hipStream_t st) {
   const unsigned blocks = (unsigned)std::min<int64_t>((n + kFB - 1) / kFB, 256 * 32);
   if (dtype == RJP_F64)
     hipLaunchKernelGGL(synth_kernel<double>, dim3(blocks), dim3(kFB), 0, st, seed, temp_mode, nz,
                        cell0, n, (double*)nd, (double*)xi, (double*)temp, (double*)pf,
-                       (double*)ts, (double*)vy);
+                       (double*)ts, (double*)vy, (double*)em0);
   else
     hipLaunchKernelGGL(synth_kernel<float>, dim3(blocks), dim3(kFB), 0, st, seed, temp_mode, nz,
                        cell0, n, (float*)nd, (float*)xi, (float*)temp, (float*)pf, (float*)ts,
-                       (float*)vy);
+                       (float*)vy, (float*)em0);
   return hipGetLastError();
 }
 
@@ -222,7 +226,8 @@ template <typename T>
 __global__ __launch_bounds__(kFB) void build_fields_kernel(GeomDev g, T* nd, T* xi, T* temp,
                                                            T* pf, T* ts, T* vy,
                                                            double* ff_raw, double* areas_raw,
-                                                           double* vx_raw, double* vz_raw) {
+                                                           double* vx_raw, double* vz_raw,
+                                                           T* em0) {
   const int64_t n = (int64_t)g.nx * g.ny * g.nz;
   const int64_t i = (int64_t)blockIdx.x * kFB + threadIdx.x;
   if (i >= n) return;
@@ -261,10 +266,14 @@ __global__ __launch_bounds__(kFB) void build_fields_kernel(GeomDev g, T* nd, T* 
   const double reff = g.R_1 + ((g.R_2 - g.R_1) * ww) / (g.w_0 * pow(rho_mod(g, ar_), g.eps));
   const double rho_c = rho_mod(g, rc);
 
-  if (nd) {
+  if (nd || em0) {
     double v = jet ? powerlaw(g.n_0, rho_c, reff, g.R_1, g.q_n, g.qd_n) : nan;
     if (rr < 0) v = v * g.rb_frac;                                 // classes.py:895
-    nd[i] = (T)with_sign(v, rr < 0);
+    if (nd) nd[i] = (T)with_sign(v, rr < 0);
+    if (em0) {     // the compact scan field straight from the builder (f64): as compact_fields_kernel
+      const double n0 = fabs(v) * (jet ? powerlaw(g.x_0, rho_c, reff, g.R_1, g.q_x, g.qd_x) : nan);
+      em0[i] = (T)with_sign(n0 * n0 * (ff / ar), rr < 0);
+    }
   }
   if (xi) xi[i] = (T)(jet ? powerlaw(g.x_0, rho_c, reff, g.R_1, g.q_x, g.qd_x) : nan);
   if (temp) {

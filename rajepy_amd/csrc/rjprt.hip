@@ -351,12 +351,16 @@ int rjp_rrl_maps(rjp_ctx* ctx, const double* d_tau_rrl, const double* d_tau_ff,
 
 int rjp_build_fields(rjp_ctx* ctx, const rjp_geometry* gm, int dtype, void* d_nd, void* d_xi,
                      void* d_temp, void* d_pf, void* d_ts, void* d_vy, double* d_ff_raw,
-                     double* d_areas_raw, double* d_vx_raw, double* d_vz_raw, void* stream) {
+                     double* d_areas_raw, double* d_vx_raw, double* d_vz_raw, void* d_em0,
+                     void* stream) {
   if (int r = bind(ctx)) return r;
   if (!gm) return fail(ctx, RJP_ERR_ARG, "geometry is NULL");
   if (dtype != RJP_F32 && dtype != RJP_F64) return fail(ctx, RJP_ERR_ARG, "bad dtype tag");
   if (gm->nx <= 0 || gm->ny <= 0 || gm->nz <= 0 || !(gm->csize > 0))
     return fail(ctx, RJP_ERR_ARG, "bad grid in geometry");
+  if (d_em0 && dtype != RJP_F64)
+    return fail(ctx, RJP_ERR_ARG, "rjp_build_fields: d_em0 is written for RJP_F64 storage only "
+                                  "(float storage goes through rjp_compact_fields' range check)");
   const double au = 149597870700.0, d2r = M_PI / 180.0;
   rjp::GeomDev g;
   g.nx = gm->nx; g.ny = gm->ny; g.nz = gm->nz; g.ccw = gm->rotation_ccw;
@@ -411,23 +415,26 @@ int rjp_build_fields(rjp_ctx* ctx, const rjp_geometry* gm, int dtype, void* d_nd
   if (dtype == RJP_F64)
     hipLaunchKernelGGL(rjp::build_fields_kernel<double>, dim3(blocks), dim3(rjp::kFB), 0, st, g,
                        (double*)d_nd, (double*)d_xi, (double*)d_temp, (double*)d_pf,
-                       (double*)d_ts, (double*)d_vy, d_ff_raw, d_areas_raw, d_vx_raw, d_vz_raw);
+                       (double*)d_ts, (double*)d_vy, d_ff_raw, d_areas_raw, d_vx_raw, d_vz_raw,
+                       (double*)d_em0);
   else
     hipLaunchKernelGGL(rjp::build_fields_kernel<float>, dim3(blocks), dim3(rjp::kFB), 0, st, g,
                        (float*)d_nd, (float*)d_xi, (float*)d_temp, (float*)d_pf, (float*)d_ts,
-                       (float*)d_vy, d_ff_raw, d_areas_raw, d_vx_raw, d_vz_raw);
+                       (float*)d_vy, d_ff_raw, d_areas_raw, d_vx_raw, d_vz_raw, (float*)nullptr);
   RJP_HIP(ctx, hipGetLastError());
   return RJP_OK;
 }
 
 int rjp_synth_fields(rjp_ctx* ctx, uint64_t seed, int32_t temp_mode, int32_t nz, int64_t cell0,
                      int64_t n, int dtype, void* d_nd, void* d_xi, void* d_temp, void* d_pf,
-                     void* d_ts, void* d_vy, void* stream) {
+                     void* d_ts, void* d_vy, void* d_em0, void* stream) {
   if (int r = bind(ctx)) return r;
   if (n <= 0 || nz <= 0 || cell0 < 0) return fail(ctx, RJP_ERR_ARG, "rjp_synth_fields: bad range");
   if (dtype != RJP_F32 && dtype != RJP_F64) return fail(ctx, RJP_ERR_ARG, "bad dtype tag");
+  if (d_em0 && dtype != RJP_F64)
+    return fail(ctx, RJP_ERR_ARG, "rjp_synth_fields: d_em0 is written for RJP_F64 storage only");
   RJP_HIP(ctx, rjp::synth_launch(seed, temp_mode, nz, cell0, n, dtype, d_nd, d_xi, d_temp, d_pf,
-                                 d_ts, d_vy, (hipStream_t)stream));
+                                 d_ts, d_vy, d_em0, (hipStream_t)stream));
   return RJP_OK;
 }
 

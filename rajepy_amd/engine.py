@@ -221,44 +221,67 @@ class RTEngine:
         if fields.ylo is not None and name in ("xi", "temp"):
             self.compute_y_bounds(fields)       # the occupied range depends on these fields
 
+    def _direct_em0(self, n, dtype):
+        """f64 producers write the compact scan field in their own pass (f32 goes through
+        rjp_compact_fields and its range check)."""
+        if dtype != RJP_F64 or os.environ.get("RJP_NO_COMPACT"):
+            return None
+        return self._f64(n)
+
     def build_fields(self, geom, dtype=RJP_F64, want_ts=True, want_vy=True, want_raw=True,
-                     want_vxz=False):
-        """K4: geometry -> packed fields on the device (`geom` is a _lib.Geometry)."""
+                     want_vxz=False, want_wide=True):
+        """K4: geometry -> packed fields on the device (`geom` is a _lib.Geometry).
+        `want_wide=False` (f64, continuum only) skips nd / xi / pf: 24 B/cell resident."""
         n = geom.nx * geom.ny * geom.nz
-        nd, xi, temp, pf = (self._empty(n, dtype) for _ in range(4))
+        em0 = self._direct_em0(n, dtype)
+        if not want_wide and em0 is None:
+            raise ValueError("want_wide=False needs the compact layout (f64 storage)")
+        nd, xi, pf = ((self._empty(n, dtype) for _ in range(3)) if want_wide
+                      else (None, None, None))
+        temp = self._empty(n, dtype)
         ts = self._empty(n, dtype) if want_ts else None
         vy = self._empty(n, dtype) if want_vy else None
         ffr = self._f64(n) if want_raw else None
         arr = self._f64(n) if want_raw else None
         vxr = self._f64(n) if want_vxz else None
         vzr = self._f64(n) if want_vxz else None
+        ptr = lambda t: t.data_ptr() if t is not None else None
         _lib.check(self.lib.rjp_build_fields(
-            self.ctx, C.byref(geom), dtype, nd.data_ptr(), xi.data_ptr(), temp.data_ptr(),
-            pf.data_ptr(), ts.data_ptr() if want_ts else None,
-            vy.data_ptr() if want_vy else None, ffr.data_ptr() if want_raw else None,
-            arr.data_ptr() if want_raw else None, vxr.data_ptr() if want_vxz else None,
-            vzr.data_ptr() if want_vxz else None, self._stream()), self.ctx,
-            "rjp_build_fields")
+            self.ctx, C.byref(geom), dtype, ptr(nd), ptr(xi), temp.data_ptr(), ptr(pf), ptr(ts),
+            ptr(vy), ptr(ffr), ptr(arr), ptr(vxr), ptr(vzr), ptr(em0), self._stream()),
+            self.ctx, "rjp_build_fields")
         out = DeviceFields((geom.nx, geom.ny, geom.nz), dtype, geom.csize, nd, xi, temp, pf,
                            ts, vy, ffr, arr)
         out.vx_raw, out.vz_raw = vxr, vzr
+        if em0 is not None:
+            out.em0 = em0
+            return out
         return self.compact(out)
 
     def synth_fields(self, shape, seed, temp_mode=0, dtype=RJP_F64, csize_au=0.5,
-                     with_vy=False, cell0=0):
+                     with_vy=False, cell0=0, wide=True):
         """Measurement harness: dense synthetic fields generated on the device
         (SURVEY.md 8(d)); `shape` may be a sub-block starting at flat cell `cell0` of a
-        grid whose z-extent is shape[2]."""
+        grid whose z-extent is shape[2].  `wide=False` (f64) generates only the compact scan
+        layout (em0, temp, ts): 24 B/cell."""
         nx, ny, nz = shape
         n = nx * ny * nz
-        nd, xi, temp, pf, ts = (self._empty(n, dtype) for _ in range(5))
+        em0 = self._direct_em0(n, dtype)
+        if not wide and em0 is None:
+            raise ValueError("wide=False needs the compact layout (f64 storage)")
+        nd, xi, pf = ((self._empty(n, dtype) for _ in range(3)) if wide else (None, None, None))
+        temp, ts = self._empty(n, dtype), self._empty(n, dtype)
         vy = self._empty(n, dtype) if with_vy else None
+        ptr = lambda t: t.data_ptr() if t is not None else None
         _lib.check(self.lib.rjp_synth_fields(
             self.ctx, int(seed), int(temp_mode), int(nz), int(cell0), int(n), dtype,
-            nd.data_ptr(), xi.data_ptr(), temp.data_ptr(), pf.data_ptr(), ts.data_ptr(),
-            vy.data_ptr() if with_vy else None, self._stream()), self.ctx,
-            "rjp_synth_fields")
-        return self.compact(DeviceFields(shape, dtype, csize_au, nd, xi, temp, pf, ts, vy))
+            ptr(nd), ptr(xi), temp.data_ptr(), ptr(pf), ts.data_ptr(), ptr(vy), ptr(em0),
+            self._stream()), self.ctx, "rjp_synth_fields")
+        out = DeviceFields(shape, dtype, csize_au, nd, xi, temp, pf, ts, vy)
+        if em0 is not None:
+            out.em0 = em0
+            return out
+        return self.compact(out)
 
     # -- K1 / K2 -----------------------------------------------------------------------------
     def ff_scan(self, fields, bursts, epochs_s, gff_mode, want_em=True, out=None):

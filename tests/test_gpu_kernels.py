@@ -628,3 +628,45 @@ def test_scans_without_emission_measure_give_the_same_tau_sums(eng, store, epoch
     assert e0 is None and e1 is not None
     assert np.array_equal(a0.cpu().numpy(), a1.cpu().numpy())
     assert np.array_equal(t0.cpu().numpy(), t1.cpu().numpy())
+
+
+@pytest.mark.parametrize("producer", ["synth0", "synth1", "cfg1_example", "tilted"])
+def test_producers_write_the_compact_field_themselves(eng, producer):
+    """f64 producers (the synthetic generator and K4) emit em0 in their own pass: it must be
+    bit-identical to what rjp_compact_fields derives from their nd, xi, pf, and a model
+    generated WITHOUT the wide fields (24 B/cell resident) must scan to the same maps."""
+    import torch
+    from rajepy_amd import engine as E
+    from rajepy_amd._lib import RjprtError
+    from rajepy_amd.classes import geometry_struct
+    if producer.startswith("synth"):
+        shape, tm = (6, 40, 32), int(producer[-1])
+        make = lambda wide: eng.synth_fields(shape, 4711, tm, 8, csize_au=0.5, wide=wide)
+        mode = E.RJP_GFF_SCALAR if tm == 0 else E.RJP_GFF_POWERLAW
+    else:
+        z, meta, p = U.load_golden(producer)
+        jet = orc.OracleJet(p)
+        geom = geometry_struct(jet.params, jet.nx, jet.ny, jet.nz)
+        make = lambda wide: eng.build_fields(geom, 8, want_ts=True, want_vy=False,
+                                             want_raw=False, want_wide=wide)
+        mode = E.RJP_GFF_SCALAR if p["power_laws"]["q_T"] == 0. else E.RJP_GFF_POWERLAW
+    f = make(True)
+    direct = f.em0.clone()
+    eng.compact(f)
+    eng.synchronize()
+    same = (direct.view(torch.int64) == f.em0.view(torch.int64))
+    assert bool(same.all())
+    ep = [0.4 * orc.YEAR, 1.1 * orc.YEAR]
+    bursts = E.make_bursts([(0.5 * orc.YEAR, 4., 2e6)], [(1.0 * orc.YEAR, 1.5, 6e6)])
+    ref = [t.clone() for t in eng.ff_scan(f, bursts, ep, mode)]
+    lean = make(False)
+    assert lean.nd is None and lean.xi is None and lean.pf is None and lean.em0 is not None
+    eng.compute_y_bounds(lean)
+    got = eng.ff_scan(lean, bursts, ep, mode)
+    eng.synchronize()
+    for a, b in zip(got, ref):
+        assert torch.equal(torch.nan_to_num(a, nan=-1.0), torch.nan_to_num(b, nan=-1.0))
+    with pytest.raises(RjprtError, match="nd/xi/temp/pf"):
+        eng.ff_cells(lean, bursts, ep[0], mode, [1.0])
+    with pytest.raises(ValueError, match="compact layout"):
+        eng.synth_fields((2, 4, 4), 1, 0, 4, wide=False)

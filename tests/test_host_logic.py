@@ -45,7 +45,7 @@ def test_abi_exports_every_declared_symbol():
     declared = set(re.findall(r"\b(rjp_[a-z0-9_]+)\s*\(", hdr))
     assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
     lib = _lib.load()                       # raises if the .so or any symbol is missing
-    assert lib.rjp_version() == 101
+    assert lib.rjp_version() == 102
     for name in declared:
         assert hasattr(lib, name)
 
