@@ -38,6 +38,8 @@ CONFIGS = {
     "cfg2": ((256, 1024, 256), 32, None, "continuum"),
     "cfg5": ((512, 4096, 512), 64, 32, "continuum"),      # 64 ch x 32 epochs, epoch-fused passes
     "cfg3": ((512, 2048, 512), 256, None, "rrl"),         # H66a cube, LTE
+    # capacity line: 8x the cells of cfg4 on ONE GPU, compact layout only (206 GB of the 288)
+    "cfg4x8": ((1024, 8192, 1024), 256, None, "continuum"),
     "tiny": ((16, 64, 64), 8, None, "continuum"),
     "tiny_rrl": ((8, 64, 64), 40, None, "rrl"),
 }
@@ -225,7 +227,9 @@ def main():
     P = lshape[0] * lshape[2]
     ncell_loc = lshape[0] * lshape[1] * lshape[2]
 
-    fields = eng.synth_fields(lshape, seed, 0, dtype, csize_au=0.5, with_vy=rrl, cell0=cell0)
+    lean = args.config == "cfg4x8"            # generate em0, temp, ts only (24 B/cell)
+    fields = eng.synth_fields(lshape, seed, 0, dtype, csize_au=0.5, with_vy=rrl, cell0=cell0,
+                              wide=not lean)
     ej = EXAMPLE_BURSTS
     red, blue = [], []
     for t0, hl, chi, which in zip(ej["t_0"], ej["hl"], ej["chi"], ej["which"]):
