@@ -21,11 +21,13 @@ constexpr int kRB = 256;     // threads per workgroup
 
 // ---- Faddeeva: Re w(x + i y), y > 0 ----------------------------------------------------
 // Core: trapezoidal rule with step h on w(z) = (i/pi) Int exp(-t^2)/(z-t) dt plus the residue
-// ("pole") correction for y < pi/h (Matta & Reichel 1971; Hunter & Regan 1972).  The node
-// lattice is shifted by h/2 whenever x is within h/4 of a node, so the pole term and the sum
-// never cancel.  Nodes are paired (+t,-t) to halve the divisions.  With h = 0.6 and 10 pairs
-// the relative error of Re w is < 1e-11 for 1e-10 <= y <= 1e3, 0 <= x <= 1e4 (measured
-// against scipy.special.wofz, which the reference calls).
+// ("pole") correction for y < pi/h (Matta & Reichel 1971; Hunter & Regan 1972).
+//  * y >= 0.03: plain lattice t = n h, nodes paired (+t,-t) to halve the divisions;
+//  * y < 0.03, where sum and pole term of the plain lattice would cancel near a node:
+//    - kernels whose waves work on one cell: lattice centred on x (voigt_centred below);
+//    - otherwise: lattice shifted by h/2 whenever x is within h/4 of a node.
+// With h = 0.6 the relative error of Re w is < 1e-11 for 1e-10 <= y <= 1e3, 0 <= x <= 1e4
+// (measured against scipy.special.wofz, which the reference calls).
 // Far field (|z|^2 > 64 and (x^2 > 64 or y > 1)): 6-term Laplace continued fraction,
 // relative error < 3e-10 there.
 constexpr double kH = 0.6;
@@ -146,27 +148,135 @@ __device__ __attribute__((noinline)) double pole_term_plain(double ax, double y,
   return 2.0 * exp_any(e) * q * num * rcp_fast(den);
 }
 
+// ---- small y, one cell per wave: lattice centred on x ------------------------------------
+// Nodes t_k = x + (k + 1/2) h: x always sits midway between two nodes, so
+//   Re w = (h y / pi) sum_k exp(-t_k^2) / ((k + 1/2)^2 h^2 + y^2)
+//          + 2 exp(y^2 - x^2) cos(2 x y) / (1 + exp(2 pi y / h))
+// holds for every y > 0 with no cancellation between the sum and the pole term (its
+// denominator 1 - exp(-2 pi i (z - t_0)/h) is the REAL number 1 + exp(2 pi y/h)).  The
+// denominators depend on the cell only (y is the same in every lane): the wave keeps
+// 1/((k+1/2)^2 h^2 + y^2) in a 64-entry LDS table, one entry per lane.  The Gaussian weights
+// of a lane follow a recurrence outward from the node nearest t = 0 (|t_m| <= h/2):
+// E_{j+1} = E_j R_j, R_{j+1} = R_j exp(-2 h^2) -- two short polynomials instead of 21 exp.
+// Relative error < 3e-12 for 1e-10 <= y < 0.03, 0 <= x <= 16 (against scipy.special.wofz).
+// The centred lattice is valid for every y (the parity tests pass with any bound); it is USED
+// below y = 0.03, where the plain lattice would cancel: above, the paired plain lattice is
+// cheaper (cfg3: 775 ms with the bound at 0.03, 815 at 0.1, 880 at 0.3, 970 at 1.0).
+constexpr double kCenYMax = 0.03;
+constexpr int kCenJ = 10;            // nodes on each side of the middle one
+constexpr int kCenOff = 38;          // table index of k = 0; window [km-10, km+10], km >= -27
+constexpr double kCenXMax = 16.0;    // beyond: continued fraction (the table ends)
+
+__device__ __forceinline__ void wave_lds_fence() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// w = (i/sqrt(pi)) / (z - (1/2)/(z - 1/(z - (3/2)/(z - 2/(z - (5/2)/(z - 3/z))))))
+__device__ __forceinline__ double voigt_far(double ax, double y) {
+  double wr = ax, wi = y;
+#pragma unroll
+  for (int k = 6; k >= 1; --k) {
+    const double s = (0.5 * k) * rcp_fast(__builtin_fma(wr, wr, wi * wi));
+    wr = __builtin_fma(-s, wr, ax);
+    wi = __builtin_fma(s, wi, y);
+  }
+  return 0.56418958354775628695 * wi * rcp_fast(__builtin_fma(wr, wr, wi * wi));
+}
+
+__device__ __forceinline__ double voigt_centred(double ax, double y, double q, double cq,
+                                                double* tab) {
+  // per-cell table, written by the 64 lanes of this wave (all of them are here: y is
+  // wave-uniform and so is the branch that leads here)
+  {
+    const int lane = threadIdx.x & (RJP_WAVE - 1);
+    const double a = ((double)(lane - kCenOff) + 0.5) * kH;
+    wave_lds_fence();                       // earlier readers of the previous cell's table
+    tab[lane] = rcp_fast(__builtin_fma(a, a, y * y));
+    wave_lds_fence();
+  }
+  const double axc = fmin(ax, kCenXMax);
+  const double km = __builtin_rint(__builtin_fma(axc, -1.0 / kH, -0.5));
+  const double tm = __builtin_fma(km + 0.5, kH, axc);          // |tm| <= h/2
+  const double w = tm * tm;                                     // <= 0.09
+  double em = -1.0 / 5040.0;                                    // exp(-w), degree 7
+  em = __builtin_fma(em, w, 1.0 / 720.0);
+  em = __builtin_fma(em, w, -1.0 / 120.0);
+  em = __builtin_fma(em, w, 1.0 / 24.0);
+  em = __builtin_fma(em, w, -1.0 / 6.0);
+  em = __builtin_fma(em, w, 0.5);
+  em = __builtin_fma(em, w, -1.0);
+  em = __builtin_fma(em, w, 1.0);
+  const double v = (-2.0 * kH) * tm;                            // |v| <= 0.36
+  double u = 2.505210838544172e-08;                             // exp(v), degree 11
+  u = __builtin_fma(u, v, 2.755731922398589e-07);
+  u = __builtin_fma(u, v, 2.7557319223985893e-06);
+  u = __builtin_fma(u, v, 2.48015873015873e-05);
+  u = __builtin_fma(u, v, 1.984126984126984e-04);
+  u = __builtin_fma(u, v, 1.388888888888889e-03);
+  u = __builtin_fma(u, v, 8.333333333333333e-03);
+  u = __builtin_fma(u, v, 4.1666666666666664e-02);
+  u = __builtin_fma(u, v, 1.6666666666666666e-01);
+  u = __builtin_fma(u, v, 0.5);
+  u = __builtin_fma(u, v, 1.0);
+  u = __builtin_fma(u, v, 1.0);
+  constexpr double kC1 = 0.69767632607103103;                   // exp(-h^2)
+  constexpr double kQ = 0.48675225595997168;                    // exp(-2 h^2)
+  const double* t = tab + ((int)km + kCenOff);
+  double s = em * t[0];
+  double e = em, r = kC1 * u;                                   // towards +t
+#pragma unroll
+  for (int j = 1; j <= kCenJ; ++j) {
+    e *= r; r *= kQ;
+    s = __builtin_fma(e, t[j], s);
+  }
+  e = em; r = kC1 * rcp_fast(u);                                // towards -t
+#pragma unroll
+  for (int j = 1; j <= kCenJ; ++j) {
+    e *= r; r *= kQ;
+    s = __builtin_fma(e, t[-j], s);
+  }
+  s *= y * (kH / 3.14159265358979323846);
+  // pole term: below 1e-13 Re w once x^2 exceeds the per-cell bound cq; skipped when no lane
+  // of the wave needs it
+  if (__builtin_amdgcn_ballot_w64(ax * ax < cq) != 0) {
+    const double th = 2.0 * ax * y, t2 = th * th;               // < 1 wherever the term matters
+    double c = 1.0 / 479001600.0;                               // cos(th), degree 12
+    c = __builtin_fma(c, t2, -1.0 / 3628800.0);
+    c = __builtin_fma(c, t2, 1.0 / 40320.0);
+    c = __builtin_fma(c, t2, -1.0 / 720.0);
+    c = __builtin_fma(c, t2, 1.0 / 24.0);
+    c = __builtin_fma(c, t2, -0.5);
+    c = __builtin_fma(c, t2, 1.0);
+    const double g = exp_nonpos(__builtin_fma(-ax, ax, y * y));
+    const double p = 2.0 * g * c * q * rcp_fast(1.0 + q);       // y < 0.03 < pi/h: q > 0
+    s += (ax * ax < cq) ? p : 0.0;
+  }
+  if (__builtin_amdgcn_ballot_w64(ax > kCenXMax) != 0) {
+    const double vf = voigt_far(ax, y);
+    s = ax > kCenXMax ? vf : s;
+  }
+  return s;
+}
+
 // Re w(x + i y) for one lane (x = ax >= 0 per lane, y > 0 THE SAME IN EVERY LANE: a wave
 // works on one cell).  Per-cell constants: q = exp(-2 pi y / h) (or -1 when y >= pi/h: no
 // pole term), omq = 1 - q (from expm1), cq = x^2 below which the pole term matters.
+// `tab` = this wave's 64-entry LDS table when every lane of the wave works on the same cell
+// (kernels with >= 64 channel lanes), else nullptr (CEN = false).
+template <bool CEN>
 __device__ __forceinline__ double voigt_rew(double ax, double y, double q, double omq,
-                                            double cq) {
+                                            double cq, double* tab) {
   const double r2 = __builtin_fma(ax, ax, y * y);
   // the far-field branch is taken only when EVERY active lane qualifies: the core formula is
   // valid everywhere, so a wave that straddles the boundary runs one path, not both
   const bool far = r2 > 64.0 && (ax * ax > 64.0 || y > 1.0);
-  if (__builtin_amdgcn_ballot_w64(!far) == 0) {
-    // w = (i/sqrt(pi)) / (z - (1/2)/(z - 1/(z - (3/2)/(z - 2/(z - (5/2)/(z - 3/z))))))
-    double wr = ax, wi = y;
-#pragma unroll
-    for (int k = 6; k >= 1; --k) {
-      const double s = (0.5 * k) * rcp_fast(__builtin_fma(wr, wr, wi * wi));
-      wr = __builtin_fma(-s, wr, ax);
-      wi = __builtin_fma(s, wi, y);
-    }
-    return 0.56418958354775628695 * wi * rcp_fast(__builtin_fma(wr, wr, wi * wi));
+  if (__builtin_amdgcn_ballot_w64(!far) == 0) return voigt_far(ax, y);
+  if (y < kCenYMax) {
+    if constexpr (CEN) return voigt_centred(ax, y, q, cq, tab);
+    else return voigt_core_shifted(ax, y, q, -2.0 * (3.14159265358979323846 / kH) * y);
   }
-  if (y < 0.03) return voigt_core_shifted(ax, y, q, -2.0 * (3.14159265358979323846 / kH) * y);
 
   // Plain lattice t = n h.  Pair (+t,-t):
   //   c [1/((x-t)^2+y^2) + 1/((x+t)^2+y^2)] = 2c (A + tau) / (A^2 + tau (W + tau)),
@@ -278,15 +388,19 @@ __device__ __forceinline__ CellLine cell_line(const RrlFields<T>& f, int64_t o,
   // x^2 < cq
   c.cq = c.y * c.y + lnq + 1.7917594692280550 - 2.0 * log(c.omq) - log(0.25 * c.y) +
          29.9336062089226 + 4.2046926193909657;
+  // centred lattice (y < 0.03): |P| <= exp(y^2 - x^2) and Re w >= y / (4 (|z|^2 + 1)) with
+  // |z|^2 <= 16^2 + 1: negligible iff x^2 > y^2 - ln y + ln(1e13) + ln(4 * 258)
+  if (c.y < kCenYMax) c.cq = c.y * c.y - log(c.y) + 29.9336062089226 + 6.9392539460415;
   if (!(c.C == c.C) || c.C == 0.0 || !(c.y > 0.0)) c.C = 0.0;     // nansum drops NaN terms
   return c;
 }
 
 // kappa_L * path of one (cell, channel): C * Re w * (1 - exp(-h nu / kT))   (rrls.py:383-389)
+template <bool CEN>
 __device__ __forceinline__ double line_term(const CellLine& c, double nu_f, double dnu,
-                                            double dnu_max) {
+                                            double dnu_max, double* tab) {
   const double xv = (nu_f - c.nu0) * c.is2;
-  const double V = voigt_rew(fabs(xv), c.y, c.q, c.omq, c.cq);
+  const double V = voigt_rew<CEN>(fabs(xv), c.y, c.q, c.omq, c.cq, tab);
   // 1 - exp(-h nu / kT) = 1 - E0 * exp(-a (nu - nu_ref))
   const double eps = c.a * dnu;
   double ex;
@@ -314,7 +428,7 @@ __global__ __launch_bounds__(kRB) void rrl_cells_kernel(RrlFields<T> f, int64_t 
                     !((double)f.vy[i] == (double)f.vy[i]);
   for (int k = 0; k < nchan; ++k) {
     double v = nan;
-    if (!dead) v = c.C == 0.0 ? 0.0 : line_term(c, nu[k], nu[k] - ln.nu_ref, ln.dnu_max);
+    if (!dead) v = c.C == 0.0 ? 0.0 : line_term<false>(c, nu[k], nu[k] - ln.nu_ref, ln.dnu_max, nullptr);
     out[(int64_t)k * ncell + i] = v;
   }
 }
@@ -344,6 +458,9 @@ __global__ __launch_bounds__(kRB, RJP_K3_WAVES) void rrl_scan_kernel(
   __shared__ double s_nu0[kRB], s_is2[kRB], s_y[kRB], s_C[kRB], s_a[kRB], s_E0[kRB],
       s_q[kRB], s_omq[kRB], s_cq[kRB];
   __shared__ double s_acc[NZP * kRB];
+  // per-wave table of the centred Voigt lattice (kernels whose waves work on one cell)
+  constexpr bool CEN = LF >= RJP_WAVE;
+  __shared__ double s_tab[CEN ? kRB / RJP_WAVE : 1][RJP_WAVE];
 
   const int ntz = (nz + ZT - 1) / ZT;
   const int x = blockIdx.x / ntz;
@@ -411,7 +528,8 @@ __global__ __launch_bounds__(kRB, RJP_K3_WAVES) void rrl_scan_kernel(
           CellLine cl;
           cl.C = C; cl.nu0 = s_nu0[ci]; cl.is2 = s_is2[ci]; cl.y = s_y[ci]; cl.a = s_a[ci];
           cl.E0 = s_E0[ci]; cl.q = s_q[ci]; cl.omq = s_omq[ci]; cl.cq = s_cq[ci];
-          const double term = line_term(cl, nu_f, dnu, ln.dnu_max);
+          const double term = line_term<CEN>(cl, nu_f, dnu, ln.dnu_max,
+                                             CEN ? s_tab[tid / RJP_WAVE] : nullptr);
           if (term == term) acc += term;
         }
       }

@@ -670,3 +670,33 @@ def test_producers_write_the_compact_field_themselves(eng, producer):
         eng.ff_cells(lean, bursts, ep[0], mode, [1.0])
     with pytest.raises(ValueError, match="compact layout"):
         eng.synth_fields((2, 4, 4), 1, 0, 4, wide=False)
+
+
+@pytest.mark.parametrize("nchan,cw", [(64, 1.5e5), (256, 1.5e5), (300, 1.0e5), (16, 4e5)])
+@pytest.mark.parametrize("thin", [1e-2, 1e-4, 1e-8])
+def test_rrl_small_voigt_y_every_lane_layout(eng, nchan, cw, thin):
+    """Cells with a tiny Lorentzian width (Voigt y from ~3e-2 down to ~1e-11): the lattice
+    centred on x (kernels with >= 64 channel lanes: one cell per wave) and the half-shifted
+    lattice (16 lanes) against scipy's wofz through the oracle, over a band wide enough for
+    the core, the pole term, the far field and |x| beyond the centred table (|x| > 16)."""
+    from rajepy_amd import _lib
+    from rajepy_amd.maths import rrls
+    shape = (2, 23, 9)
+    g = U.synth_host(shape, 20240507, 1)
+    g["nd"] = g["nd"] * thin
+    g["vy"][0, :, 0] = 0.0                               # a sightline exactly on the line centre
+    p = copy.deepcopy(U.load_golden("cfg1_example")[2])
+    p["power_laws"]["q_T"] = -0.5
+    p["grid"].update(n_x=shape[0], n_y=shape[1], n_z=shape[2])
+    jet = orc.OracleJet.from_fields(p, g["nd"], g["xi"], g["temp"], g["ff"], g["areas"],
+                                    g["ts"], g["rr"], g["vy"])
+    jet.time = 0.4 * orc.YEAR
+    fields = _upload(eng, g, jet.csize, 8)
+    nu0 = rrls.rrl_nu_0("H", 66, 1)
+    rf = orc.chan_freqs(nu0, nchan * cw, cw)
+    line = _lib.Line(**rrls.line_constants("H66a"))
+    tau = eng.rrl_scan(fields, U.bursts_from_oracle(jet), jet.time, line, rf)
+    eng.synchronize()
+    ref = jet.optical_depth_rrl("H66a", np.asarray(rf))
+    assert np.isfinite(ref).all() and (ref > 0).all()
+    np.testing.assert_allclose(tau.cpu().numpy().reshape(ref.shape), ref, rtol=1e-9)
