@@ -159,10 +159,15 @@ __device__ __attribute__((noinline)) double pole_term_plain(double ax, double y,
 // of a lane follow a recurrence outward from the node nearest t = 0 (|t_m| <= h/2):
 // E_{j+1} = E_j R_j, R_{j+1} = R_j exp(-2 h^2) -- two short polynomials instead of 21 exp.
 // Relative error < 3e-12 for 1e-10 <= y < 0.03, 0 <= x <= 16 (against scipy.special.wofz).
-// The centred lattice is valid for every y (the parity tests pass with any bound); it is USED
-// below y = 0.03, where the plain lattice would cancel: above, the paired plain lattice is
-// cheaper (cfg3: 775 ms with the bound at 0.03, 815 at 0.1, 880 at 0.3, 970 at 1.0).
-constexpr double kCenYMax = 0.03;
+// The centred lattice is valid for every y < pi/h (the parity tests pass with any bound); it is
+// USED below y = 0.03, where the plain lattice would cancel: above, the paired plain lattice is
+// cheaper (cfg3: 775 ms with the bound at 0.03, 815 at 0.1, 880 at 0.3, 970 at 1.0;
+// -DRJP_CEN_YMAX=... moves the bound for such A/B runs).
+#ifndef RJP_CEN_YMAX
+#define RJP_CEN_YMAX 0.03
+#endif
+constexpr double kCenYMax = RJP_CEN_YMAX;
+static_assert(kCenYMax >= 0.03 && kCenYMax <= 5.0, "plain lattice needs y >= 0.03; q > 0 needs y < pi/h");
 constexpr int kCenJ = 10;            // nodes on each side of the middle one
 constexpr int kCenOff = 38;          // table index of k = 0; window [km-10, km+10], km >= -27
 constexpr double kCenXMax = 16.0;    // beyond: continued fraction (the table ends)
@@ -241,16 +246,22 @@ __device__ __forceinline__ double voigt_centred(double ax, double y, double q, d
   // pole term: below 1e-13 Re w once x^2 exceeds the per-cell bound cq; skipped when no lane
   // of the wave needs it
   if (__builtin_amdgcn_ballot_w64(ax * ax < cq) != 0) {
-    const double th = 2.0 * ax * y, t2 = th * th;               // < 1 wherever the term matters
-    double c = 1.0 / 479001600.0;                               // cos(th), degree 12
-    c = __builtin_fma(c, t2, -1.0 / 3628800.0);
-    c = __builtin_fma(c, t2, 1.0 / 40320.0);
-    c = __builtin_fma(c, t2, -1.0 / 720.0);
-    c = __builtin_fma(c, t2, 1.0 / 24.0);
-    c = __builtin_fma(c, t2, -0.5);
-    c = __builtin_fma(c, t2, 1.0);
-    const double g = exp_nonpos(__builtin_fma(-ax, ax, y * y));
-    const double p = 2.0 * g * c * q * rcp_fast(1.0 + q);       // y < 0.03 < pi/h: q > 0
+    double c;
+    if (kCenYMax <= 0.03 || y < 0.03) {
+      const double th = 2.0 * ax * y, t2 = th * th;             // < 1 wherever the term matters
+      c = 1.0 / 479001600.0;                                    // cos(th), degree 12
+      c = __builtin_fma(c, t2, -1.0 / 3628800.0);
+      c = __builtin_fma(c, t2, 1.0 / 40320.0);
+      c = __builtin_fma(c, t2, -1.0 / 720.0);
+      c = __builtin_fma(c, t2, 1.0 / 24.0);
+      c = __builtin_fma(c, t2, -0.5);
+      c = __builtin_fma(c, t2, 1.0);
+    } else {
+      double sn;
+      sincos_2pi(0.31830988618379067154 * ax * y, sn, c);
+    }
+    const double g = exp_any(__builtin_fma(-ax, ax, y * y));    // y^2 - x^2 in [-256, 25]
+    const double p = 2.0 * g * c * q * rcp_fast(1.0 + q);       // y < pi/h: q > 0
     s += (ax * ax < cq) ? p : 0.0;
   }
   if (__builtin_amdgcn_ballot_w64(ax > kCenXMax) != 0) {
@@ -273,9 +284,10 @@ __device__ __forceinline__ double voigt_rew(double ax, double y, double q, doubl
   // valid everywhere, so a wave that straddles the boundary runs one path, not both
   const bool far = r2 > 64.0 && (ax * ax > 64.0 || y > 1.0);
   if (__builtin_amdgcn_ballot_w64(!far) == 0) return voigt_far(ax, y);
-  if (y < kCenYMax) {
-    if constexpr (CEN) return voigt_centred(ax, y, q, cq, tab);
-    else return voigt_core_shifted(ax, y, q, -2.0 * (3.14159265358979323846 / kH) * y);
+  if constexpr (CEN) {
+    if (y < kCenYMax) return voigt_centred(ax, y, q, cq, tab);
+  } else {
+    if (y < 0.03) return voigt_core_shifted(ax, y, q, -2.0 * (3.14159265358979323846 / kH) * y);
   }
 
   // Plain lattice t = n h.  Pair (+t,-t):
@@ -359,7 +371,7 @@ struct CellLine {
   double q = -1.0, omq = 1.0, cq = 0.0;   // pole-term constants (see voigt_rew)
 };
 
-template <typename T, bool BURSTS>
+template <typename T, bool BURSTS, bool CEN>
 __device__ __forceinline__ CellLine cell_line(const RrlFields<T>& f, int64_t o,
                                               const BurstsDev& b, double time_s,
                                               const LineDev& ln) {
@@ -390,7 +402,7 @@ __device__ __forceinline__ CellLine cell_line(const RrlFields<T>& f, int64_t o,
          29.9336062089226 + 4.2046926193909657;
   // centred lattice (y < 0.03): |P| <= exp(y^2 - x^2) and Re w >= y / (4 (|z|^2 + 1)) with
   // |z|^2 <= 16^2 + 1: negligible iff x^2 > y^2 - ln y + ln(1e13) + ln(4 * 258)
-  if (c.y < kCenYMax) c.cq = c.y * c.y - log(c.y) + 29.9336062089226 + 6.9392539460415;
+  if (CEN && c.y < kCenYMax) c.cq = c.y * c.y - log(c.y) + 29.9336062089226 + 6.9392539460415;
   if (!(c.C == c.C) || c.C == 0.0 || !(c.y > 0.0)) c.C = 0.0;     // nansum drops NaN terms
   return c;
 }
@@ -420,7 +432,7 @@ __global__ __launch_bounds__(kRB) void rrl_cells_kernel(RrlFields<T> f, int64_t 
                                                         double* __restrict__ out) {
   const int64_t i = (int64_t)blockIdx.x * kRB + threadIdx.x;
   if (i >= ncell) return;
-  const CellLine c = cell_line<T, BURSTS>(f, i, b, time_s, ln);
+  const CellLine c = cell_line<T, BURSTS, false>(f, i, b, time_s, ln);
   const double nan = __builtin_nan("");
   // a cell outside the jet is NaN in the reference's 3-D output (NaN fields propagate)
   const bool dead = !((double)f.nd[i] == (double)f.nd[i]) || !((double)f.xi[i] == (double)f.xi[i]) ||
@@ -506,7 +518,8 @@ __global__ __launch_bounds__(kRB, RJP_K3_WAVES) void rrl_scan_kernel(
       const int yy = yb + cy, zz = z0 + cz;
       CellLine cl;
       if (yy < ny && zz < nz)
-        cl = cell_line<T, BURSTS>(f, ((int64_t)x * ny + yy) * nz + zz, b, time_s, ln);
+        cl = cell_line<T, BURSTS, (LF >= RJP_WAVE)>(f, ((int64_t)x * ny + yy) * nz + zz, b,
+                                                    time_s, ln);
       const double C = cl.C, nu0 = cl.nu0, is2 = cl.is2, yv = cl.y, a = cl.a, E0 = cl.E0,
                    q = cl.q, omq = cl.omq, cq = cl.cq;
       s_C[tid] = C; s_nu0[tid] = nu0; s_is2[tid] = is2; s_y[tid] = yv; s_a[tid] = a;

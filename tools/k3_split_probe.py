@@ -35,6 +35,9 @@ def run(tag, scale, offset):
 
 
 run("as generated (y ~ 3e-3 .. 10), band on the line", 1.0, 0.0)
+run("n x 10 (y >= 0.03)", 10.0, 0.0)
+run("n x 3", 3.0, 0.0)
+run("n x 30 (y >= 0.1)", 30.0, 0.0)
 run("n x 100 (y >= 0.3: plain lattice only)", 100.0, 0.0)
 run("n / 100 (y <= 0.1: mostly shifted lattice)", 0.01, 0.0)
 run("n / 1e4 (y <= 1e-3: shifted lattice only)", 1e-4, 0.0)
