@@ -290,41 +290,49 @@ __global__ __launch_bounds__(kBlock) void ff_reduce_kernel(
 }
 
 // ---- K2 ------------------------------------------------------------------------------
-// One thread per pixel, serial over the channels of its slice: every store instruction is a
-// coalesced row segment of one (epoch, channel) map.  Write-bound: 16 B per voxel-channel.
+// One thread per VEC adjacent pixels, serial over the channels of its slice: every store
+// instruction is a coalesced row segment of one (epoch, channel) map, 16 B per lane when the
+// map has an even number of pixels.  Write-bound: 16 B per voxel-channel.  The per-channel
+// totals are reduced per wave (shuffles, no LDS, no barrier) into `part`, one slot per wave.
+template <int VEC>
 __global__ __launch_bounds__(kBlock) void ff_maps_kernel(
     const double* __restrict__ sumA, const double* __restrict__ tavg, int64_t npix,
     const double* __restrict__ ctau, const double* __restrict__ cflux, int nchan, int fchunk,
-    double* __restrict__ tau, double* __restrict__ flux, double* __restrict__ part) {
-  const int64_t p = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    double* __restrict__ tau, double* __restrict__ flux, double* __restrict__ part,
+    int nparts) {
+  const int64_t p = ((int64_t)blockIdx.x * kBlock + threadIdx.x) * VEC;
   const int e = blockIdx.y;
   const int f0 = blockIdx.z * fchunk;
   const int f1 = min(nchan, f0 + fchunk);
-  const bool live = p < npix;
-  const double A = live ? sumA[(int64_t)e * npix + p] : 0.0;
-  const double ta = live ? tavg[p] : 0.0;
-  __shared__ double red[kBlock / RJP_WAVE];
+  const bool live = p < npix;                    // npix % VEC == 0: a lane is live or not at all
+  double A[VEC], ta[VEC];
+#pragma unroll
+  for (int v = 0; v < VEC; ++v) { A[v] = 0.0; ta[v] = 0.0; }
+  if (live) {
+    load_plain(sumA + (int64_t)e * npix + p, A);
+    load_plain(tavg + p, ta);
+  }
+  const int slot = blockIdx.x * (kBlock / RJP_WAVE) + threadIdx.x / RJP_WAVE;
   for (int f = f0; f < f1; ++f) {
-    const double t = ctau[f] * A;
-    const double s = cflux[f] * (ta * (1.0 - exp(-t)));
+    double t[VEC], s[VEC];
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) {
+      t[v] = ctau[f] * A[v];
+      s[v] = cflux[f] * (ta[v] * (1.0 - exp(-t[v])));
+    }
     const int64_t o = ((int64_t)e * nchan + f) * npix + p;
     if (live) {
-      if (tau) tau[o] = t;
-      if (flux) flux[o] = s;
+      if (tau) store_plain(tau + o, t);
+      if (flux) store_plain(flux + o, s);
     }
     if (part) {
-      double v = (live && s == s) ? s : 0.0;        // nansum
+      double acc = 0.0;
 #pragma unroll
-      for (int d = RJP_WAVE / 2; d > 0; d >>= 1) v += __shfl_down(v, d, RJP_WAVE);
-      if ((threadIdx.x & (RJP_WAVE - 1)) == 0) red[threadIdx.x / RJP_WAVE] = v;
-      __syncthreads();
-      if (threadIdx.x == 0) {
-        double tot = 0.0;
+      for (int v = 0; v < VEC; ++v) acc += (live && s[v] == s[v]) ? s[v] : 0.0;      // nansum
 #pragma unroll
-        for (int w = 0; w < kBlock / RJP_WAVE; ++w) tot += red[w];
-        part[((int64_t)e * nchan + f) * gridDim.x + blockIdx.x] = tot;
-      }
-      __syncthreads();
+      for (int d = RJP_WAVE / 2; d > 0; d >>= 1) acc += __shfl_down(acc, d, RJP_WAVE);
+      if ((threadIdx.x & (RJP_WAVE - 1)) == 0)
+        part[((int64_t)e * nchan + f) * nparts + slot] = acc;
     }
   }
 }
@@ -662,27 +670,39 @@ hipError_t ff_scan_launch(const rjp_fields* fl, const rjp_bursts* hb, const doub
 }
 
 size_t ff_maps_workspace_bytes(int64_t npix, int n_epochs, int n_chan) {
-  const int64_t nblk = (npix + kBlock - 1) / kBlock;
-  return (size_t)nblk * n_epochs * n_chan * sizeof(double) + 256;
+  // one partial per wave of the map kernels (1 or 2 pixels per lane): at most npix/64 + 4
+  const int64_t nparts = ((npix + kBlock - 1) / kBlock) * (kBlock / RJP_WAVE);
+  return (size_t)nparts * n_epochs * n_chan * sizeof(double) + 256;
 }
 
 hipError_t ff_maps_launch(const double* sumA, const double* tavg, int64_t npix, int n_epochs,
                           const double* d_ctau, const double* d_cflux, int n_chan, double* tau,
                           double* flux, double* ftot, double* part, hipStream_t st) {
-  const unsigned nblk = (unsigned)((npix + kBlock - 1) / kBlock);
+  // two pixels per lane (16-B loads and stores) when every map row pair is 16-B aligned
+  bool vec2 = (npix % 2) == 0;
+  for (const void* q : {(const void*)sumA, (const void*)tavg, (const void*)tau, (const void*)flux})
+    if (q && ((uintptr_t)q % 16) != 0) vec2 = false;
+  const int vec = vec2 ? 2 : 1;
+  const int64_t lanes = npix / vec;
+  const unsigned nblk = (unsigned)((lanes + kBlock - 1) / kBlock);
+  const int nparts = (int)nblk * (kBlock / RJP_WAVE);
   // split channels over gridDim.z so that small maps still expose >= ~2048 blocks
   int fsplit = 1;
   while ((int64_t)nblk * n_epochs * fsplit < 2048 && fsplit < n_chan) fsplit *= 2;
   const int fchunk = (n_chan + fsplit - 1) / fsplit;
   fsplit = (n_chan + fchunk - 1) / fchunk;
   dim3 grid(nblk, (unsigned)n_epochs, (unsigned)fsplit);
-  hipLaunchKernelGGL(ff_maps_kernel, grid, dim3(kBlock), 0, st, sumA, tavg, npix, d_ctau,
-                     d_cflux, n_chan, fchunk, tau, flux, ftot ? part : nullptr);
+  if (vec2)
+    hipLaunchKernelGGL(ff_maps_kernel<2>, grid, dim3(kBlock), 0, st, sumA, tavg, npix, d_ctau,
+                       d_cflux, n_chan, fchunk, tau, flux, ftot ? part : nullptr, nparts);
+  else
+    hipLaunchKernelGGL(ff_maps_kernel<1>, grid, dim3(kBlock), 0, st, sumA, tavg, npix, d_ctau,
+                       d_cflux, n_chan, fchunk, tau, flux, ftot ? part : nullptr, nparts);
   hipError_t err = hipGetLastError();
   if (err != hipSuccess) return err;
   if (ftot) {
     hipLaunchKernelGGL(sum_partials_kernel, dim3((unsigned)(n_epochs * n_chan)), dim3(kBlock),
-                       0, st, part, (int)nblk, ftot);
+                       0, st, part, nparts, ftot);
     err = hipGetLastError();
   }
   return err;

@@ -36,6 +36,22 @@ __device__ __forceinline__ void load_vec(const float* __restrict__ p, double (&o
   out[0] = (double)*p;
 }
 
+// cached (not non-temporal) vector loads / stores of small maps
+__device__ __forceinline__ void load_plain(const double* __restrict__ p, double (&out)[2]) {
+  rjp_d2 t = *reinterpret_cast<const rjp_d2*>(p);
+  out[0] = t.x; out[1] = t.y;
+}
+__device__ __forceinline__ void load_plain(const double* __restrict__ p, double (&out)[1]) {
+  out[0] = *p;
+}
+__device__ __forceinline__ void store_plain(double* __restrict__ p, const double (&v)[2]) {
+  rjp_d2 t; t.x = v[0]; t.y = v[1];
+  *reinterpret_cast<rjp_d2*>(p) = t;
+}
+__device__ __forceinline__ void store_plain(double* __restrict__ p, const double (&v)[1]) {
+  p[0] = v[0];
+}
+
 // ---- burst factor chi(t) (classes.py:442-448, 866-868) ---------------------------------
 // Kernel-argument copy of rjp_bursts (lives in SGPRs / scalar cache).
 struct BurstsDev {
