@@ -71,6 +71,26 @@ __device__ __forceinline__ void sincos_2pi(double u, double& sn, double& cs) {
   cs = (q == 1 || q == 2) ? -b : b;
 }
 
+// cos(2 pi u) alone: half-turn reduction, one even polynomial on |w| <= pi/2 (truncation
+// 2e-17), no quadrant selects.  |u| < 2^30.
+__device__ __forceinline__ double cos_2pi(double u) {
+  const double k = __builtin_rint(2.0 * u);
+  const double w = 6.28318530717958647692 * __builtin_fma(-0.5, k, u);
+  const double w2 = w * w;
+  double p = 4.1103176233121648585e-19;                  //  1/20!
+  p = __builtin_fma(p, w2, -1.5619206968586226462e-16);  // -1/18!
+  p = __builtin_fma(p, w2, 4.7794773323873852974e-14);   //  1/16!
+  p = __builtin_fma(p, w2, -1.1470745597729724714e-11);  // -1/14!
+  p = __builtin_fma(p, w2, 2.0876756987868098979e-09);   //  1/12!
+  p = __builtin_fma(p, w2, -2.7557319223985888276e-07);  // -1/10!
+  p = __builtin_fma(p, w2, 2.4801587301587301566e-05);   //  1/8!
+  p = __builtin_fma(p, w2, -1.3888888888888889419e-03);  // -1/6!
+  p = __builtin_fma(p, w2, 4.1666666666666664354e-02);   //  1/4!
+  p = __builtin_fma(p, w2, -0.5);
+  p = __builtin_fma(p, w2, 1.0);
+  return ((int)k & 1) ? -p : p;
+}
+
 __device__ __forceinline__ double rcp_fast(double d) {
 #if defined(RJP_RCP_F32)
   double r = (double)__builtin_amdgcn_rcpf((float)d);   // f32 seed (d within f32 range)
@@ -135,16 +155,17 @@ __device__ __attribute__((noinline)) double voigt_core_shifted(double ax, double
 // line core need it.
 __device__ __attribute__((noinline)) double pole_term_plain(double ax, double y, double q,
                                                            double omq) {
+  // Re[e^{-i phi} conj(q - e^{-i theta})] = q cos(phi) - cos(theta - phi), phi = 2 x y;
+  // |q - e^{-i theta}|^2 = 1 - 2 q cos(theta) + q^2 >= (1 - q)^2 >= 0.07 (y >= 0.03 here), so
+  // three cosines do: no half-angle forms needed against cancellation
+  (void)omq;
   const double e = y * y - ax * ax;
   const double u = ax * (1.0 / kH);
-  const double fr = u - __builtin_floor(u);
-  double sh, ch, s2, c2;
-  sincos_2pi(0.5 * fr, sh, ch);                       // half angle: theta/2 = pi fr
-  sincos_2pi(0.31830988618379067154 * ax * y, s2, c2);
-  const double omc = 2.0 * sh * sh;                   // 1 - cos(theta)
-  const double st = 2.0 * sh * ch;                    // sin(theta)
-  const double den = __builtin_fma(omq, omq, 2.0 * q * omc);   // |q - e^{-i theta}|^2
-  const double num = __builtin_fma(c2, omc - omq, -s2 * st);   // Re[e^{-2ixy} conj(q - e^{-i theta})]
+  const double fr = u - __builtin_floor(u);                     // theta / 2 pi
+  const double ph = 0.31830988618379067154 * ax * y;            // phi / 2 pi
+  const double cth = cos_2pi(fr), cph = cos_2pi(ph), cps = cos_2pi(fr - ph);
+  const double den = __builtin_fma(q, q - 2.0 * cth, 1.0);
+  const double num = __builtin_fma(q, cph, -cps);
   return 2.0 * exp_any(e) * q * num * rcp_fast(den);
 }
 
