@@ -153,12 +153,10 @@ __device__ __attribute__((noinline)) double voigt_core_shifted(double ax, double
 // theta = 2 pi x / h = 2 pi fr (mod 2 pi), written without cancellation near a node
 // (1 - cos theta = 2 sin^2(theta/2), 1 - q from expm1).  Out of line: only the waves near the
 // line core need it.
-__device__ __attribute__((noinline)) double pole_term_plain(double ax, double y, double q,
-                                                           double omq) {
+__device__ __attribute__((noinline)) double pole_term_plain(double ax, double y, double q) {
   // Re[e^{-i phi} conj(q - e^{-i theta})] = q cos(phi) - cos(theta - phi), phi = 2 x y;
   // |q - e^{-i theta}|^2 = 1 - 2 q cos(theta) + q^2 >= (1 - q)^2 >= 0.07 (y >= 0.03 here), so
   // three cosines do: no half-angle forms needed against cancellation
-  (void)omq;
   const double e = y * y - ax * ax;
   const double u = ax * (1.0 / kH);
   const double fr = u - __builtin_floor(u);                     // theta / 2 pi
@@ -294,12 +292,12 @@ __device__ __forceinline__ double voigt_centred(double ax, double y, double q, d
 
 // Re w(x + i y) for one lane (x = ax >= 0 per lane, y > 0 THE SAME IN EVERY LANE: a wave
 // works on one cell).  Per-cell constants: q = exp(-2 pi y / h) (or -1 when y >= pi/h: no
-// pole term), omq = 1 - q (from expm1), cq = x^2 below which the pole term matters.
+// pole term), cq = x^2 below which the pole term matters.
 // `tab` = this wave's 64-entry LDS table when every lane of the wave works on the same cell
 // (kernels with >= 64 channel lanes), else nullptr (CEN = false).
 template <bool CEN>
-__device__ __forceinline__ double voigt_rew(double ax, double y, double q, double omq,
-                                            double cq, double* tab) {
+__device__ __forceinline__ double voigt_rew(double ax, double y, double q, double cq,
+                                            double* tab) {
   const double r2 = __builtin_fma(ax, ax, y * y);
   // the far-field branch is taken only when EVERY active lane qualifies: the core formula is
   // valid everywhere, so a wave that straddles the boundary runs one path, not both
@@ -358,7 +356,7 @@ __device__ __forceinline__ double voigt_rew(double ax, double y, double q, doubl
   // Pole term P = Re[ 2 exp(-z^2) q / (q - exp(-i theta)) ], theta = 2 pi x / h.
   // |P| <= 6 exp(y^2 - x^2) q / (1 - q)^2 and Re w >= y / (4 (|z|^2 + 1)) with |z|^2 < 66 in
   // this branch: P is below 1e-13 Re w, and skipped, once x^2 exceeds the per-cell bound cq.
-  if (q >= 0.0 && ax * ax < cq) s += pole_term_plain(ax, y, q, omq);
+  if (q >= 0.0 && ax * ax < cq) s += pole_term_plain(ax, y, q);
   return s;
 }
 
@@ -389,7 +387,7 @@ struct CellLine {
   double y = 1.0;      // Voigt y = (fwhm_L / 2) / (sigma sqrt 2)
   double a = 0.0;      // h / (k T) [1/Hz]
   double E0 = 0.0;     // exp(-a nu_ref)
-  double q = -1.0, omq = 1.0, cq = 0.0;   // pole-term constants (see voigt_rew)
+  double q = -1.0, cq = 0.0;   // pole-term constants (see voigt_rew)
 };
 
 template <typename T, bool BURSTS, bool CEN>
@@ -416,10 +414,10 @@ __device__ __forceinline__ CellLine cell_line(const RrlFields<T>& f, int64_t o,
   c.E0 = exp(-c.a * ln.nu_ref);
   const double lnq = -2.0 * kPiOverH * c.y;
   c.q = (c.y < kPiOverH) ? exp(lnq) : -1.0;
-  c.omq = -expm1(lnq);
+  const double omq = -expm1(lnq);                                  // 1 - q
   // pole term needed iff y^2 - x^2 + ln(6 q / (1-q)^2) > ln(1e-13 y / (4 * 67)), i.e. iff
   // x^2 < cq
-  c.cq = c.y * c.y + lnq + 1.7917594692280550 - 2.0 * log(c.omq) - log(0.25 * c.y) +
+  c.cq = c.y * c.y + lnq + 1.7917594692280550 - 2.0 * log(omq) - log(0.25 * c.y) +
          29.9336062089226 + 4.2046926193909657;
   // centred lattice (y < 0.03): |P| <= exp(y^2 - x^2) and Re w >= y / (4 (|z|^2 + 1)) with
   // |z|^2 <= 16^2 + 1: negligible iff x^2 > y^2 - ln y + ln(1e13) + ln(4 * 258)
@@ -433,7 +431,7 @@ template <bool CEN>
 __device__ __forceinline__ double line_term(const CellLine& c, double nu_f, double dnu,
                                             double dnu_max, double* tab) {
   const double xv = (nu_f - c.nu0) * c.is2;
-  const double V = voigt_rew<CEN>(fabs(xv), c.y, c.q, c.omq, c.cq, tab);
+  const double V = voigt_rew<CEN>(fabs(xv), c.y, c.q, c.cq, tab);
   // 1 - exp(-h nu / kT) = 1 - E0 * exp(-a (nu - nu_ref))
   const double eps = c.a * dnu;
   double ex;
@@ -489,7 +487,7 @@ __global__ __launch_bounds__(kRB, RJP_K3_WAVES) void rrl_scan_kernel(
   static_assert(ZT % TL::G == 0, "tile/group mismatch");
 
   __shared__ double s_nu0[kRB], s_is2[kRB], s_y[kRB], s_C[kRB], s_a[kRB], s_E0[kRB],
-      s_q[kRB], s_omq[kRB], s_cq[kRB];
+      s_q[kRB], s_cq[kRB];
   __shared__ double s_acc[NZP * kRB];
   // per-wave table of the centred Voigt lattice (kernels whose waves work on one cell)
   constexpr bool CEN = LF >= RJP_WAVE;
@@ -542,9 +540,9 @@ __global__ __launch_bounds__(kRB, RJP_K3_WAVES) void rrl_scan_kernel(
         cl = cell_line<T, BURSTS, (LF >= RJP_WAVE)>(f, ((int64_t)x * ny + yy) * nz + zz, b,
                                                     time_s, ln);
       const double C = cl.C, nu0 = cl.nu0, is2 = cl.is2, yv = cl.y, a = cl.a, E0 = cl.E0,
-                   q = cl.q, omq = cl.omq, cq = cl.cq;
+                   q = cl.q, cq = cl.cq;
       s_C[tid] = C; s_nu0[tid] = nu0; s_is2[tid] = is2; s_y[tid] = yv; s_a[tid] = a;
-      s_E0[tid] = E0; s_q[tid] = q; s_omq[tid] = omq; s_cq[tid] = cq;
+      s_E0[tid] = E0; s_q[tid] = q; s_cq[tid] = cq;
     }
     __syncthreads();
 
@@ -561,7 +559,7 @@ __global__ __launch_bounds__(kRB, RJP_K3_WAVES) void rrl_scan_kernel(
         if (live) {
           CellLine cl;
           cl.C = C; cl.nu0 = s_nu0[ci]; cl.is2 = s_is2[ci]; cl.y = s_y[ci]; cl.a = s_a[ci];
-          cl.E0 = s_E0[ci]; cl.q = s_q[ci]; cl.omq = s_omq[ci]; cl.cq = s_cq[ci];
+          cl.E0 = s_E0[ci]; cl.q = s_q[ci]; cl.cq = s_cq[ci];
           const double term = line_term<CEN>(cl, nu_f, dnu, ln.dnu_max,
                                              CEN ? s_tab[tid / RJP_WAVE] : nullptr);
           if (term == term) acc += term;
