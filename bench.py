@@ -54,8 +54,10 @@ EXAMPLE_BURSTS = {"t_0": [0.5, 0.75, 1., 2.], "hl": [0.15, 0.15, 0.45, 0.5],
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    # defaults: long enough that clock ramp-up and first-touch effects of a fresh box stay in
+    # the warm-up and the timed region averages over > 100 ms of device work
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--config", default=os.environ.get("RJP_BENCH_CONFIG", "cfg4"),
                     choices=sorted(CONFIGS))
     ap.add_argument("--storage", default="f64", choices=("f64", "f32"))
