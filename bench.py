@@ -338,9 +338,11 @@ def main():
     else:
         k_ms = eng.time_ff_scan(fields, bursts, my_epochs, E.RJP_GFF_SCALAR, reps=5,
                                 want_em=em is not None)
-        # epoch tiles share a pass over the grid: 16 uniformly spaced epochs, else 8 (f64
+        # epoch tiles share a pass over the grid: 32 uniformly spaced epochs when no EM maps are
+        # asked for, 16 with them, else 8 (f64
         # lanes) or 4 (f32 lanes)
-        tile = 16 if E_loc >= 16 else (8 if args.storage == "f64" else 4)
+        tile = (32 if (E_loc >= 32 and em is None) else 16 if E_loc >= 16 else
+                (8 if args.storage == "f64" else 4))
         npass = -(-E_loc // tile) if E_loc > 1 else 1
         # fields K1 streams per cell: em0, temp, ts in the compact f64 layout (DESIGN.md
         # "Data layout"), else nd, xi, temp, pf, ts

@@ -30,7 +30,7 @@ extern "C" {
 
 #define RJP_VERSION 102          /* 0.1.2 */
 #define RJP_MAX_BURSTS 8         /* per jet (red / blue) */
-#define RJP_MAX_EPOCH_TILE 16    /* most epochs evaluated per grid pass (uniformly spaced, f64 lanes; else 8) */
+#define RJP_MAX_EPOCH_TILE 32    /* most epochs evaluated per grid pass: 32 uniformly spaced ones when d_em is NULL, 16 uniformly spaced ones with d_em, else 8 */
 
 enum rjp_status {
   RJP_OK = 0,

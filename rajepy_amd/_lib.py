@@ -14,7 +14,7 @@ LIB_PATH = os.environ.get("RJP_LIB") or os.path.join(_HERE, "librjprt.so")
 RJP_F32, RJP_F64 = 4, 8
 RJP_GFF_SCALAR, RJP_GFF_POWERLAW = 0, 1
 RJP_MAX_BURSTS = 8
-RJP_MAX_EPOCH_TILE = 16
+RJP_MAX_EPOCH_TILE = 32
 RJP_OK = 0
 
 

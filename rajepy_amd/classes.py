@@ -495,7 +495,7 @@ class JetModel:
 
     # ------------------------------------------------------------------ K1 cache ----
     def prefetch_epochs(self, times_s):
-        """Scan the grid for several model times at once (8-16 epochs share one pass over
+        """Scan the grid for several model times at once (8-32 epochs share one pass over
         HBM); later RT calls at those times reuse the base maps."""
         todo = [t for t in dict.fromkeys(float(t) for t in times_s)
                 if t not in self._scan_cache]
@@ -564,7 +564,7 @@ class JetModel:
         """Light curves: total flux density [Jy] of the whole map at every (model time,
         frequency) -> array (len(times), len(freq)).  The reference gets these numbers by
         looping `time` and summing `flux_ff` maps (Pipeline results, classes.py:2461-2467);
-        here the maps are reduced on the device and up to 16 epochs share one pass over HBM.
+        here the maps are reduced on the device and up to 32 epochs share one pass over HBM.
         Inside a torch.distributed group the epochs are shared out over the ranks."""
         from . import parallel
         rank, world, _ = _dist_info()
@@ -996,7 +996,7 @@ class Pipeline:
         self._multi_rank = world > 1
 
         if not dryrun:
-            # one pass over HBM serves 8-16 epochs
+            # one pass over HBM serves 8-32 epochs
             pending = [self.runs[i].year * con.year for i in mine
                        if self.runs[i].radiative_transfer and
                        not (self.runs[i].completed and resume and not clobber)]

@@ -59,7 +59,7 @@ struct EpochTile {
 };
 
 constexpr int kBlock = 256;
-constexpr int kMaxTile = 16;     // largest epoch tile (uniformly spaced epochs, f64 lanes)
+constexpr int kMaxTile = 32;     // largest epoch tile (uniformly spaced epochs, no EM maps)
 // y-rows of loads kept in flight per lane; fewer when many accumulators are live so the
 // kernel stays inside the 256-VGPR budget without scratch
 #ifndef RJP_UNROLL_BASE
@@ -274,7 +274,7 @@ __global__ __launch_bounds__(kBlock) void ff_reduce_kernel(
     double a = 0.0, g = 0.0;
     for (int s = 0; s < nsplit; ++s) {
       a += ws[((int64_t)s * na + e) * npix + p];
-      g += ws[((int64_t)s * na + et + e) * npix + p];
+      if (em) g += ws[((int64_t)s * na + et + e) * npix + p];     // not written without EM
     }
     sumA[(int64_t)(e0 + e) * npix + p] = a;
     if (em) em[(int64_t)(e0 + e) * npix + p] = g * em_scale;
@@ -544,7 +544,14 @@ static hipError_t launch_tile(const rjp_fields* fl, const BurstsDev& b, const do
   dim3 grid((unsigned)((nchunks + kBlock - 1) / kBlock), (unsigned)nsplit);
   // the recurrence pays with at least 4 epochs per tile; short tiles of f32 storage keep
   // their 9-instruction float-accuracy exp instead
-  if constexpr (BURSTS && ET >= 4 && (sizeof(T) == 8 || ET == 16)) {
+  if constexpr (ET == 32) {
+    // 32 epochs per pass: recurrence only, and only without the emission-measure accumulators
+    if (ep.un.on && !want_em) {
+      hipLaunchKernelGGL((ff_scan_kernel<T, VEC, ET, MODE, true, true, CMP, false>), grid,
+                         dim3(kBlock), 0, st, f, fl->ny, fl->nz, nchunks, npix, ylen, b, ep, ws);
+      return hipGetLastError();
+    }
+  } else if constexpr (BURSTS && ET >= 4 && (sizeof(T) == 8 || ET == 16)) {
     if (ep.un.on) {
       if (want_em)
         hipLaunchKernelGGL((ff_scan_kernel<T, VEC, ET, MODE, true, true, CMP, true>), grid,
@@ -587,6 +594,10 @@ static hipError_t dispatch_et(const rjp_fields* fl, const BurstsDev& b, bool bur
       if constexpr (VEC == 1)
         return launch_tile<T, VEC, 16, MODE, true, CMP>(fl, b, t, nsplit, ylen, ws, want_em, st);
       else return hipErrorInvalidValue;
+    case 32:
+      if constexpr (VEC == 1)
+        return launch_tile<T, VEC, 32, MODE, true, CMP>(fl, b, t, nsplit, ylen, ws, want_em, st);
+      else return hipErrorInvalidValue;
   }
   return hipErrorInvalidValue;
 }
@@ -603,6 +614,12 @@ static hipError_t dispatch_mode(const rjp_fields* fl, const BurstsDev& b, bool b
   if (mode == RJP_GFF_SCALAR)
     return dispatch_et<T, VEC, RJP_GFF_SCALAR, false>(fl, b, bursts, t, et, nsplit, ylen, ws, want_em, st);
   return dispatch_et<T, VEC, RJP_GFF_POWERLAW, false>(fl, b, bursts, t, et, nsplit, ylen, ws, want_em, st);
+}
+
+static bool use_tile32() {
+  static int v = -1;
+  if (v < 0) v = getenv("RJP_NO_TILE32") ? 0 : 1;          // A/B runs
+  return v != 0;
 }
 
 // Enqueue the whole scan for n_epochs epochs.  Returns hipSuccess or the first error.
@@ -631,17 +648,22 @@ hipError_t ff_scan_launch(const rjp_fields* fl, const rjp_bursts* hb, const doub
         uniform_tile(epochs + e0, 16, b, probe);
         if (probe.on) et = 16;
       }
+      if (left >= 32 && !em && use_tile32()) {
+        UnifDev probe;
+        uniform_tile(epochs + e0, 32, b, probe);
+        if (probe.on) et = 32;
+      }
     }
     hipError_t err;
     const double* t = epochs + e0;
     if (fl->dtype == RJP_F64) {
       // 16-epoch tiles are ALU-bound and register-hungry: one sightline per lane (160 VGPRs,
       // 3 waves/SIMD) beats two (256 VGPRs, 1 wave/SIMD) by 15 %
-      err = (vec == 2 && et != 16)
+      err = (vec == 2 && et < 16)
                 ? dispatch_mode<double, 2>(fl, b, bursts, mode, t, et, nsplit, ylen, ws, em != nullptr, st)
                 : dispatch_mode<double, 1>(fl, b, bursts, mode, t, et, nsplit, ylen, ws, em != nullptr, st);
     } else {
-      err = (vec == 4 && et != 16)
+      err = (vec == 4 && et < 16)
                 ? dispatch_mode<float, 4>(fl, b, bursts, mode, t, et, nsplit, ylen, ws, em != nullptr, st)
                 : dispatch_mode<float, 1>(fl, b, bursts, mode, t, et, nsplit, ylen, ws, em != nullptr, st);
     }

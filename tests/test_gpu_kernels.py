@@ -610,7 +610,8 @@ def test_negative_path_factors_keep_the_wide_layout(eng):
                                     [0.2, 0.25, 0.4, 0.8, 1.3, 1.35, 2.0, 2.9, 3.3]])
 def test_scans_without_emission_measure_give_the_same_tau_sums(eng, store, epochs):
     """Flux-vs-time sweeps pass d_em = NULL and get kernels without the EM accumulators (tiles
-    of 4, 8 and 16 epochs, uniform and not): sumA and T_avg must not change by a bit."""
+    of 4, 8 and 16 epochs, uniform and not): sumA and T_avg must not change by a bit.
+    (From 32 uniformly spaced epochs on they also get a larger tile: next test.)"""
     from rajepy_amd import engine as E
     shape = (5, 70, 32)
     f = _layout(eng.synth_fields(shape, 31337, 1, _store(store), csize_au=0.5), store)
@@ -700,3 +701,38 @@ def test_rrl_small_voigt_y_every_lane_layout(eng, nchan, cw, thin):
     ref = jet.optical_depth_rrl("H66a", np.asarray(rf))
     assert np.isfinite(ref).all() and (ref > 0).all()
     np.testing.assert_allclose(tau.cpu().numpy().reshape(ref.shape), ref, rtol=1e-9)
+
+
+@pytest.mark.parametrize("store", ["f64", "f32"])
+@pytest.mark.parametrize("n_ep,t1", [(32, 5.0), (45, 4.0), (64, 2.0), (33, 0.6)])
+def test_32_epoch_tiles_of_em_less_sweeps_follow_the_oracle(eng, store, n_ep, t1):
+    """d_em = NULL and >= 32 uniformly spaced epochs: one pass serves 32 epochs (recurrence
+    anchored at the tile's middle epoch).  Against the oracle at every epoch, and against the
+    16-epoch tiles of the same sweep with EM maps."""
+    from rajepy_amd import engine as E
+    shape = (4, 37, 16)
+    dtype = _store(store)
+    seed = 20240511
+    fields = eng.synth_fields(shape, seed, 1, dtype, csize_au=0.5)
+    g = U.synth_host(shape, seed, 1)
+    p = copy.deepcopy(U.load_golden("cfg1_example")[2])
+    p["ejection"] = U.example_bursts_params()
+    p["power_laws"]["q_T"] = -0.5
+    p["grid"].update(n_x=shape[0], n_y=shape[1], n_z=shape[2])
+    jet = orc.OracleJet.from_fields(p, g["nd"], g["xi"], g["temp"], g["ff"], g["areas"],
+                                    g["ts"], g["rr"], g["vy"])
+    years = np.linspace(0.0, t1, n_ep)
+    ep = [y * orc.YEAR for y in years]
+    bursts = U.bursts_from_oracle(jet)
+    a32, none, _ = eng.ff_scan(fields, bursts, ep, E.RJP_GFF_POWERLAW, want_em=False)
+    a32 = a32.clone()
+    a16, em16, _ = eng.ff_scan(fields, bursts, ep, E.RJP_GFF_POWERLAW, want_em=True)
+    eng.synchronize()
+    assert none is None
+    tol = 1e-11 if dtype == 8 else RTOL
+    np.testing.assert_allclose(a32.cpu().numpy(), a16.cpu().numpy(), rtol=tol)
+    ctau, _ = E.ff_channel_coeffs([5e9], jet.csize, p["target"]["dist"], E.RJP_GFF_POWERLAW)
+    got = a32.cpu().numpy().reshape(n_ep, shape[0], shape[2]) * ctau[0]
+    for e in (0, 1, n_ep // 2, 31, n_ep - 1):
+        jet.time = ep[e]
+        np.testing.assert_allclose(got[e], jet.optical_depth_ff(5e9), rtol=tol)
