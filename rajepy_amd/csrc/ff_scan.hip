@@ -5,7 +5,7 @@
 // over the device-resident fields (three in the compact layout, five in the wide one): one
 // lane owns VEC adjacent (x,z) sightlines (16 B of every field per load, 1 KiB per
 // wave-instruction, lanes adjacent along the contiguous z-axis), walks y serially with UNROLL
-// rows of loads in flight, evaluates the burst factor chi(t) for a tile of up to 16 epochs in
+// rows of loads in flight, evaluates the burst factor chi(t) for a tile of up to 32 epochs in
 // registers and keeps FP64 accumulators.  The y-range is split over gridDim.y so small maps
 // still fill 256 CUs; partial sums go to a workspace and a tiny second kernel reduces them in
 // a fixed order (bitwise reproducible, no atomics).

@@ -136,7 +136,7 @@ def gather_to_root(local, shards, rank, axis=0, root=0, group=None):
 
 def sweep_flux_vs_time(model, epochs_s, freqs, rank=0, world=1, group=None):
     """Epoch-sharded continuum sweep through the JetModel API: every rank scans its epochs
-    (8-16 per pass over HBM), reduces each (epoch, channel) map to its total flux on the
+    (8-32 per pass over HBM), reduces each (epoch, channel) map to its total flux on the
     device and the [E, F] light curves are all_gathered.  Returns a host array [E, F] [Jy]."""
     from . import engine as E
     from .maths import physics as mphys
