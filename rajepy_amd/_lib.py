@@ -15,6 +15,7 @@ RJP_F32, RJP_F64 = 4, 8
 RJP_GFF_SCALAR, RJP_GFF_POWERLAW = 0, 1
 RJP_MAX_BURSTS = 8
 RJP_MAX_EPOCH_TILE = 32
+RJP_VERSION = 102             # include/rjprt.h; the binding below matches exactly this ABI
 RJP_OK = 0
 
 
@@ -115,8 +116,9 @@ def load():
         fn = getattr(lib, name)          # AttributeError if a declared symbol is missing
         fn.restype = res
         fn.argtypes = args
-    if lib.rjp_version() < 102:
-        raise RjprtError("librjprt.so is older than this binding")
+    if lib.rjp_version() != RJP_VERSION:
+        raise RjprtError("librjprt.so is version %d, this binding is for %d: rebuild it "
+                         "(rajepy_amd/csrc/build.sh)" % (lib.rjp_version(), RJP_VERSION))
     _lib = lib
     return lib
 

@@ -45,7 +45,9 @@ def test_abi_exports_every_declared_symbol():
     declared = set(re.findall(r"\b(rjp_[a-z0-9_]+)\s*\(", hdr))
     assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
     lib = _lib.load()                       # raises if the .so or any symbol is missing
-    assert lib.rjp_version() == 102
+    # header, library and binding agree on the ABI version
+    assert int(re.search(r"#define RJP_VERSION (\d+)", hdr).group(1)) == _lib.RJP_VERSION
+    assert lib.rjp_version() == _lib.RJP_VERSION
     for name in declared:
         assert hasattr(lib, name)
 
@@ -293,3 +295,10 @@ def test_logger_format(tmp_path):
     assert lines[2].strip() == ": again"
     with pytest.raises(TypeError):
         log.add_entry("DEBUG", "x")
+
+
+def test_graft_entry_build_compiles_and_binds():
+    """The driver's build check: __graft_entry__.build() must compile the library in-tree and
+    bind every symbol (no GPU needed)."""
+    import __graft_entry__ as g
+    g.build()
