@@ -67,8 +67,18 @@ constexpr int kMaxTile = 32;     // largest epoch tile (uniformly spaced epochs,
 #endif
 // 4-wide (f32) lanes on the wide layout: 2 rows (8 cells per batch, 166 VGPRs; 4 rows need
 // 256 + AGPR spills); on the compact layout 4 rows still fit 3 waves/SIMD and are 3 % faster
-__host__ __device__ constexpr int unroll_for(int vec, int et, bool compact) {
-  return vec * et >= 16 ? 1 : (vec * et >= 8 ? 2 : (vec == 4 && !compact ? 2 : RJP_UNROLL_BASE));
+// ... and 2 rows in the power-law Gaunt mode, whose T^-1.35 chains are batched by eight cells
+__host__ __device__ constexpr int unroll_for(int vec, int et, bool compact, int mode) {
+  return vec * et >= 16 ? 1
+         : vec * et >= 8 ? 2
+         : vec == 4 && (!compact || mode == RJP_GFF_POWERLAW) ? 2 : RJP_UNROLL_BASE;
+}
+// The fast T^-1.35 (power-law Gaunt mode) is a property of the KERNEL, not of a row batch:
+// the unrolled body and the row tail must evaluate a cell identically, or a scan would depend
+// on where its y-range starts.  The 16- and 32-epoch tiles are register-bound and keep
+// T^-1.5 * pow(T, 0.15), whose libm call lives out of line.
+__host__ __device__ constexpr bool fast_power_law(int vec, int et, bool compact, int mode) {
+  return mode == RJP_GFF_POWERLAW && et <= 8 && unroll_for(vec, et, compact, mode) * vec <= 8;
 }
 
 // number of accumulator planes a tile of ET epochs writes per y-split
@@ -156,9 +166,23 @@ __device__ __forceinline__ void scan_rows(const FieldPtrs<T>& f, int64_t off, in
 
   // temperature powers of the whole batch: T^-1.5 (scalar Gaunt) or T^-1.35 = T^-1.5 * T^0.15
   // (power law)
+  constexpr bool kFastPowerLaw = fast_power_law(VEC, ET, CMP, MODE);
   double tpw[U][VEC];
-  pow_m1p5_batch<U * VEC>(reinterpret_cast<const double (&)[U * VEC]>(tp),
-                          reinterpret_cast<double (&)[U * VEC]>(tpw));
+  if constexpr (kFastPowerLaw && (U * VEC) % 4 == 0 && U * VEC > 4) {
+    // groups of four: the log/exp chains are long, interleaving all eight costs a wave of
+    // occupancy
+#pragma unroll
+    for (int g4 = 0; g4 < U * VEC; g4 += 4) {
+      pow_m1p35_batch<4>(*reinterpret_cast<const double (*)[4]>(&tp[0][0] + g4),
+                         *reinterpret_cast<double (*)[4]>(&tpw[0][0] + g4));
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  } else if constexpr (kFastPowerLaw)
+    pow_m1p35_batch<U * VEC>(reinterpret_cast<const double (&)[U * VEC]>(tp),
+                             reinterpret_cast<double (&)[U * VEC]>(tpw));
+  else
+    pow_m1p5_batch<U * VEC>(reinterpret_cast<const double (&)[U * VEC]>(tp),
+                            reinterpret_cast<double (&)[U * VEC]>(tpw));
 
 #pragma unroll
   for (int u = 0; u < U; ++u) {
@@ -166,7 +190,7 @@ __device__ __forceinline__ void scan_rows(const FieldPtrs<T>& f, int64_t off, in
     for (int v = 0; v < VEC; ++v) {
       const double Tk = tp[u][v];
       double tpow = tpw[u][v];
-      if (MODE == RJP_GFF_POWERLAW) tpow *= pow(Tk, 0.15);
+      if (MODE == RJP_GFF_POWERLAW && !kFastPowerLaw) tpow *= pow(Tk, 0.15);
       // nanmean over T > 0 (classes.py:1471): max(T, 0) adds T, or an exact zero for
       // T <= 0 and NaN
       accT[v] += __builtin_fmax(Tk, 0.0);
@@ -199,7 +223,7 @@ template <typename T, int VEC, int ET, int MODE, bool BURSTS, bool UNIF, bool CM
 __global__ __launch_bounds__(kBlock) void ff_scan_kernel(
     FieldPtrs<T> f, int ny, int nz, int64_t nchunks, int64_t npix, int ylen, BurstsDev b,
     EpochTile<ET> ep, double* __restrict__ ws) {
-  constexpr int kUnroll = unroll_for(VEC, ET, CMP);
+  constexpr int kUnroll = unroll_for(VEC, ET, CMP, MODE);
   const int64_t c = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   const bool lane_live = c < nchunks;
   const int64_t p0 = c * VEC;              // first sightline (pixel) of this lane

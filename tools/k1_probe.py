@@ -10,10 +10,11 @@ from rajepy_amd import engine as E
 cfg, storage = sys.argv[1], sys.argv[2]
 nep = int(sys.argv[3]) if len(sys.argv) > 3 else 1
 want_em = os.environ.get("PROBE_NO_EM") is None
+MODE = E.RJP_GFF_POWERLAW if os.environ.get("PROBE_POWERLAW") else E.RJP_GFF_SCALAR
 shape = bench.CONFIGS[cfg][0]
 eng = E.RTEngine(0)
 dtype = E.RJP_F64 if storage == "f64" else E.RJP_F32
-fields = eng.synth_fields(shape, 20240504, 0, dtype, csize_au=0.5)
+fields = eng.synth_fields(shape, 20240504, 1 if os.environ.get("PROBE_POWERLAW") else 0, dtype, csize_au=0.5)
 ej = bench.EXAMPLE_BURSTS
 red, blue = [], []
 for t0, hl, chi, which in zip(ej["t_0"], ej["hl"], ej["chi"], ej["which"]):
@@ -23,8 +24,8 @@ for t0, hl, chi, which in zip(ej["t_0"], ej["hl"], ej["chi"], ej["which"]):
             lst.append((t0 * bench.YEAR, chi - 1., sig))
 bursts = E.make_bursts(red, blue)
 ep = list(np.linspace(0.5, 4.5, nep) * bench.YEAR)
-eng.time_ff_scan(fields, bursts, ep, E.RJP_GFF_SCALAR, reps=2, want_em=want_em)
-ms = min(eng.time_ff_scan(fields, bursts, ep, E.RJP_GFF_SCALAR, reps=5, want_em=want_em) for _ in range(3))
+eng.time_ff_scan(fields, bursts, ep, MODE, reps=2, want_em=want_em)
+ms = min(eng.time_ff_scan(fields, bursts, ep, MODE, reps=5, want_em=want_em) for _ in range(3))
 n = shape[0] * shape[1] * shape[2]
 npass = -(-nep // (16 if nep >= 16 else 8)) if nep > 1 else 1   # linspace epochs: tiles of 16
 gb = npass * fields.nbytes() / 1e9
