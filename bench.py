@@ -61,6 +61,10 @@ def parse():
     ap.add_argument("--config", default=os.environ.get("RJP_BENCH_CONFIG", "cfg4"),
                     choices=sorted(CONFIGS))
     ap.add_argument("--storage", default="f64", choices=("f64", "f32"))
+    ap.add_argument("--gaunt", default="scalar", choices=("scalar", "powerlaw"),
+                    help="scalar = the q_T == 0 branch (T = 1e4 K, one van Hoof Gaunt factor per "
+                         "channel: the headline); powerlaw = the q_T != 0 branch "
+                         "(T = 5e3 + 1.5e4 u, 11.95 T^0.15 nu^-0.1 per cell), SURVEY.md 8(d)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--sharding", default="epochs", choices=("epochs", "xslab", "channels"),
                     help="N>1: epochs = one epoch of the full grid per rank (weak scaling, the "
@@ -80,12 +84,14 @@ def parse():
     return ap.parse_args()
 
 
-def _oracle_jet(sub, seed):
+def _oracle_jet(sub, seed, plaw=False):
     from oracle import rt_oracle as orc
     from tests import gpu_util as U
-    g = U.synth_host(sub, seed, 0)
+    g = U.synth_host(sub, seed, 1 if plaw else 0)
     p = U.load_golden("cfg1_example")[2]
     p["ejection"] = U.example_bursts_params()
+    if plaw:
+        p["power_laws"]["q_T"] = -0.5            # selects the power-law Gaunt branch
     p["grid"].update(n_x=sub[0], n_y=sub[1], n_z=sub[2])
     jet = orc.OracleJet.from_fields(p, g["nd"], g["xi"], g["temp"], g["ff"], g["areas"],
                                     g["ts"], g["rr"], g["vy"])
@@ -93,7 +99,7 @@ def _oracle_jet(sub, seed):
     return jet
 
 
-def cpu_baseline(shape, freqs, seed, target_s, rrl=None, all_cores=True):
+def cpu_baseline(shape, freqs, seed, target_s, rrl=None, all_cores=True, plaw=False):
     """The CPU oracle (oracle/rt_oracle.py, a literal NumPy restatement of the reference's
     per-channel re-streaming path) timed on a y-truncated block with the same n_x, n_z and a
     subset of the same channels: what Pipeline.execute issues per run -- optical_depth_ff +
@@ -116,7 +122,7 @@ def cpu_baseline(shape, freqs, seed, target_s, rrl=None, all_cores=True):
 
     nyb, dt = 2, 0.0
     for _ in range(4):                       # grow the block until it costs ~target_s
-        dt = run(_oracle_jet((nx, nyb, nz), seed))
+        dt = run(_oracle_jet((nx, nyb, nz), seed, plaw))
         if dt >= 0.6 * target_s or nyb >= ny:
             break
         nyb = int(min(ny, max(nyb + 1, nyb * min(target_s / dt, 64.0))))
@@ -127,7 +133,8 @@ def cpu_baseline(shape, freqs, seed, target_s, rrl=None, all_cores=True):
            "sample": "oracle %s on a %dx%dx%d y-truncated block of the same synthetic grid x "
                      "%d of the channels (%.1f s)" % (what, nx, nyb, nz, nch, dt)}
     if all_cores:
-        out["all_cores"] = cpu_baseline_all_cores((nx, max(2, nyb // 4), nz), sel, seed, rrl)
+        out["all_cores"] = cpu_baseline_all_cores((nx, max(2, nyb // 4), nz), sel, seed, rrl,
+                                                  plaw)
     return out
 
 
@@ -137,7 +144,7 @@ sys.path.insert(0, %(root)r)
 import numpy as np
 import bench
 sub, seed, sel, rrl, t_start = %(sub)r, %(seed)r, np.array(%(sel)r), %(rrl)r, %(t_start)r
-jet = bench._oracle_jet(sub, seed)
+jet = bench._oracle_jet(sub, seed, %(plaw)r)
 ready = time.time()
 time.sleep(max(0.0, t_start - ready))
 if rrl:
@@ -148,7 +155,7 @@ print(json.dumps({"late": ready > t_start, "end": time.time() - t_start}))
 """
 
 
-def cpu_baseline_all_cores(sub, sel, seed, rrl):
+def cpu_baseline_all_cores(sub, sel, seed, rrl, plaw=False):
     """The same oracle calls in one process per host core of this job's CPU share, each on its
     own copy of a (smaller) block, started together: aggregate rate = what a channel-sharded
     process pool of the reference path would reach on this host."""
@@ -160,7 +167,7 @@ def cpu_baseline_all_cores(sub, sel, seed, rrl):
     cores = max(1, min(cores, 16))           # one GPU's share of the box
     t_start = time.time() + 25.0             # children import, build their block, then wait
     code = _CHILD % {"root": ROOT, "sub": tuple(sub), "seed": seed, "sel": [float(x) for x in sel],
-                     "rrl": rrl, "t_start": t_start}
+                     "rrl": rrl, "t_start": t_start, "plaw": bool(plaw)}
     env = dict(os.environ, OMP_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1", MKL_NUM_THREADS="1")
     procs = [subprocess.Popen([sys.executable, "-c", code], stdout=subprocess.PIPE,
                               stderr=subprocess.DEVNULL, text=True, env=env)
@@ -230,7 +237,10 @@ def main():
     ncell_loc = lshape[0] * lshape[1] * lshape[2]
 
     lean = args.config == "cfg4x8"            # generate em0, temp, ts only (24 B/cell)
-    fields = eng.synth_fields(lshape, seed, 0, dtype, csize_au=0.5, with_vy=rrl, cell0=cell0,
+    plaw = args.gaunt == "powerlaw"
+    gmode = E.RJP_GFF_POWERLAW if plaw else E.RJP_GFF_SCALAR
+    fields = eng.synth_fields(lshape, seed, 1 if plaw else 0, dtype, csize_au=0.5, with_vy=rrl,
+                              cell0=cell0,
                               wide=not lean)
     ej = EXAMPLE_BURSTS
     red, blue = [], []
@@ -253,8 +263,8 @@ def main():
         cshards = ChannelShards(freqs, world)
         freqs = cshards.local(rank)
         nchan = len(freqs)
-    gv = [ph.gff(nu, 1e4) for nu in freqs]
-    ctau, cflux = E.ff_channel_coeffs(freqs, 0.5, 120., E.RJP_GFF_SCALAR, gv)
+    gv = None if plaw else [ph.gff(nu, 1e4) for nu in freqs]
+    ctau, cflux = E.ff_channel_coeffs(freqs, 0.5, 120., gmode, gv)
 
     # epochs: cfg5 = its 32 epochs split over the ranks; otherwise one epoch per rank per
     # step (weak scaling over the burst-time sweep)
@@ -280,7 +290,7 @@ def main():
         flux = eng._f64(E_loc, nchan, P)
 
     def step():
-        eng.ff_scan(fields, bursts, my_epochs, E.RJP_GFF_SCALAR, out=(sumA, em, tavg))
+        eng.ff_scan(fields, bursts, my_epochs, gmode, out=(sumA, em, tavg))
         eng.ff_maps(sumA, tavg, ctau, cflux, out=(tau, flux, ftot))
         res = ftot
         if rrl:
@@ -336,7 +346,7 @@ def main():
         alg_bytes = 6 * ncell_loc * int(dtype) + nchan * P * 8
         kname, extra = "rrl_scan_kernel", {"voigt_evals_per_s": ncell_loc * nchan / (k_ms * 1e-3)}
     else:
-        k_ms = eng.time_ff_scan(fields, bursts, my_epochs, E.RJP_GFF_SCALAR, reps=5,
+        k_ms = eng.time_ff_scan(fields, bursts, my_epochs, gmode, reps=5,
                                 want_em=em is not None)
         # epoch tiles share a pass over the grid: 32 uniformly spaced epochs when no EM maps are
         # asked for, 16 with them, else 8 (f64
@@ -376,7 +386,7 @@ def main():
                                    "K3 RRL scan + K1/K2 continuum + line flux cube" if rrl else
                                    "K1 scan + K2 flux-vs-time" if n_ep_cfg else
                                    "K1 scan + K2 tau/flux cubes")),
-                   "storage": args.storage,
+                   "storage": args.storage, "gaunt": args.gaunt,
                    "layout": "compact (3 fields/cell)" if fields.em0 is not None else
                              "wide (5 fields/cell)",
                    "sharding": ("xslab" if xslab else "channels" if chsh else "epochs")
@@ -389,7 +399,7 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(shape, freqs, seed, args.cpu_seconds,
                                               rrl="H66a" if rrl else None,
-                                              all_cores=not args.no_cpu_all_cores)
+                                              all_cores=not args.no_cpu_all_cores, plaw=plaw)
     if rank == 0:
         chk = float(out.sum().item())
         result["checksum_flux_total_jy"] = chk
