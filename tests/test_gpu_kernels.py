@@ -704,7 +704,8 @@ def test_rrl_small_voigt_y_every_lane_layout(eng, nchan, cw, thin):
 
 
 @pytest.mark.parametrize("store", ["f64", "f32"])
-@pytest.mark.parametrize("n_ep,t1", [(32, 5.0), (45, 4.0), (64, 2.0), (33, 0.6)])
+@pytest.mark.parametrize("n_ep,t1", [(32, 5.0), (45, 4.0), (64, 2.0), (33, 0.6),
+                                     (32, 8.0)])      # last: too wide for 32, falls back to 16
 def test_32_epoch_tiles_of_em_less_sweeps_follow_the_oracle(eng, store, n_ep, t1):
     """d_em = NULL and >= 32 uniformly spaced epochs: one pass serves 32 epochs (recurrence
     anchored at the tile's middle epoch).  Against the oracle at every epoch, and against the
