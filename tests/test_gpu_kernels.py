@@ -737,3 +737,30 @@ def test_32_epoch_tiles_of_em_less_sweeps_follow_the_oracle(eng, store, n_ep, t1
     for e in (0, 1, n_ep // 2, 31, n_ep - 1):
         jet.time = ep[e]
         np.testing.assert_allclose(got[e], jet.optical_depth_ff(5e9), rtol=tol)
+
+
+def test_per_call_tables_are_reused_only_when_equal(eng):
+    """The map stage keeps recent coefficient tables on the device and reuses a copy when a
+    call brings the same content: alternate and cycle through more tables than the ring
+    holds (same length, different values) and check every result against its own table."""
+    import torch
+    P = 700
+    A = torch.linspace(0.5, 3.0, P, dtype=torch.float64, device=eng.device).reshape(1, P)
+    tavg = torch.full((P,), 8e3, dtype=torch.float64, device=eng.device)
+    tables = [(np.array([1.0, 2.0, 3.0]) * (k + 1), np.array([0.5, 0.25, 0.125]) * (k + 2))
+              for k in range(11)]
+    order = [0, 1, 0, 0, 2, 3, 4, 5, 6, 7, 8, 9, 10, 0, 1, 10, 0]
+    outs = []
+    for k in order:                                   # no synchronisation between the calls
+        ctau, cflux = tables[k]
+        tau, flux, ftot = eng.ff_maps(A, tavg, ctau, cflux)
+        outs.append((k, tau, flux, ftot))
+    eng.synchronize()
+    a = A.cpu().numpy()[0]
+    for k, tau, flux, ftot in outs:
+        ctau, cflux = tables[k]
+        want_tau = ctau[:, None] * a[None, :]
+        want_flux = cflux[:, None] * (8e3 * (1.0 - np.exp(-want_tau)))
+        np.testing.assert_allclose(tau.cpu().numpy()[0], want_tau, rtol=1e-15)
+        np.testing.assert_allclose(flux.cpu().numpy()[0], want_flux, rtol=1e-13)
+        np.testing.assert_allclose(ftot.cpu().numpy()[0], want_flux.sum(axis=1), rtol=1e-12)
