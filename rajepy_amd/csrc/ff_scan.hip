@@ -6,7 +6,7 @@
 // lane owns VEC adjacent (x,z) sightlines (16 B of every field per load, 1 KiB per
 // wave-instruction, lanes adjacent along the contiguous z-axis), walks y serially with UNROLL
 // rows of loads in flight, evaluates the burst factor chi(t) for a tile of up to 32 epochs in
-// registers and keeps FP64 accumulators.  The y-range is split over gridDim.y so small maps
+// registers and keeps FP64 accumulators.  The y-range is split over workgroups so small maps
 // still fill 256 CUs; partial sums go to a workspace and a tiny second kernel reduces them in
 // a fixed order (bitwise reproducible, no atomics).
 // HBM-bound: algorithmic bytes = 5 fields * sizeof(T) per cell per epoch tile in the wide
@@ -221,13 +221,17 @@ __device__ __forceinline__ void scan_rows(const FieldPtrs<T>& f, int64_t off, in
 // accumulator set: fewer registers, one more wave per SIMD on the 16-epoch tiles.
 template <typename T, int VEC, int ET, int MODE, bool BURSTS, bool UNIF, bool CMP, bool EM>
 __global__ __launch_bounds__(kBlock) void ff_scan_kernel(
-    FieldPtrs<T> f, int ny, int nz, int64_t nchunks, int64_t npix, int ylen, BurstsDev b,
-    EpochTile<ET> ep, double* __restrict__ ws) {
+    FieldPtrs<T> f, int ny, int nz, int64_t nchunks, int64_t npix, int ylen, int nsplit,
+    BurstsDev b, EpochTile<ET> ep, double* __restrict__ ws) {
   constexpr int kUnroll = unroll_for(VEC, ET, CMP, MODE);
-  const int64_t c = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  // 1-D grid with the y-split index fastest: workgroups that run together stream consecutive
+  // y-ranges of the same sightlines, i.e. neighbouring memory, instead of ranges 16 MiB apart
+  // (n_y n_z elements) -- +5 % on cfg4 (6.0 -> 6.3 TB/s)
+  const int split = (int)(blockIdx.x % (unsigned)nsplit);
+  const int64_t c = (int64_t)(blockIdx.x / (unsigned)nsplit) * kBlock + threadIdx.x;
   const bool lane_live = c < nchunks;
   const int64_t p0 = c * VEC;              // first sightline (pixel) of this lane
-  int y0 = blockIdx.y * ylen;
+  int y0 = split * ylen;
   int y1 = min(ny, y0 + ylen);
   if (f.ylo) {
     // sparse models: clip this workgroup's rows to the occupied range of its sightlines
@@ -271,7 +275,7 @@ __global__ __launch_bounds__(kBlock) void ff_scan_kernel(
   }
 
   // partial sums: ws[split][plane][pixel]
-  double* w = ws + (int64_t)blockIdx.y * nacc(ET) * npix + p0;
+  double* w = ws + (int64_t)split * nacc(ET) * npix + p0;
 #pragma unroll
   for (int e = 0; e < ET; ++e) {
 #pragma unroll
@@ -565,24 +569,24 @@ static hipError_t launch_tile(const rjp_fields* fl, const BurstsDev& b, const do
   uniform_tile(t, ET, b, ep.un);
   const int64_t npix = (int64_t)fl->nx * fl->nz;
   const int64_t nchunks = npix / VEC;
-  dim3 grid((unsigned)((nchunks + kBlock - 1) / kBlock), (unsigned)nsplit);
+  dim3 grid((unsigned)(((nchunks + kBlock - 1) / kBlock) * nsplit), 1u);
   // the recurrence pays with at least 4 epochs per tile; short tiles of f32 storage keep
   // their 9-instruction float-accuracy exp instead
   if constexpr (ET == 32) {
     // 32 epochs per pass: recurrence only, and only without the emission-measure accumulators
     if (ep.un.on && !want_em) {
       hipLaunchKernelGGL((ff_scan_kernel<T, VEC, ET, MODE, true, true, CMP, false>), grid,
-                         dim3(kBlock), 0, st, f, fl->ny, fl->nz, nchunks, npix, ylen, b, ep, ws);
+                         dim3(kBlock), 0, st, f, fl->ny, fl->nz, nchunks, npix, ylen, nsplit, b, ep, ws);
       return hipGetLastError();
     }
   } else if constexpr (BURSTS && ET >= 4 && (sizeof(T) == 8 || ET == 16)) {
     if (ep.un.on) {
       if (want_em)
         hipLaunchKernelGGL((ff_scan_kernel<T, VEC, ET, MODE, true, true, CMP, true>), grid,
-                           dim3(kBlock), 0, st, f, fl->ny, fl->nz, nchunks, npix, ylen, b, ep, ws);
+                           dim3(kBlock), 0, st, f, fl->ny, fl->nz, nchunks, npix, ylen, nsplit, b, ep, ws);
       else
         hipLaunchKernelGGL((ff_scan_kernel<T, VEC, ET, MODE, true, true, CMP, false>), grid,
-                           dim3(kBlock), 0, st, f, fl->ny, fl->nz, nchunks, npix, ylen, b, ep, ws);
+                           dim3(kBlock), 0, st, f, fl->ny, fl->nz, nchunks, npix, ylen, nsplit, b, ep, ws);
       return hipGetLastError();
     }
   }
@@ -590,10 +594,10 @@ static hipError_t launch_tile(const rjp_fields* fl, const BurstsDev& b, const do
     // single-epoch and generic tiles always carry the emission measure (cheap there)
     if (want_em || ET < 4)
       hipLaunchKernelGGL((ff_scan_kernel<T, VEC, ET, MODE, BURSTS, false, CMP, true>), grid,
-                         dim3(kBlock), 0, st, f, fl->ny, fl->nz, nchunks, npix, ylen, b, ep, ws);
+                         dim3(kBlock), 0, st, f, fl->ny, fl->nz, nchunks, npix, ylen, nsplit, b, ep, ws);
     else
       hipLaunchKernelGGL((ff_scan_kernel<T, VEC, ET, MODE, BURSTS, false, CMP, false>), grid,
-                         dim3(kBlock), 0, st, f, fl->ny, fl->nz, nchunks, npix, ylen, b, ep, ws);
+                         dim3(kBlock), 0, st, f, fl->ny, fl->nz, nchunks, npix, ylen, nsplit, b, ep, ws);
     return hipGetLastError();
   }
   return hipErrorInvalidValue;       // a 16-epoch tile that is not uniform: launcher bug
