@@ -88,16 +88,20 @@ __host__ __device__ constexpr int nacc(int et) { return 2 * et + 2; }
 // then the burst factors of all U*VEC*ET (cell, epoch) pairs as ONE batch so their exp()
 // polynomial chains interleave (FP64 FMA latency is what limits a single chain), then the
 // accumulation.
-template <typename T, int VEC, int ET, int MODE, bool BURSTS, bool UNIF, bool CMP, bool EM, int U>
-__device__ __forceinline__ void scan_rows(const FieldPtrs<T>& f, int64_t off, int64_t stride,
-                                          const BurstsDev& b, const EpochTile<ET>& ep,
-                                          double (&accA)[ET][VEC],
-                                          double (&accE)[EM ? ET : 1][VEC],
-                                          double (&accT)[VEC], int (&cnt)[VEC]) {
-  // g = (n x)^2 * ff/areas at chi = 1 and the jet flag: from three wide fields or from the
-  // one compact field
-  double g0[U][VEC], tp[U][VEC], ts[U][VEC];
-  bool rj[U][VEC];
+// U rows x VEC sightlines of one lane as they come out of memory
+template <int VEC, int U>
+struct RowBatch {
+  double g0[U][VEC];     // (n x)^2 * ff/areas at chi = 1
+  double tp[U][VEC];     // temperature
+  double ts[U][VEC];     // launch time
+  bool rj[U][VEC];       // red-jet flag
+};
+
+template <typename T, int VEC, bool BURSTS, bool CMP, int U>
+__device__ __forceinline__ void load_rows(const FieldPtrs<T>& f, int64_t off, int64_t stride,
+                                          RowBatch<VEC, U>& rb) {
+  auto& g0 = rb.g0; auto& tp = rb.tp; auto& ts = rb.ts; auto& rj = rb.rj;
+  // g and the jet flag: from three wide fields or from the one compact field
   if constexpr (CMP) {
 #pragma unroll
     for (int u = 0; u < U; ++u) {
@@ -133,7 +137,14 @@ __device__ __forceinline__ void scan_rows(const FieldPtrs<T>& f, int64_t off, in
         rj[u][v] = signbit_d(nd[u][v]);
       }
   }
+}
 
+template <typename T, int VEC, int ET, int MODE, bool BURSTS, bool UNIF, bool CMP, bool EM, int U>
+__device__ __forceinline__ void compute_rows(const RowBatch<VEC, U>& rb, const BurstsDev& b,
+                                             const EpochTile<ET>& ep, double (&accA)[ET][VEC],
+                                             double (&accE)[EM ? ET : 1][VEC],
+                                             double (&accT)[VEC], int (&cnt)[VEC]) {
+  const auto& g0 = rb.g0; const auto& tp = rb.tp; const auto& ts = rb.ts; const auto& rj = rb.rj;
   constexpr int NB = ET * U * VEC;
   double chi[NB];
   if (BURSTS && UNIF) {
@@ -217,6 +228,17 @@ __device__ __forceinline__ void scan_rows(const FieldPtrs<T>& f, int64_t off, in
   }
 }
 
+template <typename T, int VEC, int ET, int MODE, bool BURSTS, bool UNIF, bool CMP, bool EM, int U>
+__device__ __forceinline__ void scan_rows(const FieldPtrs<T>& f, int64_t off, int64_t stride,
+                                          const BurstsDev& b, const EpochTile<ET>& ep,
+                                          double (&accA)[ET][VEC],
+                                          double (&accE)[EM ? ET : 1][VEC],
+                                          double (&accT)[VEC], int (&cnt)[VEC]) {
+  RowBatch<VEC, U> rb;
+  load_rows<T, VEC, BURSTS, CMP, U>(f, off, stride, rb);
+  compute_rows<T, VEC, ET, MODE, BURSTS, UNIF, CMP, EM, U>(rb, b, ep, accA, accE, accT, cnt);
+}
+
 // EM = false (flux-vs-time sweeps: no emission-measure maps wanted) drops the second
 // accumulator set: fewer registers, one more wave per SIMD on the 16-epoch tiles.
 template <typename T, int VEC, int ET, int MODE, bool BURSTS, bool UNIF, bool CMP, bool EM>
@@ -265,6 +287,8 @@ __global__ __launch_bounds__(kBlock) void ff_scan_kernel(
   const int64_t stride = nz;
 
   int y = y0;
+  // (issuing the next half-batch's loads before computing the current one was tried: 165
+  // VGPRs, 3 waves/SIMD, 7 % slower)
   for (; y + kUnroll <= y1; y += kUnroll) {
     scan_rows<T, VEC, ET, MODE, BURSTS, UNIF, CMP, EM, kUnroll>(f, off, stride, b, ep, accA, accE, accT, cnt);
     off += kUnroll * stride;
