@@ -2,24 +2,39 @@
 """Throughput benchmark of the line-of-sight RT hot path on MI355X.
 
     python bench.py --gpus N --steps K --warmup W
-    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+N > 1 without WORLD_SIZE in the environment: this process starts N fresh children itself
+(`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ...
+bench.py <same flags>`), BEFORE anything touches the GPU, relays rank 0's single JSON line and
+exits with the children's status.  Under torch.distributed.run (WORLD_SIZE set) it is one
+rank of the job.
 
 Workload (BASELINE.json, the configuration its metric is quoted on): a 512x4096x512 grid of
 dense synthetic fields (generated on the device), 256 continuum channels
 1-50 GHz, with the example model's four ejection bursts.  One "step" = one pass of the hot
 path over one epoch: K1 (grid scan -> base maps) + K2 (tau and flux cubes for all 256
 channels + per-channel total flux), fields already resident in HBM.
-N > 1 ranks: burst-time epochs shard embarrassingly -- every rank holds the grid (generated
-on its own GPU from the same hash) and processes a different epoch per step; the only
-exchange is an all_gather of the per-channel flux vectors (flux-vs-time) over RCCL.
-Per-GPU work is fixed as N grows -> "scaling": "weak".
 
-Prints ONE JSON line (rank 0) with the driver's contract fields plus `roofline` and
-`cpu_baseline`.
+N > 1 (no data-path collective, one gather/reduce per step over RCCL):
+  cfg4 / cfg2  timed region: burst-time epochs shard embarrassingly -- every rank holds the
+               grid (generated on its own GPU from the same hash) and scans a different epoch
+               per step, flux-vs-time vectors are all_gathered ("scaling": "weak").  The same
+               line carries two more measured legs, each labelled: `strong_xslab` (the ONE
+               grid split into n_x/N row slabs, per-channel fluxes all_reduced) and
+               `channel_sharded` (the north star's frequency-sharded sweep: every rank scans
+               the whole grid and maps F/N channels -- continuum channels share the grid
+               pass, SURVEY finding 2, so this cannot scale the scan).
+  cfg5 / cfg3  x-slabs (strong scaling): every rank keeps the 32-epoch tile / the 256-lane
+               RRL kernel on its n_x/N rows; per-channel fluxes all_reduced.
+
+Prints ONE JSON line (rank 0) with the driver's contract fields plus `roofline`,
+`cpu_baseline` (N = 1), `sustained`, `ranks_seen` and, for N > 1, `n1` and `legs`.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -31,6 +46,7 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0            # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 YEAR = 31536000.0
+SEED = 20240504
 
 CONFIGS = {
     # name: (shape, n_chan, n_epochs_total or None, kind) -- BASELINE.json configs[1..4]
@@ -41,6 +57,7 @@ CONFIGS = {
     # capacity line: 8x the cells of cfg4 on ONE GPU, compact layout only (206 GB of the 288)
     "cfg4x8": ((1024, 8192, 1024), 256, None, "continuum"),
     "tiny": ((16, 64, 64), 8, None, "continuum"),
+    "tiny5": ((16, 64, 64), 8, 32, "continuum"),
     "tiny_rrl": ((8, 64, 64), 40, None, "rrl"),
 }
 
@@ -51,7 +68,7 @@ EXAMPLE_BURSTS = {"t_0": [0.5, 0.75, 1., 2.], "hl": [0.15, 0.15, 0.45, 0.5],
                   "chi": [5., 5., 2.5, 10.], "which": ["R", "B", "B", "RB"]}
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     # defaults: long enough that clock ramp-up and first-touch effects of a fresh box stay in
@@ -61,29 +78,82 @@ def parse():
     ap.add_argument("--config", default=os.environ.get("RJP_BENCH_CONFIG", "cfg4"),
                     choices=sorted(CONFIGS))
     ap.add_argument("--storage", default="f64", choices=("f64", "f32"))
+    ap.add_argument("--layout", default="compact", choices=("compact", "wide"),
+                    help="compact = K1 streams em0, temp, ts (3 fields/cell, the default); "
+                         "wide = nd, xi, temp, pf, ts (5 fields/cell, SURVEY 8(d)'s byte model)")
     ap.add_argument("--gaunt", default="scalar", choices=("scalar", "powerlaw"),
                     help="scalar = the q_T == 0 branch (T = 1e4 K, one van Hoof Gaunt factor per "
                          "channel: the headline); powerlaw = the q_T != 0 branch "
                          "(T = 5e3 + 1.5e4 u, 11.95 T^0.15 nu^-0.1 per cell), SURVEY.md 8(d)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--sharding", default="epochs", choices=("epochs", "xslab", "channels"),
-                    help="N>1: epochs = one epoch of the full grid per rank (weak scaling, the "
-                         "default); xslab = the ONE grid split into n_x/N row slabs (strong "
-                         "scaling, per-channel fluxes all_reduced); channels = the north "
-                         "star's frequency-sharded sweep: every rank scans the whole grid and "
-                         "maps 1/N of the channels (continuum channels share the grid pass, so "
-                         "this cannot scale the scan -- SURVEY finding 2)")
+    ap.add_argument("--sharding", default="auto",
+                    choices=("auto", "epochs", "xslab", "channels"),
+                    help="N>1.  auto = epochs for single-epoch continuum configs (weak scaling, "
+                         "plus the strong_xslab and channel_sharded legs in the same line), "
+                         "xslab for cfg5 / RRL.  epochs = one epoch of the full grid per rank; "
+                         "xslab = the ONE grid split into n_x/N row slabs (strong scaling, "
+                         "per-channel fluxes all_reduced); channels = every rank scans the whole "
+                         "grid and maps 1/N of the channels")
+    ap.add_argument("--no-extra-legs", action="store_true",
+                    help="N>1: skip the additional labelled legs and the N=1 reference")
     ap.add_argument("--backend", default="nccl", choices=("nccl", "gloo"),
                     help="gloo = rehearsal of the N>1 path (e.g. several ranks on one GPU)")
     ap.add_argument("--share-gpu", action="store_true",
                     help="rehearsal only: all ranks use cuda:0")
+    ap.add_argument("--rehearse-cpu", action="store_true",
+                    help="no GPU, no kernels: drive launcher, shard planners and collectives "
+                         "under gloo with placeholder per-rank vectors; the line says "
+                         "\"rehearsal\": true and carries no throughput")
     ap.add_argument("--cpu-seconds", type=float, default=20.0,
                     help="target CPU time of the bounded cpu_baseline sample")
     ap.add_argument("--no-cpu-all-cores", action="store_true",
                     help="skip the one-process-per-core leg of cpu_baseline")
-    return ap.parse_args()
+    ap.add_argument("--sustained-seconds", type=float, default=2.0,
+                    help="length of the back-to-back leg after the contract timing (0 = skip)")
+    ap.add_argument("--no-api-level", action="store_true",
+                    help="skip the PCIe-inclusive leg (step + copy of the cubes to pinned host)")
+    return ap.parse_args(argv)
 
 
+# ---------------------------------------------------------------------------------------
+# self-launch (N > 1, plain `python bench.py --gpus N`)
+# ---------------------------------------------------------------------------------------
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def self_launch(args, argv):
+    """Start N ranks of this script under torch.distributed.run as CHILD processes (this
+    process never touches a GPU), relay rank 0's JSON line.  Returns the exit status."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
+           "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True, env=env)
+    line = None
+    for raw in proc.stdout:
+        if raw.startswith('{"metric"'):
+            line = raw.strip()                 # the contract line: relayed once, at the end
+        else:
+            sys.stderr.write(raw)              # anything else a rank printed
+    rc = proc.wait()
+    if line is not None:
+        print(line, flush=True)
+    elif rc == 0:
+        print("bench.py: the ranks exited cleanly but printed no result line", file=sys.stderr)
+        rc = 1
+    return rc
+
+
+# ---------------------------------------------------------------------------------------
+# CPU baseline (the oracle, timed on the host; rank 0 at N = 1 only)
+# ---------------------------------------------------------------------------------------
 def _oracle_jet(sub, seed, plaw=False):
     from oracle import rt_oracle as orc
     from tests import gpu_util as U
@@ -159,7 +229,6 @@ def cpu_baseline_all_cores(sub, sel, seed, rrl, plaw=False):
     """The same oracle calls in one process per host core of this job's CPU share, each on its
     own copy of a (smaller) block, started together: aggregate rate = what a channel-sharded
     process pool of the reference path would reach on this host."""
-    import subprocess
     try:
         cores = len(os.sched_getaffinity(0))
     except AttributeError:
@@ -191,26 +260,248 @@ def cpu_baseline_all_cores(sub, sel, seed, rrl, plaw=False):
                                                                len(sel), max(ends))}
 
 
-def main():
-    args = parse()
+# ---------------------------------------------------------------------------------------
+# shard plan (pure: shared by the GPU path and the CPU rehearsal)
+# ---------------------------------------------------------------------------------------
+def resolve_sharding(args, world):
+    """The sharding the TIMED region uses."""
+    _, _, n_ep_cfg, kind = CONFIGS[args.config]
+    if world == 1:
+        return "none"
+    if args.sharding != "auto":
+        if args.sharding == "channels" and kind == "rrl":
+            return "xslab"
+        return args.sharding
+    return "xslab" if (n_ep_cfg or kind == "rrl") else "epochs"
+
+
+def plan(config, sharding, rank, world):
+    """Local grid shape, first flat cell, local channel slice and local epochs of one rank."""
+    from rajepy_amd.parallel import ChannelShards, EpochShards, SlabShards
+    shape, nchan, n_ep_cfg, kind = CONFIGS[config]
+    rrl = kind == "rrl"
+    if rrl:
+        from rajepy_amd.maths import rrls
+        nu_rest = rrls.line_constants("H66a")["nu_rest"]
+        freqs = nu_rest - nchan * 1e5 / 2. + 1e5 / 2. + np.arange(nchan) * 1e5
+    else:
+        freqs = np.geomspace(1e9, 5e10, nchan)
+    lshape, cell0 = shape, 0
+    if sharding == "xslab":
+        x0, x1 = SlabShards(shape[0], world).bounds[rank]
+        lshape, cell0 = (x1 - x0, shape[1], shape[2]), x0 * shape[1] * shape[2]
+    cshards = None
+    my_freqs = freqs
+    if sharding == "channels":
+        cshards = ChannelShards(freqs, world)
+        my_freqs = cshards.local(rank)
+    # epochs: cfg5 = its 32 uniformly spaced epochs; otherwise one epoch per rank per step
+    # under epoch sharding (weak scaling over the burst-time sweep), else the single epoch
+    if n_ep_cfg:
+        epochs = np.linspace(0., 5., n_ep_cfg) * YEAR
+    elif sharding == "epochs":
+        epochs = np.linspace(0., 5., world) * YEAR
+    else:
+        epochs = np.array([1.0 * YEAR])
+    eshards = EpochShards(epochs, world if sharding == "epochs" else 1)
+    my_epochs = [float(t) for t in eshards.local(rank if sharding == "epochs" else 0)]
+    return {"shape": shape, "lshape": lshape, "cell0": cell0, "freqs": freqs,
+            "my_freqs": my_freqs, "cshards": cshards, "eshards": eshards,
+            "my_epochs": my_epochs, "rrl": rrl, "n_ep_cfg": n_ep_cfg, "sharding": sharding}
+
+
+GATHER = {"none": "none", "epochs": "all_gather of flux-vs-time [E,F]",
+          "xslab": "all_reduce of per-channel fluxes [E,F]",
+          "channels": "all_gather of per-channel fluxes along F"}
+
+
+def collect(res, pl, rank, world, backend):
+    """The one collective of a step: per-rank flux vectors -> the whole job's [E, F]."""
+    import torch.distributed as dist
+    from rajepy_amd.parallel import all_gather_blocks, gather_flux_vs_time
+    sh = pl["sharding"]
+    if world == 1 or sh == "none":
+        return res
+    if sh == "channels":                  # [E, F/N] per rank -> [E, F]
+        return all_gather_blocks(res, pl["cshards"], rank, axis=1)
+    if sh == "xslab":                     # partial per-channel fluxes of this slab -> totals
+        if backend == "nccl" or not res.is_cuda:
+            dist.all_reduce(res)
+            return res
+        tmp = res.cpu()
+        dist.all_reduce(tmp)
+        return tmp.to(res.device)
+    return gather_flux_vs_time(res, pl["eshards"], rank)
+
+
+# ---------------------------------------------------------------------------------------
+# CPU rehearsal of the N > 1 plumbing (no GPU, no kernels, no throughput)
+# ---------------------------------------------------------------------------------------
+def rehearse_cpu(args, rank, world):
+    import torch
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    legs = {}
+    main_sh = resolve_sharding(args, world)
+    order = [main_sh]
+    if world > 1 and main_sh == "epochs" and not args.no_extra_legs:
+        order += ["xslab", "channels"]
+    for sh in order:
+        pl = plan(args.config, sh, rank, world)
+        nx = pl["shape"][0]
+        E_tot = pl["eshards"].n_epochs if sh == "epochs" else len(pl["my_epochs"])
+        F_tot = len(pl["freqs"])
+        # placeholder "flux" of epoch e, channel f, summed over the rows a rank owns
+        full = (1.0 + np.arange(E_tot))[:, None] * 1e-3 + np.arange(F_tot)[None, :] * 1e-6
+        if sh == "epochs":
+            loc = full[pl["eshards"].slice(rank)]
+        elif sh == "channels":
+            loc = full[:, pl["cshards"].slice(rank)]
+        elif sh == "xslab":
+            loc = full * (pl["lshape"][0] / nx)
+        else:
+            loc = full
+        for _ in range(args.warmup + args.steps):
+            out = collect(torch.from_numpy(np.ascontiguousarray(loc)).clone(), pl, rank, world,
+                          "gloo")
+        ok = bool(np.allclose(out.numpy(), full, rtol=1e-12, atol=0))
+        legs[sh] = {"ok": ok, "shape": list(out.shape), "gather": GATHER[sh]}
+    seen = torch.ones(1, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(seen)
+        dist.barrier()
+    result = {"metric": "Mvoxel-freq/s", "value": None, "unit": "Mvoxel-freq/s",
+              "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": None,
+              "higher_is_better": True, "scaling": "weak" if main_sh in ("epochs", "none")
+              else "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+              "rehearsal": True, "ranks_seen": int(seen.item()),
+              "config": {"workload": args.config + " (CPU rehearsal of launcher, planners and "
+                                                   "collectives; no kernels run)",
+                         "sharding": main_sh, "gather": GATHER[main_sh]},
+              "legs": legs}
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+    return 0 if all(v["ok"] for v in legs.values()) and result["ranks_seen"] == world else 1
+
+
+# ---------------------------------------------------------------------------------------
+# the GPU workload of one rank under one sharding
+# ---------------------------------------------------------------------------------------
+class Workload:
+    def __init__(self, eng, args, sharding, rank, world):
+        from rajepy_amd import _lib, engine as E
+        from rajepy_amd.maths import physics as ph, rrls
+        self.eng, self.args, self.rank, self.world = eng, args, rank, world
+        self.pl = pl = plan(args.config, sharding, rank, world)
+        self.rrl = pl["rrl"]
+        self.dtype = E.RJP_F64 if args.storage == "f64" else E.RJP_F32
+        self.plaw = args.gaunt == "powerlaw"
+        self.gmode = E.RJP_GFF_POWERLAW if self.plaw else E.RJP_GFF_SCALAR
+        lshape = pl["lshape"]
+        self.P = lshape[0] * lshape[2]
+        self.ncell_loc = lshape[0] * lshape[1] * lshape[2]
+        lean = args.config == "cfg4x8"            # generate em0, temp, ts only (24 B/cell)
+        self.fields = eng.synth_fields(lshape, SEED, 1 if self.plaw else 0, self.dtype,
+                                       csize_au=0.5, with_vy=self.rrl, cell0=pl["cell0"],
+                                       wide=not lean)
+        self._em0 = self.fields.em0
+        if args.layout == "wide":
+            self.fields.em0 = None
+        ej = EXAMPLE_BURSTS
+        red, blue = [], []
+        for t0, hl, chi, which in zip(ej["t_0"], ej["hl"], ej["chi"], ej["which"]):
+            sig = hl * YEAR * 2. / (2. * np.sqrt(2. * np.log(2.)))
+            for jet, lst in (("R", red), ("B", blue)):
+                if jet in str(which):
+                    lst.append((t0 * YEAR, chi - 1., sig))
+        self.bursts = E.make_bursts(red, blue)
+        freqs = pl["my_freqs"]
+        self.nchan = len(freqs)
+        if self.rrl:
+            self.line = _lib.Line(**rrls.line_constants("H66a"))
+            self.cfl_rrl, self.hnu_k = E.rrl_channel_coeffs(freqs, 0.5, 120.)
+        gv = None if self.plaw else [ph.gff(nu, 1e4) for nu in freqs]
+        self.ctau, self.cflux = E.ff_channel_coeffs(freqs, 0.5, 120., self.gmode, gv)
+        self.freqs = freqs
+        self.my_epochs = pl["my_epochs"]
+        E_loc = self.E_loc = len(self.my_epochs)
+        self.sumA = eng._f64(E_loc, self.P)
+        # flux-vs-time sweeps (cfg5) ask for no emission-measure maps, as
+        # parallel.sweep_flux_vs_time
+        self.em = None if pl["n_ep_cfg"] else eng._f64(E_loc, self.P)
+        self.tavg = eng._f64(self.P)
+        self.ftot = eng._f64(E_loc, self.nchan)
+        if pl["n_ep_cfg"]:
+            self.tau = self.flux = None       # flux-vs-time output: maps reduced on the device
+        else:
+            self.tau = eng._f64(E_loc, self.nchan, self.P)
+            self.flux = eng._f64(E_loc, self.nchan, self.P)
+
+    @property
+    def total_epochs(self):
+        pl = self.pl
+        return pl["eshards"].n_epochs if pl["sharding"] == "epochs" else self.E_loc
+
+    def local_step(self):
+        """The hot path on this rank's shard; returns its per-channel fluxes [E_loc, F_loc]."""
+        eng = self.eng
+        eng.ff_scan(self.fields, self.bursts, self.my_epochs, self.gmode,
+                    out=(self.sumA, self.em, self.tavg))
+        eng.ff_maps(self.sumA, self.tavg, self.ctau, self.cflux,
+                    out=(self.tau, self.flux, self.ftot))
+        res = self.ftot
+        if self.rrl:
+            tau_rrl = eng.rrl_scan(self.fields, self.bursts, self.my_epochs[0], self.line,
+                                   self.freqs)
+            _, res = eng.rrl_maps(tau_rrl, self.tau.reshape(self.nchan, self.P), self.tavg,
+                                  self.flux.reshape(self.nchan, self.P), self.cfl_rrl,
+                                  self.hnu_k)
+            res = res.reshape(1, self.nchan)
+        return res
+
+    def step(self):
+        return collect(self.local_step(), self.pl, self.rank, self.world, self.args.backend)
+
+    def release(self):
+        self.fields = self._em0 = self.sumA = self.em = self.tau = self.flux = None
+        import torch
+        torch.cuda.empty_cache()
+
+
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else argv
+    args = parse(argv)
+    world_env = os.environ.get("WORLD_SIZE")
+    if args.gpus > 1 and world_env is None:
+        # plain `python bench.py --gpus N`: become the launcher.  Nothing above imported torch
+        # or touched a GPU, and the ranks are children, not a re-exec of this process.
+        sys.exit(self_launch(args, argv))
     rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    world = int(world_env or "1")
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         if rank == 0:
-            print("bench.py: --gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)"
-                  % (args.gpus, world), file=sys.stderr)
+            print("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world), file=sys.stderr)
         sys.exit(2)
+    if args.rehearse_cpu:
+        sys.exit(rehearse_cpu(args, rank, world))
 
     import torch
     import torch.distributed as dist
-    from rajepy_amd import _lib, engine as E
-    from rajepy_amd.maths import physics as ph, rrls
-    from rajepy_amd.parallel import (ChannelShards, EpochShards, SlabShards,
-                                     all_gather_blocks, gather_flux_vs_time)
+    from rajepy_amd import engine as E
 
     if args.share_gpu:
         local = 0
+    ndev = torch.cuda.device_count()
+    if local >= ndev:
+        print("bench.py: rank %d needs cuda:%d but %d device(s) are visible (one process per "
+              "GPU; --share-gpu --backend gloo rehearses several ranks on one)"
+              % (rank, local, ndev), file=sys.stderr)
+        sys.exit(2)
     torch.cuda.set_device(local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -220,165 +511,222 @@ def main():
         else:
             dist.init_process_group("gloo", rank=rank, world_size=world)
     eng = E.RTEngine(local)
-    shape, nchan, n_ep_cfg, kind = CONFIGS[args.config]
-    dtype = E.RJP_F64 if args.storage == "f64" else E.RJP_F32
-    seed = 20240504
+    shape, nchan_total, n_ep_cfg, kind = CONFIGS[args.config]
     ncell = shape[0] * shape[1] * shape[2]          # cells of the whole grid
     rrl = kind == "rrl"
-    xslab = args.sharding == "xslab" and world > 1
-    chsh = args.sharding == "channels" and world > 1 and not rrl
-    if xslab:
-        x0, x1 = SlabShards(shape[0], world).bounds[rank]
-        lshape = (x1 - x0, shape[1], shape[2])
-        cell0 = x0 * shape[1] * shape[2]
-    else:
-        lshape, cell0 = shape, 0
-    P = lshape[0] * lshape[2]
-    ncell_loc = lshape[0] * lshape[1] * lshape[2]
-
-    lean = args.config == "cfg4x8"            # generate em0, temp, ts only (24 B/cell)
-    plaw = args.gaunt == "powerlaw"
-    gmode = E.RJP_GFF_POWERLAW if plaw else E.RJP_GFF_SCALAR
-    fields = eng.synth_fields(lshape, seed, 1 if plaw else 0, dtype, csize_au=0.5, with_vy=rrl,
-                              cell0=cell0,
-                              wide=not lean)
-    ej = EXAMPLE_BURSTS
-    red, blue = [], []
-    for t0, hl, chi, which in zip(ej["t_0"], ej["hl"], ej["chi"], ej["which"]):
-        sig = hl * YEAR * 2. / (2. * np.sqrt(2. * np.log(2.)))
-        for jet, lst in (("R", red), ("B", blue)):
-            if jet in str(which):
-                lst.append((t0 * YEAR, chi - 1., sig))
-    bursts = E.make_bursts(red, blue)
-
-    if rrl:
-        line_c = rrls.line_constants("H66a")
-        line = _lib.Line(**line_c)
-        freqs = line_c["nu_rest"] - nchan * 1e5 / 2. + 1e5 / 2. + np.arange(nchan) * 1e5
-        cfl_rrl, hnu_k = E.rrl_channel_coeffs(freqs, 0.5, 120.)
-    else:
-        freqs = np.geomspace(1e9, 5e10, nchan)
-    nchan_total = nchan
-    if chsh:                      # this rank's slice of the channel list
-        cshards = ChannelShards(freqs, world)
-        freqs = cshards.local(rank)
-        nchan = len(freqs)
-    gv = None if plaw else [ph.gff(nu, 1e4) for nu in freqs]
-    ctau, cflux = E.ff_channel_coeffs(freqs, 0.5, 120., gmode, gv)
-
-    # epochs: cfg5 = its 32 epochs split over the ranks; otherwise one epoch per rank per
-    # step (weak scaling over the burst-time sweep)
-    if n_ep_cfg:
-        epochs = np.linspace(0., 5., n_ep_cfg) * YEAR
-    elif xslab or chsh:
-        epochs = np.array([1.0 * YEAR])
-    else:
-        epochs = np.linspace(0., 5., world) * YEAR if world > 1 else np.array([1.0 * YEAR])
-    shards = EpochShards(epochs, 1 if (xslab or chsh) else world)
-    my_epochs = [float(t) for t in shards.local(0 if (xslab or chsh) else rank)]
-    E_loc = len(my_epochs)
-
-    sumA = eng._f64(E_loc, P)
-    # flux-vs-time sweeps (cfg5) ask for no emission-measure maps, as parallel.sweep_flux_vs_time
-    em = None if n_ep_cfg else eng._f64(E_loc, P)
-    tavg = eng._f64(P)
-    ftot = eng._f64(E_loc, nchan)
-    if n_ep_cfg:
-        tau = flux = None                   # flux-vs-time output: maps reduced on the device
-    else:
-        tau = eng._f64(E_loc, nchan, P)
-        flux = eng._f64(E_loc, nchan, P)
-
-    def step():
-        eng.ff_scan(fields, bursts, my_epochs, gmode, out=(sumA, em, tavg))
-        eng.ff_maps(sumA, tavg, ctau, cflux, out=(tau, flux, ftot))
-        res = ftot
-        if rrl:
-            tau_rrl = eng.rrl_scan(fields, bursts, my_epochs[0], line, freqs)
-            _, res = eng.rrl_maps(tau_rrl, tau.reshape(nchan, P), tavg, flux.reshape(nchan, P),
-                                  cfl_rrl, hnu_k)
-            res = res.reshape(1, nchan)
-        if chsh:                  # [1, F/N] per rank -> [1, F]
-            return all_gather_blocks(res, cshards, rank, axis=1)
-        if xslab:                 # partial per-channel fluxes of this slab -> whole-map totals
-            if args.backend == "nccl":
-                dist.all_reduce(res)
-            else:
-                tmp = res.cpu()
-                dist.all_reduce(tmp)
-                res = tmp.to(res.device)
-            return res
-        return gather_flux_vs_time(res, shards, rank) if world > 1 else res
 
     def fence():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = step()
-    fence()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        tmax = torch.tensor([dt], dtype=torch.float64,
-                            device=eng.device if args.backend == "nccl" else "cpu")
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
-    ms_step = dt / args.steps * 1e3
-    total_epochs = shards.n_epochs
-    value = ncell * nchan_total * total_epochs / (ms_step * 1e-3) / 1e6
+    def max_over_ranks(dt):
+        if world == 1:
+            return dt
+        t = torch.tensor([dt], dtype=torch.float64,
+                         device=eng.device if args.backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
 
-    # dominant kernel, timed live with HIP events on the launch stream
+    def timed(step, steps, warmup):
+        out = None
+        for _ in range(warmup):
+            out = step()
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            out = step()
+        fence()
+        return max_over_ranks(time.perf_counter() - t0), out
+
+    def rate(ms_step, epochs):
+        return ncell * nchan_total * epochs / (ms_step * 1e-3) / 1e6
+
+    # ---- the contract's timed region ---------------------------------------------------
+    sharding = resolve_sharding(args, world)
+    wl = Workload(eng, args, sharding, rank, world)
+    dt, out = timed(wl.step, args.steps, args.warmup)
+    ms_step = dt / args.steps * 1e3
+    total_epochs = wl.total_epochs
+    value = rate(ms_step, total_epochs)
+    chk = float(out.sum().item())
+
+    # every rank really took part: an all_reduce of ones over the job's process group
+    ranks_seen = 1
+    if world > 1:
+        ones = torch.ones(1, dtype=torch.float64,
+                          device=eng.device if args.backend == "nccl" else "cpu")
+        dist.all_reduce(ones)
+        ranks_seen = int(ones.item())
+
+    # ---- sustained leg: >= 2 s of back-to-back steps (clock / power droop would show) ----
+    sustained = None
+    if args.sustained_seconds > 0:
+        n_sus = int(min(20000, max(3, np.ceil(args.sustained_seconds * 1e3 / ms_step))))
+        dts, _ = timed(wl.step, n_sus, 0)
+        sustained = {"steps": n_sus, "seconds": dts, "ms_per_step": dts / n_sus * 1e3,
+                     "value": rate(dts / n_sus * 1e3, total_epochs)}
+
+    # ---- dominant kernel, timed live with HIP events on the launch stream ---------------
+    fields = wl.fields
+    dsz = int(wl.dtype)
+    E_loc, P, ncell_loc = wl.E_loc, wl.P, wl.ncell_loc
+    roof_extra = {}
     if rrl:
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         ev0.record()
         for _ in range(2):
-            eng.rrl_scan(fields, bursts, my_epochs[0], line, freqs)
+            eng.rrl_scan(fields, wl.bursts, wl.my_epochs[0], wl.line, wl.freqs)
         ev1.record()
         torch.cuda.synchronize()
         k_ms = ev0.elapsed_time(ev1) / 2
         # K3 is vector-ALU bound by construction (SURVEY.md finding 3): report its HBM rate
         # against the HBM peak anyway and the Voigt-evaluation rate beside it
-        alg_bytes = 6 * ncell_loc * int(dtype) + nchan * P * 8
-        kname, extra = "rrl_scan_kernel", {"voigt_evals_per_s": ncell_loc * nchan / (k_ms * 1e-3)}
+        alg_bytes = 6 * ncell_loc * dsz + wl.nchan * P * 8
+        alg_8d = alg_bytes
+        kname = "rrl_scan_kernel"
+        roof_extra = {"voigt_evals_per_s": ncell_loc * wl.nchan / (k_ms * 1e-3),
+                      "fp64_vector_peak_lane_ops_per_s": 256 * 4 * 16 * 2.4e9}
     else:
-        k_ms = eng.time_ff_scan(fields, bursts, my_epochs, gmode, reps=5,
-                                want_em=em is not None)
-        # epoch tiles share a pass over the grid: 32 uniformly spaced epochs when no EM maps are
-        # asked for, 16 with them, else 8 (f64
-        # lanes) or 4 (f32 lanes)
-        tile = (32 if (E_loc >= 32 and em is None) else 16 if E_loc >= 16 else
+        want_em = wl.em is not None
+        k_ms = eng.time_ff_scan(fields, wl.bursts, wl.my_epochs, wl.gmode, reps=5,
+                                want_em=want_em)
+        # epoch tiles share a pass over the grid: 32 uniformly spaced epochs when no EM maps
+        # are asked for, 16 with them, else 8 (f64 lanes) or 4 (f32 lanes)
+        tile = (32 if (E_loc >= 32 and not want_em) else 16 if E_loc >= 16 else
                 (8 if args.storage == "f64" else 4))
         npass = -(-E_loc // tile) if E_loc > 1 else 1
-        # fields K1 streams per cell: em0, temp, ts in the compact f64 layout (DESIGN.md
-        # "Data layout"), else nd, xi, temp, pf, ts
+        # fields K1 streams per cell: em0, temp, ts in the compact layout (DESIGN.md "Data
+        # layout"), else nd, xi, temp, pf, ts
         nfld = 3 if fields.em0 is not None else 5
-        alg_bytes = npass * nfld * ncell_loc * int(dtype) + E_loc * P * 2 * 8
-        kname, extra = "ff_scan_kernel", {"grid_passes_per_launch": npass,
-                                          "fields_streamed_per_cell": nfld}
+        base_maps = E_loc * P * 2 * 8
+        alg_bytes = npass * nfld * ncell_loc * dsz + base_maps
+        # SURVEY 8(d)'s byte model: 5 fields per cell (per grid pass of this launch)
+        alg_8d = npass * 5 * ncell_loc * dsz + base_maps
+        kname = "ff_scan_kernel"
+        roof_extra = {"grid_passes_per_launch": npass, "fields_streamed_per_cell": nfld,
+                      "epochs_per_launch": E_loc}
+        if n_ep_cfg:
+            # 8(d) prices one grid pass PER EPOCH; the fused tiles make `npass` passes serve
+            # E_loc epochs -- both figures, as 8(d) asks
+            roof_extra["algorithmic_bytes_8d_unfused"] = E_loc * 5 * ncell_loc * dsz + base_maps
+        if nfld == 3 and fields.nd is not None:
+            # the 8(d) bytes are what the WIDE layout moves: time that kernel on the same
+            # fields, and the one-off pass that derives the compact field from them
+            em0, fields.em0 = fields.em0, None
+            wide_ms = eng.time_ff_scan(fields, wl.bursts, wl.my_epochs, wl.gmode, reps=3,
+                                       want_em=want_em)
+            ev0, ev1 = (torch.cuda.Event(enable_timing=True),
+                        torch.cuda.Event(enable_timing=True))
+            eng.compact(fields)
+            torch.cuda.synchronize()
+            ev0.record()
+            eng.compact(fields)
+            ev1.record()
+            torch.cuda.synchronize()
+            build_ms = ev0.elapsed_time(ev1)
+            fields.em0 = em0
+            roof_extra.update({
+                "wide_ms_per_launch": wide_ms, "layout_build_ms": build_ms,
+                "frac_8d": alg_8d / (wide_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                "frac_8d_kernel": "the wide-layout ff_scan_kernel (5 fields/cell), timed live "
+                                  "on the same fields",
+                "first_epoch_from_wide_fields_ms": {"compact": build_ms + k_ms,
+                                                    "wide": wide_ms}})
+        elif nfld == 5:
+            roof_extra["frac_8d"] = alg_8d / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
     achieved = alg_bytes / (k_ms * 1e-3) / 1e9
-    traffic = None
-    pmc = os.path.join(ROOT, "profiles", "r01_%s_%s_pmc.json" % (args.config, args.storage))
-    if os.path.exists(pmc):
-        try:
-            traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
-        except Exception:
-            traffic = None
+    traffic, traffic_source = None, None
+    for rnd in ("r02", "r01"):
+        rel = os.path.join("profiles", "%s_%s_%s_pmc.json" % (rnd, args.config, args.storage))
+        if nfld_is_wide(roof_extra):
+            rel = rel.replace("_pmc.json", "_wide5_pmc.json")
+        if os.path.exists(os.path.join(ROOT, rel)):
+            try:
+                traffic = json.load(open(os.path.join(ROOT, rel))).get("hbm_bytes_per_launch")
+                traffic_source = rel + " (rocprofv3 --pmc passes of an earlier run of this " \
+                                       "command, not measured in this run)"
+            except Exception:
+                traffic = None
+            break
     roofline = {"bound": "hbm", "kernel": kname, "achieved": achieved,
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                "traffic": traffic, "ms_per_launch": k_ms, "algorithmic_bytes": alg_bytes}
-    roofline.update(extra)
+                "traffic": traffic, "traffic_source": traffic_source,
+                "ms_per_launch": k_ms, "algorithmic_bytes": alg_bytes,
+                "algorithmic_bytes_8d": alg_8d}
+    roofline.update(roof_extra)
+    if not rrl:
+        # whole step = K1 + K2: the bytes both really move against the step's wall time
+        k2_bytes = 0 if wl.tau is None else E_loc * wl.nchan * P * 16
+        roofline["step"] = {"bytes": alg_bytes + k2_bytes, "per": "rank",
+                            "achieved": (alg_bytes + k2_bytes) / (ms_step * 1e-3) / 1e9}
+        roofline["step"]["frac"] = roofline["step"]["achieved"] / HBM_PEAK_GBS
+
+    # ---- PCIe-inclusive figure: what a caller who wants NumPy cubes waits for ------------
+    api_level = None
+    if world == 1 and wl.tau is not None and not args.no_api_level:
+        try:
+            ht = torch.empty(wl.tau.shape, dtype=torch.float64, pin_memory=True)
+            hf = torch.empty(wl.flux.shape, dtype=torch.float64, pin_memory=True)
+
+            def api_step():
+                wl.local_step()
+                ht.copy_(wl.tau, non_blocking=True)
+                hf.copy_(wl.flux, non_blocking=True)
+                return wl.ftot
+            n_api = 3
+            dta, _ = timed(api_step, n_api, 1)
+            api_level = {"ms_per_step": dta / n_api * 1e3,
+                         "value": rate(dta / n_api * 1e3, total_epochs),
+                         "what": "step + device->pinned-host copy of the tau and flux cubes "
+                                 "(%.2f GB); never `value`"
+                                 % ((ht.numel() + hf.numel()) * 8 / 1e9)}
+            del ht, hf
+        except RuntimeError as exc:
+            api_level = {"error": str(exc)[:200]}
+
+    # ---- N > 1: the other labelled legs and the N = 1 reference --------------------------
+    legs, n1 = {}, None
+    if world > 1 and not args.no_extra_legs:
+        wl.release()
+        if sharding == "epochs":
+            for name, sh in (("strong_xslab", "xslab"), ("channel_sharded", "channels")):
+                w2 = Workload(eng, args, sh, rank, world)
+                dt2, _ = timed(w2.step, args.steps, args.warmup)
+                ms2 = dt2 / args.steps * 1e3
+                legs[name] = {"sharding": sh, "scaling": "strong", "ms_per_step": ms2,
+                              "value": rate(ms2, w2.total_epochs), "gather": GATHER[sh],
+                              "epochs_per_step": w2.total_epochs}
+                w2.release()
+            legs["channel_sharded"]["note"] = (
+                "every rank scans the whole grid (continuum channels share the grid pass, "
+                "SURVEY finding 2): only the map stage is divided")
+        # the one-GPU workload on rank 0 alone, no collective: the N = 1 value of this box
+        if rank == 0:
+            w1 = Workload(eng, args, "none", 0, 1)
+            for _ in range(args.warmup):
+                w1.local_step()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                w1.local_step()
+            torch.cuda.synchronize()
+            ms1 = (time.perf_counter() - t0) / args.steps * 1e3
+            n1 = {"ms_per_step": ms1, "value": rate(ms1, w1.total_epochs),
+                  "what": "the N=1 workload on rank 0 alone while the other ranks wait"}
+            w1.release()
+        dist.barrier()
+        for leg in legs.values():
+            if n1:
+                leg["speedup_vs_n1"] = leg["value"] / n1["value"]
 
     result = {
         "metric": "Mvoxel-freq/s", "value": value, "unit": "Mvoxel-freq/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": ms_step, "higher_is_better": True,
-        "scaling": "strong" if (n_ep_cfg or xslab or chsh) else "weak",
-        "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "scaling": "weak" if sharding in ("epochs", "none") and not n_ep_cfg else "strong",
+        "vs_baseline": None, "dtype": "f64", "storage_dtype": args.storage,
+        "data": "synthetic",
         "config": {"workload": "%s: %dx%dx%d grid x %d %s, %d epoch(s) per step, %s"
                                % ((args.config,) + shape + (
                                    nchan_total, "H66a channels of 100 kHz" if rrl else
@@ -387,25 +735,36 @@ def main():
                                    "K1 scan + K2 flux-vs-time" if n_ep_cfg else
                                    "K1 scan + K2 tau/flux cubes")),
                    "storage": args.storage, "gaunt": args.gaunt,
-                   "layout": "compact (3 fields/cell)" if fields.em0 is not None else
-                             "wide (5 fields/cell)",
-                   "sharding": ("xslab" if xslab else "channels" if chsh else "epochs")
-                   if world > 1 else "none",
-                   "gather": ("all_reduce of per-channel fluxes [E,F]" if xslab else
-                              "all_gather of per-channel fluxes along F" if chsh else
-                              "all_gather of flux-vs-time [E,F]") if world > 1 else "none"},
+                   "arithmetic": "f64 accumulation and transcendental functions; storage "
+                                 "dtype of the 3-D fields as given",
+                   "layout": "compact (3 fields/cell)" if roof_extra.get(
+                       "fields_streamed_per_cell", 5) == 3 else "wide (5 fields/cell)",
+                   "sharding": sharding, "gather": GATHER[sharding]},
+        "ranks_seen": ranks_seen,
         "roofline": roofline,
     }
+    if sustained:
+        result["sustained"] = sustained
+    if api_level:
+        result["api_level"] = api_level
+    if legs:
+        result["legs"] = legs
+    if n1:
+        result["n1"] = n1
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        result["cpu_baseline"] = cpu_baseline(shape, freqs, seed, args.cpu_seconds,
+        result["cpu_baseline"] = cpu_baseline(shape, wl.pl["freqs"], SEED, args.cpu_seconds,
                                               rrl="H66a" if rrl else None,
-                                              all_cores=not args.no_cpu_all_cores, plaw=plaw)
+                                              all_cores=not args.no_cpu_all_cores,
+                                              plaw=wl.plaw)
     if rank == 0:
-        chk = float(out.sum().item())
         result["checksum_flux_total_jy"] = chk
-        print(json.dumps(result))
+        print(json.dumps(result), flush=True)
     if world > 1:
         dist.destroy_process_group()
+
+
+def nfld_is_wide(roof_extra):
+    return roof_extra.get("fields_streamed_per_cell") == 5
 
 
 if __name__ == "__main__":

@@ -28,8 +28,7 @@
 extern "C" {
 #endif
 
-#define RJP_VERSION 102          /* 0.1.2 */
-#define RJP_MAX_BURSTS 8         /* per jet (red / blue) */
+#define RJP_VERSION 103          /* 0.1.3 */
 #define RJP_MAX_EPOCH_TILE 32    /* most epochs evaluated per grid pass: 32 uniformly spaced ones when d_em is NULL, 16 uniformly spaced ones with d_em, else 8 */
 
 enum rjp_status {
@@ -37,7 +36,11 @@ enum rjp_status {
   RJP_ERR_ARG = -1,        /* bad argument (null pointer, shape, dtype tag ...) */
   RJP_ERR_HIP = -2,        /* a HIP runtime call failed */
   RJP_ERR_NODEVICE = -3,   /* no usable gfx950 device */
-  RJP_ERR_WORKSPACE = -4   /* workspace too small */
+  RJP_ERR_WORKSPACE = -4,  /* workspace too small */
+  RJP_ERR_DEGENERATE = -5  /* rjp_build_fields: the launch-time integral's 2F1 is a logarithmic
+                              case the device series does not cover; nothing was enqueued --
+                              the caller evaluates `ts` itself (scipy hyp2f1, as the reference
+                              does, maths/geometry.py:166-171) and uploads it */
 };
 
 enum rjp_dtype { RJP_F32 = 4, RJP_F64 = 8 };   /* storage width of the 3-D fields */
@@ -87,12 +90,16 @@ typedef struct rjp_fields {
 } rjp_fields;
 
 /* Ejection bursts (classes.py:399-463): mdot(t)/mdot_ss = 1 + sum_b amp_rel_b *
- * exp(-(t - t0_b)^2 * inv2s2_b); index 0 = red jet, 1 = blue jet. */
+ * exp(-(t - t0_b)^2 * inv2s2_b); index 0 = red jet, 1 = blue jet.  ANY number of bursts per
+ * jet, as in the reference (classes.py:245-264 registers every row of params["ejection"]):
+ * the arrays are HOST pointers to n[j] doubles each (may be NULL when n[j] == 0), read
+ * during the call.  The first eight bursts of a jet travel to the kernels as scalar
+ * arguments, the rest in a small device table the library stages on the stream. */
 typedef struct rjp_bursts {
   int32_t n[2];
-  double t0[2][RJP_MAX_BURSTS];        /* [s] */
-  double amp_rel[2][RJP_MAX_BURSTS];   /* (peak_jml - ss_jml) / ss_jml */
-  double inv2s2[2][RJP_MAX_BURSTS];    /* 1 / (2 sigma^2) [s^-2] */
+  const double* t0[2];        /* [s] */
+  const double* amp_rel[2];   /* (peak_jml - ss_jml) / ss_jml */
+  const double* inv2s2[2];    /* 1 / (2 sigma^2) [s^-2] */
 } rjp_bursts;
 
 /* One radio recombination line, host-side scalars of maths/rrls.py (LTE path). */
@@ -228,7 +235,8 @@ typedef struct rjp_geometry {
  * d_vx_raw / d_vz_raw (float64, optional) the transverse components of JetModel.vel.
  * Launch times: closed form for q^d_v = 0, otherwise Gauss' 2F1(a, b; b+1; -A) of
  * maths/geometry.py:166-171 evaluated on the device (Pfaff + 1/z connection formula);
- * RJP_ERR_ARG if a-b or b is a non-positive integer (logarithmic cases) and d_ts != NULL.
+ * RJP_ERR_DEGENERATE if a-b or b is a non-positive integer (logarithmic cases) and
+ * d_ts != NULL.
  * d_em0 (optional, RJP_F64 only): the compact scan field of rjp_fields.d_em0 written in the
  * same pass, bit-identical to what rjp_compact_fields derives from nd, xi, pf -- with d_nd,
  * d_xi, d_pf NULL a continuum-only model occupies 24 B/cell (12e9 cells per 288 GB GPU). */

@@ -8,19 +8,27 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-# RJP_LIB overrides the library path (A/B runs of experimental builds; never a CPU path)
-LIB_PATH = os.environ.get("RJP_LIB") or os.path.join(_HERE, "librjprt.so")
+# One debug flag: only with RJP_DEBUG=1 in the environment do the experiment variables count
+# (RJP_LIB = path of an experimental build of the same library, e.g. csrc/build.sh
+# --debug-switches; RJP_NO_COMPACT, see engine.py).  Never a CPU path.
+DEBUG = os.environ.get("RJP_DEBUG") == "1"
+LIB_PATH = (DEBUG and os.environ.get("RJP_LIB")) or os.path.join(_HERE, "librjprt.so")
 
 RJP_F32, RJP_F64 = 4, 8
 RJP_GFF_SCALAR, RJP_GFF_POWERLAW = 0, 1
-RJP_MAX_BURSTS = 8
 RJP_MAX_EPOCH_TILE = 32
-RJP_VERSION = 102             # include/rjprt.h; the binding below matches exactly this ABI
+RJP_VERSION = 103             # include/rjprt.h; the binding below matches exactly this ABI
 RJP_OK = 0
+RJP_ERR_ARG, RJP_ERR_HIP, RJP_ERR_NODEVICE, RJP_ERR_WORKSPACE, RJP_ERR_DEGENERATE = \
+    -1, -2, -3, -4, -5
 
 
 class RjprtError(RuntimeError):
-    """A librjprt call returned a negative status."""
+    """A librjprt call returned a negative status (`.status`, enum rjp_status)."""
+
+    def __init__(self, message, status=None):
+        super().__init__(message)
+        self.status = status
 
 
 class Fields(C.Structure):
@@ -32,10 +40,12 @@ class Fields(C.Structure):
 
 
 class Bursts(C.Structure):
+    """rjp_bursts: per-jet counts + host pointers to n[j] doubles each.  The arrays the
+    pointers refer to are kept alive in `_keep` (engine.make_bursts)."""
     _fields_ = [("n", C.c_int32 * 2),
-                ("t0", (C.c_double * RJP_MAX_BURSTS) * 2),
-                ("amp_rel", (C.c_double * RJP_MAX_BURSTS) * 2),
-                ("inv2s2", (C.c_double * RJP_MAX_BURSTS) * 2)]
+                ("t0", C.POINTER(C.c_double) * 2),
+                ("amp_rel", C.POINTER(C.c_double) * 2),
+                ("inv2s2", C.POINTER(C.c_double) * 2)]
 
 
 class Line(C.Structure):
@@ -128,7 +138,7 @@ def check(status, ctx=None, what=""):
         msg = load().rjp_last_error(ctx)
         raise RjprtError("%s failed (status %d): %s"
                          % (what or "librjprt call", status,
-                            msg.decode() if msg else "?"))
+                            msg.decode() if msg else "?"), status=status)
 
 
 def dbl_array(values):

@@ -8,6 +8,7 @@ reduction runs in librjprt's HIP kernels through the C-ABI of include/rjprt.h.  
 serves every continuum channel of an epoch (the reference re-streams the grid per channel),
 and up to sixteen epochs share a pass.  There is no CPU fallback for any of it.
 """
+import collections
 import os
 import pickle
 import runpy
@@ -45,6 +46,23 @@ def geometry_struct(params, nx, ny, nz, ix0=0, nx_total=0):
     s.rb_frac = pr['mlr_rj'] / pr['mlr_bj']
     s.ix0, s.nx_total = int(ix0), int(nx_total)
     return s
+
+
+def build_model_fields(model, geom, **kw):
+    """K4 for `geom` (the whole grid of `model`, or an x-slab of it).  Only the library's
+    dedicated refusal of a logarithmic 2F1 case (RJP_ERR_DEGENERATE: q^d_v and the
+    launch-time exponent differ by an integer) is answered with the host evaluation of the
+    launch times; every other failure (bad geometry, HIP error, ABI mismatch) propagates."""
+    eng = model.engine
+    try:
+        return eng.build_fields(geom, model._dtype, want_ts=True, **kw)
+    except _lib.RjprtError as exc:
+        if exc.status != _lib.RJP_ERR_DEGENERATE:
+            raise
+    dev = eng.build_fields(geom, model._dtype, want_ts=False, **kw)
+    ts = model._host_launch_times(geom.ix0, geom.ix0 + geom.nx)
+    eng.replace_field(dev, "ts", ts)
+    return dev
 
 
 def _dist_info():
@@ -184,7 +202,7 @@ class JetModel:
         self._engine = engine
         self._dev = None
         self._version = 0            # bumped whenever a field or the burst list changes
-        self._scan_cache = {}        # time -> (sumA[P], em[P]) device tensors
+        self._scan_cache = collections.OrderedDict()   # time -> (sumA[1,P], em[1,P]) tensors
         self._tavg = None
         self._vxz = None
         self._rrl_cache = None
@@ -284,7 +302,9 @@ class JetModel:
 
     def add_ejection_event(self, t_0, peak_jml, half_life, which):
         """Gaussian mass-loss burst (classes.py:399-463): t_0, half_life [s], peak [kg/s]."""
-        assert which in ('R', 'B')
+        which = which.upper()                                    # classes.py:450, 455
+        if which not in ('R', 'B'):
+            raise ValueError("which must be 'R' or 'B'")
         ss = self._ss_jml_bj if which == 'B' else self._ss_jml_rj
         sigma = half_life * 2. / (2. * np.sqrt(2. * np.log(2.)))
         self._bursts[which].append((t_0, (peak_jml - ss) / ss, sigma))
@@ -321,7 +341,7 @@ class JetModel:
 
     def _invalidate(self):
         self._version = getattr(self, "_version", 0) + 1
-        self._scan_cache = {}
+        self._scan_cache = collections.OrderedDict()
         self._tavg = None
         self._rrl_cache = None
 
@@ -339,14 +359,7 @@ class JetModel:
                 self.log.add_entry("INFO", "Calculating cells' fill factors/projected areas")
             then = _time.time()
             geom = geometry_struct(self.params, self.nx, self.ny, self.nz)
-            try:
-                self._dev = self.engine.build_fields(geom, self._dtype, want_ts=True)
-            except _lib.RjprtError:
-                # degenerate 2F1 parameters (q^d_v and the launch-time exponent differ by an
-                # integer): the library refuses; evaluate the launch times with scipy's hyp2f1
-                # exactly as the reference does (maths/geometry.py:150-178) and upload them
-                self._dev = self.engine.build_fields(geom, self._dtype, want_ts=False)
-                self.engine.replace_field(self._dev, "ts", self._host_launch_times())
+            self._dev = build_model_fields(self, geom)
             # a jet fills a few per cent of its grid: record each sightline's occupied rows
             # once so that every later scan touches only those
             self.engine.compute_y_bounds(self._dev)
@@ -356,9 +369,13 @@ class JetModel:
                     'Finished in %Hh%Mm%Ss', _time.gmtime(_time.time() - then)))
         return self._dev
 
-    def _host_launch_times(self):
+    def _host_launch_times(self, x0=0, x1=None):
+        """Launch times [s] of rows [x0, x1) of the grid evaluated on the host with scipy's
+        hyp2f1, exactly as the reference does (maths/geometry.py:150-178) -- only for the
+        logarithmic 2F1 cases the device series refuses (RJP_ERR_DEGENERATE)."""
         g = self.params['geometry']
-        ix, iy, iz = np.meshgrid(np.arange(self.nx), np.arange(self.ny), np.arange(self.nz),
+        x1 = self.nx if x1 is None else x1
+        ix, iy, iz = np.meshgrid(np.arange(x0, x1), np.arange(self.ny), np.arange(self.nz),
                                  indexing='ij')
         c = self.csize
         rr, ww, _ = mgeom.xyz_to_rwp(c * (ix - self.nx // 2) + c / 2., c * (iy - self.ny // 2) +
@@ -494,6 +511,8 @@ class JetModel:
         return self._vxz[0], self._grid(self.device_fields.vy), self._vxz[1]
 
     # ------------------------------------------------------------------ K1 cache ----
+    SCAN_CACHE_EPOCHS = 64       # base-map pairs kept on the device (2 x P x 8 B each)
+
     def prefetch_epochs(self, times_s):
         """Scan the grid for several model times at once (8-32 epochs share one pass over
         HBM); later RT calls at those times reuse the base maps."""
@@ -501,10 +520,20 @@ class JetModel:
                 if t not in self._scan_cache]
         if not todo:
             return
+        # the cache is bounded (a long sweep must not pin an [E, P] pair per epoch for ever):
+        # at most SCAN_CACHE_EPOCHS epochs stay resident, oldest first out; a longer request
+        # keeps its FIRST epochs, the ones a caller walking the list in order needs next
+        todo = todo[:self.SCAN_CACHE_EPOCHS]
         dev = self.device_fields
         sumA, em, tavg = self.engine.ff_scan(dev, self._rjp_bursts(), todo, self.gff_mode)
         for i, t in enumerate(todo):
-            self._scan_cache[t] = (sumA[i:i + 1], em[i:i + 1])
+            # own copies: a slice would keep the whole [E, P] result alive
+            self._scan_cache[t] = (sumA[i:i + 1].clone(), em[i:i + 1].clone())
+        while len(self._scan_cache) > self.SCAN_CACHE_EPOCHS:
+            old = next(iter(self._scan_cache))
+            if old in todo:
+                break
+            del self._scan_cache[old]
         self._tavg = tavg
 
     def _base_maps(self):
@@ -995,14 +1024,17 @@ class Pipeline:
         mine = [i for i, r in enumerate(self.runs) if owner[float(r.year)] == rank]
         self._multi_rank = world > 1
 
+        pending = []
         if not dryrun:
-            # one pass over HBM serves 8-32 epochs
             pending = [self.runs[i].year * con.year for i in mine
                        if self.runs[i].radiative_transfer and
                        not (self.runs[i].completed and resume and not clobber)]
-            if pending:
-                self.model.prefetch_epochs(pending)
+            pending = list(dict.fromkeys(pending))
 
+        # A rank that fails must still reach the gather and the barrier below, or its peers
+        # would wait in the collective until the RCCL timeout: per-run failures are recorded
+        # and re-raised on EVERY rank after the exchange.
+        failure = None
         for idx in mine:
             run = self.runs[idx]
             self.model.time = run.year * con.year
@@ -1018,29 +1050,53 @@ class Pipeline:
                                                "".format(run.rt_dcy), timestamp=False)
                     os.makedirs(run.rt_dcy, exist_ok=True)
                 if not dryrun and run.radiative_transfer:
+                    t_now = float(self.model.time)
+                    if t_now in pending:
+                        # one pass over HBM serves up to 32 of the epochs still to come
+                        k = pending.index(t_now)
+                        self.model.prefetch_epochs(pending[k:k + 32])
+                        del pending[:k + 1]
                     self._radiative_transfer(idx, run, clobber)
             except KeyboardInterrupt:
                 self.log.add_entry("ERROR", "Pipeline interrupted by user, saving state")
-                if rank == 0:
-                    self.save(self.save_file)
-                    self.model.save(self.model_file)
-                raise KeyboardInterrupt("Pipeline interrupted by user")
+                failure = (idx, "KeyboardInterrupt", "Pipeline interrupted by user")
+                break
+            except Exception as exc:                      # noqa: BLE001 -- re-raised below
+                if world == 1:
+                    raise
+                self.log.add_entry("ERROR", "Run #{} failed on rank {}: {}: {}".format(
+                    idx + 1, rank, type(exc).__name__, exc))
+                failure = (idx, type(exc).__name__, str(exc))
+                break
             run.completed = True                                   # classes.py:2853
 
+        failures = [failure] if failure else []
         if world > 1:
-            # one small object gather: {run index: (results, completed)} from every rank
-            local = {i: (self.runs[i].results, self.runs[i].completed) for i in mine}
+            # one small object gather: {run index: (results, completed)} + the failure (if
+            # any) of every rank
+            local = {"runs": {i: (self.runs[i].results, self.runs[i].completed) for i in mine},
+                     "failure": failure, "rank": rank}
             parts = [None] * world
             dist.all_gather_object(parts, local)
+            failures = []
             for part in parts:
-                for i, (res, done) in part.items():
+                for i, (res, done) in part["runs"].items():
                     self.runs[i].results = res
                     self.runs[i].completed = done
+                if part["failure"]:
+                    failures.append(part["failure"] + (part["rank"],))
         if rank == 0:
             self.save(self.save_file)
             self.model.save(self.model_file)
         if world > 1:
             dist.barrier()
+        if failures:
+            f = failures[0]
+            if f[1] == "KeyboardInterrupt":
+                raise KeyboardInterrupt(f[2])
+            where = " on rank %d" % f[3] if len(f) > 3 else ""
+            raise RuntimeError("Pipeline run #%d failed%s: %s: %s (state saved; completed "
+                               "runs are skipped on resume)" % (f[0] + 1, where, f[1], f[2]))
 
     def _radiative_transfer(self, idx, run, clobber):
         m = self.model

@@ -1,6 +1,10 @@
 #!/bin/bash
 # Builds librjprt.so for gfx950 in-tree (rajepy_amd/librjprt.so).  hipcc cross-compiles
-# without a GPU.  Usage: build.sh [--report]  (--report prints per-kernel register use)
+# without a GPU.  Usage: build.sh [--report | --debug-switches]
+#   --report          prints per-kernel register use
+#   --debug-switches  builds rajepy_amd/librjprt_dbg.so with -DRJP_DEBUG_SWITCHES: the only build
+#                     that reads the RJP_YSPLIT / RJP_FORCE_VEC1 / RJP_NO_UNIFORM / RJP_NO_TILE32
+#                     experiment variables (load it with RJP_DEBUG=1 RJP_LIB=<path>)
 set -euo pipefail
 here="$(cd "$(dirname "${BASH_SOURCE[0]}")" && pwd)"
 out="$here/../librjprt.so"
@@ -26,6 +30,9 @@ for r, n in zip(rows, names):
     n = re.sub(r"\(.*", "", n).replace("void rjp::", "")
     print("%-6s %-6s %-8s %-4s %-6s %s" % (r.get("VGPRs"), r.get("TotalSGPRs"), r.get("ScratchSize"), r.get("Occupancy"), r.get("LDS Size"), n))
 PY
+elif [[ "${1:-}" == "--debug-switches" ]]; then
+  out="$here/../librjprt_dbg.so"
+  hipcc "${flags[@]}" -DRJP_DEBUG_SWITCHES -o "$out" "$here/rjprt.hip"
 else
   hipcc "${flags[@]}" -o "$out" "$here/rjprt.hip"
 fi

@@ -14,6 +14,7 @@
 // jet flag in its sign bit, temp, ts).
 #include <algorithm>
 #include <cmath>
+#include <vector>
 
 #include "rjp_device.h"
 
@@ -477,10 +478,11 @@ __global__ __launch_bounds__(kBlock) void ff_cells_kernel(FieldPtrs<T> f, int64_
   for (int k = 0; k < nchan; ++k) out[(int64_t)k * ncell + i] = ctau[k] * a;
 }
 
-hipError_t ff_cells_launch(const rjp_fields* fl, const rjp_bursts* hb, double time_s, int mode,
-                           const double* d_ctau, int nchan, double* out, hipStream_t st) {
+hipError_t ff_cells_launch(const rjp_fields* fl, const rjp_bursts* hb, const double* d_ext,
+                           double time_s, int mode, const double* d_ctau, int nchan,
+                           double* out, hipStream_t st) {
   BurstsDev b;
-  const bool bursts = bursts_to_dev(hb, b);
+  const bool bursts = bursts_to_dev(hb, b, d_ext);
   if (bursts && !fl->d_ts) return hipErrorInvalidValue;
   const int64_t n = (int64_t)fl->nx * fl->ny * fl->nz;
   const dim3 grid((unsigned)((n + kBlock - 1) / kBlock)), blk(kBlock);
@@ -514,10 +516,21 @@ static int ysplit_rule(int64_t nchunks, int ny) {
   return (int)s;
 }
 
+// Experiment switches (A/B runs of launch parameters) exist only in builds made with
+// -DRJP_DEBUG_SWITCHES (build.sh --debug-switches); the shipped library reads no environment.
+static const char* debug_env(const char* name) {
+#ifdef RJP_DEBUG_SWITCHES
+  return getenv(name);
+#else
+  (void)name;
+  return nullptr;
+#endif
+}
+
 static int forced_ysplit() {
   static int forced = -1;
   if (forced < 0) {
-    const char* s = getenv("RJP_YSPLIT");           // experiments only
+    const char* s = debug_env("RJP_YSPLIT");
     forced = s ? atoi(s) : 0;
   }
   return forced;
@@ -537,7 +550,7 @@ int ff_scan_vec(const rjp_fields* fl) {
     if (p && ((uintptr_t)p % 16) != 0) ok = false;
   (void)esz;
   static int force1 = -1;
-  if (force1 < 0) force1 = getenv("RJP_FORCE_VEC1") ? 1 : 0;     // experiments only
+  if (force1 < 0) force1 = debug_env("RJP_FORCE_VEC1") ? 1 : 0;
   return (ok && !force1) ? full : 1;
 }
 
@@ -552,15 +565,22 @@ size_t ff_scan_workspace_bytes(int nx, int ny, int nz, int n_epochs) {
 }
 
 // Decide whether a tile of epochs may use the uniform-spacing recurrence and fill its
-// per-burst constants.  RJP_NO_UNIFORM=1 forces the direct evaluation (A/B, tests).
-static void uniform_tile(const double* t, int et, const BurstsDev& b, UnifDev& un) {
+// per-burst constants: un.q for the bursts that travel by value, `qext` (2 * next doubles,
+// may be nullptr when the model has no overflow bursts) for the rest.
+static void uniform_tile(const double* t, int et, const rjp_bursts* hb, UnifDev& un,
+                         double* qext) {
   un.on = 0;
   un.dt = 0.0;
-  for (int j = 0; j < 2; ++j)
-    for (int i = 0; i < RJP_MAX_BURSTS; ++i) un.q[j][i] = 1.0;
+  un.qext = nullptr;
+  const int next = bursts_overflow(hb);
+  for (int j = 0; j < 2; ++j) {
+    for (int i = 0; i < RJP_SGPR_BURSTS; ++i) un.q[j][i] = 1.0;
+    for (int i = 0; qext && i < next; ++i) qext[j * next + i] = 1.0;
+  }
   static int disabled = -1;
-  if (disabled < 0) disabled = getenv("RJP_NO_UNIFORM") ? 1 : 0;
-  if (et < 4 || disabled) return;
+  if (disabled < 0) disabled = debug_env("RJP_NO_UNIFORM") ? 1 : 0;
+  if (et < 4 || disabled || !hb) return;
+  if (next > 0 && !qext) return;
   const double dt = (t[et - 1] - t[0]) / (et - 1);
   double tmax = 0.0, dev = 0.0;
   for (int e = 0; e < et; ++e) {
@@ -571,12 +591,14 @@ static void uniform_tile(const double* t, int et, const BurstsDev& b, UnifDev& u
   const int m = et / 2;
   const double half_span = std::max(m, et - 1 - m) * std::fabs(dt);
   for (int j = 0; j < 2; ++j)
-    for (int i = 0; i < b.n[j]; ++i) {
-      const double inv = b.inv2s2[j][i];
+    for (int i = 0; i < hb->n[j]; ++i) {
+      const double inv = hb->inv2s2[j][i];
       if (!(inv > 0.0)) return;
       const double sigma = std::sqrt(0.5 / inv);
       if (!(half_span <= 28.0 * sigma)) return;   // anchor underflow would hide live epochs
-      un.q[j][i] = std::exp(-2.0 * inv * dt * dt);
+      const double q = std::exp(-2.0 * inv * dt * dt);
+      if (i < RJP_SGPR_BURSTS) un.q[j][i] = q;
+      else qext[j * next + (i - RJP_SGPR_BURSTS)] = q;
     }
   un.on = 1;
   un.dt = dt;
@@ -584,13 +606,15 @@ static void uniform_tile(const double* t, int et, const BurstsDev& b, UnifDev& u
 
 template <typename T, int VEC, int ET, int MODE, bool BURSTS, bool CMP>
 static hipError_t launch_tile(const rjp_fields* fl, const BurstsDev& b, const double* t,
-                              int nsplit, int ylen, double* ws, bool want_em, hipStream_t st) {
+                              const UnifDev& un, int nsplit, int ylen, double* ws, bool want_em,
+                              hipStream_t st) {
   FieldPtrs<T> f{(const T*)fl->d_nd, (const T*)fl->d_xi, (const T*)fl->d_temp,
                  (const T*)fl->d_pf, (const T*)fl->d_ts, fl->d_ylo, fl->d_yhi,
                  (const T*)fl->d_em0};
   EpochTile<ET> ep;
   for (int e = 0; e < ET; ++e) ep.t[e] = t[e];
-  uniform_tile(t, ET, b, ep.un);
+  ep.un = un;
+  if (ET < 4) ep.un.on = 0;
   const int64_t npix = (int64_t)fl->nx * fl->nz;
   const int64_t nchunks = npix / VEC;
   dim3 grid((unsigned)(((nchunks + kBlock - 1) / kBlock) * nsplit), 1u);
@@ -629,26 +653,26 @@ static hipError_t launch_tile(const rjp_fields* fl, const BurstsDev& b, const do
 
 template <typename T, int VEC, int MODE, bool CMP>
 static hipError_t dispatch_et(const rjp_fields* fl, const BurstsDev& b, bool bursts,
-                              const double* t, int et, int nsplit, int ylen, double* ws,
-                              bool want_em, hipStream_t st) {
-  if (!bursts) return launch_tile<T, VEC, 1, MODE, false, CMP>(fl, b, t, nsplit, ylen, ws, want_em, st);
+                              const double* t, const UnifDev& un, int et, int nsplit, int ylen,
+                              double* ws, bool want_em, hipStream_t st) {
+  if (!bursts) return launch_tile<T, VEC, 1, MODE, false, CMP>(fl, b, t, un, nsplit, ylen, ws, want_em, st);
   switch (et) {
-    case 1: return launch_tile<T, VEC, 1, MODE, true, CMP>(fl, b, t, nsplit, ylen, ws, want_em, st);
-    case 2: return launch_tile<T, VEC, 2, MODE, true, CMP>(fl, b, t, nsplit, ylen, ws, want_em, st);
-    case 4: return launch_tile<T, VEC, 4, MODE, true, CMP>(fl, b, t, nsplit, ylen, ws, want_em, st);
+    case 1: return launch_tile<T, VEC, 1, MODE, true, CMP>(fl, b, t, un, nsplit, ylen, ws, want_em, st);
+    case 2: return launch_tile<T, VEC, 2, MODE, true, CMP>(fl, b, t, un, nsplit, ylen, ws, want_em, st);
+    case 4: return launch_tile<T, VEC, 4, MODE, true, CMP>(fl, b, t, un, nsplit, ylen, ws, want_em, st);
     case 8:
       // 4 sightlines x 8 epochs x 2 sums does not fit 256 VGPRs: the launcher caps the
       // epoch tile at 4 for 4-wide (f32) lanes
       if constexpr (VEC == 4) return hipErrorInvalidValue;
-      else return launch_tile<T, VEC, 8, MODE, true, CMP>(fl, b, t, nsplit, ylen, ws, want_em, st);
+      else return launch_tile<T, VEC, 8, MODE, true, CMP>(fl, b, t, un, nsplit, ylen, ws, want_em, st);
     case 16:
       // only the uniform-epoch recurrence keeps 16 epochs of state in registers
       if constexpr (VEC == 1)
-        return launch_tile<T, VEC, 16, MODE, true, CMP>(fl, b, t, nsplit, ylen, ws, want_em, st);
+        return launch_tile<T, VEC, 16, MODE, true, CMP>(fl, b, t, un, nsplit, ylen, ws, want_em, st);
       else return hipErrorInvalidValue;
     case 32:
       if constexpr (VEC == 1)
-        return launch_tile<T, VEC, 32, MODE, true, CMP>(fl, b, t, nsplit, ylen, ws, want_em, st);
+        return launch_tile<T, VEC, 32, MODE, true, CMP>(fl, b, t, un, nsplit, ylen, ws, want_em, st);
       else return hipErrorInvalidValue;
   }
   return hipErrorInvalidValue;
@@ -656,68 +680,111 @@ static hipError_t dispatch_et(const rjp_fields* fl, const BurstsDev& b, bool bur
 
 template <typename T, int VEC>
 static hipError_t dispatch_mode(const rjp_fields* fl, const BurstsDev& b, bool bursts,
-                                int mode, const double* t, int et, int nsplit, int ylen,
-                                double* ws, bool want_em, hipStream_t st) {
+                                int mode, const double* t, const UnifDev& un, int et,
+                                int nsplit, int ylen, double* ws, bool want_em, hipStream_t st) {
   if (fl->d_em0) {                                  // compact layout attached
     if (mode == RJP_GFF_SCALAR)
-      return dispatch_et<T, VEC, RJP_GFF_SCALAR, true>(fl, b, bursts, t, et, nsplit, ylen, ws, want_em, st);
-    return dispatch_et<T, VEC, RJP_GFF_POWERLAW, true>(fl, b, bursts, t, et, nsplit, ylen, ws, want_em, st);
+      return dispatch_et<T, VEC, RJP_GFF_SCALAR, true>(fl, b, bursts, t, un, et, nsplit, ylen, ws, want_em, st);
+    return dispatch_et<T, VEC, RJP_GFF_POWERLAW, true>(fl, b, bursts, t, un, et, nsplit, ylen, ws, want_em, st);
   }
   if (mode == RJP_GFF_SCALAR)
-    return dispatch_et<T, VEC, RJP_GFF_SCALAR, false>(fl, b, bursts, t, et, nsplit, ylen, ws, want_em, st);
-  return dispatch_et<T, VEC, RJP_GFF_POWERLAW, false>(fl, b, bursts, t, et, nsplit, ylen, ws, want_em, st);
+    return dispatch_et<T, VEC, RJP_GFF_SCALAR, false>(fl, b, bursts, t, un, et, nsplit, ylen, ws, want_em, st);
+  return dispatch_et<T, VEC, RJP_GFF_POWERLAW, false>(fl, b, bursts, t, un, et, nsplit, ylen, ws, want_em, st);
 }
 
 static bool use_tile32() {
   static int v = -1;
-  if (v < 0) v = getenv("RJP_NO_TILE32") ? 0 : 1;          // A/B runs
+  if (v < 0) v = debug_env("RJP_NO_TILE32") ? 0 : 1;
   return v != 0;
 }
 
-// Enqueue the whole scan for n_epochs epochs.  Returns hipSuccess or the first error.
-hipError_t ff_scan_launch(const rjp_fields* fl, const rjp_bursts* hb, const double* epochs,
-                          int n_epochs, int mode, double* sumA, double* em, double* tavg,
-                          double* ws, hipStream_t st) {
-  BurstsDev b;
-  const bool bursts = bursts_to_dev(hb, b);
-  if (bursts && !fl->d_ts) return hipErrorInvalidValue;
+// The epoch tiling of one scan, decided on the host before anything is enqueued, so that the
+// constants of bursts beyond RJP_SGPR_BURSTS (parameters + one q per tile) can travel to the
+// device in ONE small table: ext = [params: 6 * next][tile 0 q: 2 * next][tile 1 q] ...
+struct ScanTile {
+  int e0, et;
+  UnifDev un;          // un.qext is patched to the device table by ff_scan_run
+};
+struct ScanPlan {
+  bool bursts = false;
+  int vec = 1, nsplit = 1, ylen = 1, next = 0;
+  std::vector<ScanTile> tiles;
+  std::vector<double> ext;       // host image of the overflow table (empty without overflow)
+};
+
+void ff_scan_plan(const rjp_fields* fl, const rjp_bursts* hb, const double* epochs,
+                  int n_epochs, bool want_em, ScanPlan& pl) {
+  BurstsDev probe_b;
+  pl.bursts = bursts_to_dev(hb, probe_b);
+  pl.next = bursts_overflow(hb);
   const int64_t npix = (int64_t)fl->nx * fl->nz;
-  const int vec = ff_scan_vec(fl);
-  const int nsplit = choose_ysplit(npix / vec, fl->ny);
-  const int ylen = (fl->ny + nsplit - 1) / nsplit;
+  pl.vec = ff_scan_vec(fl);
+  pl.nsplit = choose_ysplit(npix / pl.vec, fl->ny);
+  pl.ylen = (fl->ny + pl.nsplit - 1) / pl.nsplit;
+  pl.tiles.clear();
+  pl.ext.assign(bursts_ext_doubles(hb), 0.0);
+  if (pl.next > 0) bursts_fill_ext(hb, pl.ext.data());
+  std::vector<double> q((size_t)2 * pl.next + 1);
+  int e0 = 0;
+  while (e0 < n_epochs) {
+    ScanTile tl;
+    tl.e0 = e0;
+    tl.et = 1;
+    uniform_tile(epochs + e0, 1, hb, tl.un, q.data());       // un.on = 0, q = 1
+    if (pl.bursts) {
+      const int left = n_epochs - e0;
+      tl.et = (left >= 8 && pl.vec != 4) ? 8 : left >= 4 ? 4 : left >= 2 ? 2 : 1;
+      UnifDev probe;
+      if (left >= 16) {
+        uniform_tile(epochs + e0, 16, hb, probe, q.data());
+        if (probe.on) tl.et = 16;
+      }
+      if (left >= 32 && !want_em && use_tile32()) {
+        uniform_tile(epochs + e0, 32, hb, probe, q.data());
+        if (probe.on) tl.et = 32;
+      }
+      // the tile's own constants (short tiles of f32 storage keep their float-accuracy exp:
+      // launch_tile ignores `un` there)
+      uniform_tile(epochs + e0, tl.et, hb, tl.un, q.data());
+    }
+    if (pl.next > 0) pl.ext.insert(pl.ext.end(), q.begin(), q.begin() + 2 * pl.next);
+    pl.tiles.push_back(tl);
+    if (!pl.bursts) break;
+    e0 += tl.et;
+  }
+}
+
+// Enqueue the whole scan for n_epochs epochs.  `d_ext` = device copy of pl.ext (nullptr when
+// it is empty).  Returns hipSuccess or the first error.
+hipError_t ff_scan_run(const rjp_fields* fl, const rjp_bursts* hb, const ScanPlan& pl,
+                       const double* d_ext, const double* epochs, int n_epochs, int mode,
+                       double* sumA, double* em, double* tavg, double* ws, hipStream_t st) {
+  BurstsDev b;
+  const bool bursts = bursts_to_dev(hb, b, d_ext);
+  if (bursts && !fl->d_ts) return hipErrorInvalidValue;
+  if (pl.next > 0 && !d_ext) return hipErrorInvalidValue;
+  const int64_t npix = (int64_t)fl->nx * fl->nz;
+  const int vec = pl.vec, nsplit = pl.nsplit, ylen = pl.ylen;
   // em = sum (n x)^2 * csize*au/pc * pf  (classes.py:1116-1118)
   const double em_scale = fl->csize_au * 149597870700.0 / 3.085677581491367e+16;
   const unsigned rblocks = (unsigned)((npix + kBlock - 1) / kBlock);
 
-  int e0 = 0;
-  while (e0 < n_epochs) {
-    int et = 1;
-    if (bursts) {
-      const int left = n_epochs - e0;
-      et = (left >= 8 && vec != 4) ? 8 : left >= 4 ? 4 : left >= 2 ? 2 : 1;
-      if (left >= 16) {
-        UnifDev probe;
-        uniform_tile(epochs + e0, 16, b, probe);
-        if (probe.on) et = 16;
-      }
-      if (left >= 32 && !em && use_tile32()) {
-        UnifDev probe;
-        uniform_tile(epochs + e0, 32, b, probe);
-        if (probe.on) et = 32;
-      }
-    }
+  for (size_t k = 0; k < pl.tiles.size(); ++k) {
+    const int e0 = pl.tiles[k].e0, et = pl.tiles[k].et;
+    UnifDev un = pl.tiles[k].un;
+    un.qext = pl.next > 0 ? d_ext + bursts_ext_doubles(hb) + k * 2 * (size_t)pl.next : nullptr;
     hipError_t err;
     const double* t = epochs + e0;
     if (fl->dtype == RJP_F64) {
       // 16-epoch tiles are ALU-bound and register-hungry: one sightline per lane (160 VGPRs,
       // 3 waves/SIMD) beats two (256 VGPRs, 1 wave/SIMD) by 15 %
       err = (vec == 2 && et < 16)
-                ? dispatch_mode<double, 2>(fl, b, bursts, mode, t, et, nsplit, ylen, ws, em != nullptr, st)
-                : dispatch_mode<double, 1>(fl, b, bursts, mode, t, et, nsplit, ylen, ws, em != nullptr, st);
+                ? dispatch_mode<double, 2>(fl, b, bursts, mode, t, un, et, nsplit, ylen, ws, em != nullptr, st)
+                : dispatch_mode<double, 1>(fl, b, bursts, mode, t, un, et, nsplit, ylen, ws, em != nullptr, st);
     } else {
       err = (vec == 4 && et < 16)
-                ? dispatch_mode<float, 4>(fl, b, bursts, mode, t, et, nsplit, ylen, ws, em != nullptr, st)
-                : dispatch_mode<float, 1>(fl, b, bursts, mode, t, et, nsplit, ylen, ws, em != nullptr, st);
+                ? dispatch_mode<float, 4>(fl, b, bursts, mode, t, un, et, nsplit, ylen, ws, em != nullptr, st)
+                : dispatch_mode<float, 1>(fl, b, bursts, mode, t, un, et, nsplit, ylen, ws, em != nullptr, st);
     }
     if (err != hipSuccess) return err;
     hipLaunchKernelGGL(ff_reduce_kernel, dim3(rblocks), dim3(kBlock), 0, st, ws, nsplit, et,
@@ -738,7 +805,6 @@ hipError_t ff_scan_launch(const rjp_fields* fl, const rjp_bursts* hb, const doub
       }
       break;
     }
-    e0 += et;
   }
   return hipSuccess;
 }

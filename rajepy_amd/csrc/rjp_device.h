@@ -53,27 +53,62 @@ __device__ __forceinline__ void store_plain(double* __restrict__ p, const double
 }
 
 // ---- burst factor chi(t) (classes.py:442-448, 866-868) ---------------------------------
-// Kernel-argument copy of rjp_bursts (lives in SGPRs / scalar cache).
+// Kernel-argument copy of rjp_bursts.  The first RJP_SGPR_BURSTS bursts of each jet travel by
+// value (they live in SGPRs / the scalar cache: the fast path of every shipped example); a jet
+// with more keeps the rest in a small device table `ext`, read with wave-uniform scalar
+// loads: ext[(jet * 3 + k) * next + (i - RJP_SGPR_BURSTS)], k = 0 t0, 1 amp_rel, 2 inv2s2.
+// The reference registers any number of bursts (classes.py:245-264, 399-463).
+#define RJP_SGPR_BURSTS 8
 struct BurstsDev {
   int n[2];
-  double t0[2][RJP_MAX_BURSTS];
-  double amp_rel[2][RJP_MAX_BURSTS];
-  double inv2s2[2][RJP_MAX_BURSTS];
+  double t0[2][RJP_SGPR_BURSTS];
+  double amp_rel[2][RJP_SGPR_BURSTS];
+  double inv2s2[2][RJP_SGPR_BURSTS];
+  const double* ext;      // overflow bursts (nullptr when every jet has <= RJP_SGPR_BURSTS)
+  int next;               // overflow capacity per jet = max(n) - RJP_SGPR_BURSTS, or 0
 };
 
-// host: rjp_bursts -> kernel-argument copy; returns true when any burst is present
-static inline bool bursts_to_dev(const rjp_bursts* hb, BurstsDev& b) {
+static inline int bursts_overflow(const rjp_bursts* hb) {
+  if (!hb) return 0;
+  const int m = hb->n[0] > hb->n[1] ? hb->n[0] : hb->n[1];
+  return m > RJP_SGPR_BURSTS ? m - RJP_SGPR_BURSTS : 0;
+}
+
+// doubles of the device table the overflow bursts need (parameters only)
+static inline size_t bursts_ext_doubles(const rjp_bursts* hb) {
+  return (size_t)bursts_overflow(hb) * 6;
+}
+
+// host: fill the parameter part of the overflow table (unused slots contribute 0)
+static inline void bursts_fill_ext(const rjp_bursts* hb, double* tab) {
+  const int next = bursts_overflow(hb);
+  for (int j = 0; j < 2; ++j)
+    for (int i = 0; i < next; ++i) {
+      const int src = RJP_SGPR_BURSTS + i;
+      const bool live = src < hb->n[j];
+      tab[(j * 3 + 0) * next + i] = live ? hb->t0[j][src] : 0.0;
+      tab[(j * 3 + 1) * next + i] = live ? hb->amp_rel[j][src] : 0.0;
+      tab[(j * 3 + 2) * next + i] = live ? hb->inv2s2[j][src] : 0.0;
+    }
+}
+
+// host: rjp_bursts -> kernel-argument copy; returns true when any burst is present.
+// `d_ext` = device copy of the table bursts_fill_ext() wrote (nullptr without overflow).
+static inline bool bursts_to_dev(const rjp_bursts* hb, BurstsDev& b,
+                                 const double* d_ext = nullptr) {
   bool any = false;
   for (int j = 0; j < 2; ++j) {
     b.n[j] = hb ? hb->n[j] : 0;
     if (b.n[j] > 0) any = true;
-    for (int i = 0; i < RJP_MAX_BURSTS; ++i) {
+    for (int i = 0; i < RJP_SGPR_BURSTS; ++i) {
       const bool live = hb && i < hb->n[j];
       b.t0[j][i] = live ? hb->t0[j][i] : 0.0;
       b.amp_rel[j][i] = live ? hb->amp_rel[j][i] : 0.0;   // unused slots contribute 0
       b.inv2s2[j][i] = live ? hb->inv2s2[j][i] : 0.0;
     }
   }
+  b.next = bursts_overflow(hb);
+  b.ext = b.next > 0 ? d_ext : nullptr;
   return any;
 }
 
@@ -142,14 +177,22 @@ __device__ __forceinline__ double exp_burst(double x) {
   return F32ACC ? exp_nonpos_f32acc(x) : exp_nonpos(x);
 }
 
-// chi for one cell of one jet (wave-uniform loop count; parameters come from SGPRs)
+// chi for one cell of one jet (wave-uniform loop count; parameters come from SGPRs, those of
+// bursts beyond RJP_SGPR_BURSTS from the overflow table)
 __device__ __forceinline__ double chi_jet(const BurstsDev& b, int jet, double tl) {
   double chi = 1.0;
   const int nb = b.n[jet];
-  for (int i = 0; i < nb; ++i) {
+  const int n0 = nb < RJP_SGPR_BURSTS ? nb : RJP_SGPR_BURSTS;
+  for (int i = 0; i < n0; ++i) {
     double d = tl - b.t0[jet][i];
     double arg = -(d * d) * b.inv2s2[jet][i];
     chi = __builtin_fma(b.amp_rel[jet][i], exp_nonpos(arg), chi);
+  }
+  for (int i = RJP_SGPR_BURSTS; i < nb; ++i) {
+    const double* e = b.ext + (size_t)(jet * 3) * b.next + (i - RJP_SGPR_BURSTS);
+    double d = tl - e[0];
+    double arg = -(d * d) * e[2 * b.next];
+    chi = __builtin_fma(e[b.next], exp_nonpos(arg), chi);
   }
   return chi;
 }
@@ -175,25 +218,40 @@ __device__ __forceinline__ void chi_batch(const BurstsDev& b, const bool (&red)[
   if (!(wave_red && wave_blue)) {
     const int jet = wave_red ? 0 : 1;
     const int nb = b.n[jet];
-    for (int i = 0; i < nb; ++i) {
-      const double t0 = b.t0[jet][i], inv = b.inv2s2[jet][i], amp = b.amp_rel[jet][i];
+    const int n0 = nb < RJP_SGPR_BURSTS ? nb : RJP_SGPR_BURSTS;
+    auto one = [&](double t0, double inv, double amp) __attribute__((always_inline)) {
 #pragma unroll
       for (int k = 0; k < NB; ++k) {
         const double d = tl[k] - t0;
         chi[k] = __builtin_fma(amp, exp_burst<F32ACC>(-(d * d) * inv), chi[k]);
       }
+    };
+    for (int i = 0; i < n0; ++i) one(b.t0[jet][i], b.inv2s2[jet][i], b.amp_rel[jet][i]);
+    for (int i = RJP_SGPR_BURSTS; i < nb; ++i) {
+      const double* e = b.ext + (size_t)(jet * 3) * b.next + (i - RJP_SGPR_BURSTS);
+      one(e[0], e[2 * b.next], e[b.next]);
     }
   } else {
     const int nb = b.n[0] > b.n[1] ? b.n[0] : b.n[1];
-    for (int i = 0; i < nb; ++i) {
+    const int n0 = nb < RJP_SGPR_BURSTS ? nb : RJP_SGPR_BURSTS;
+    auto one = [&](double t0r, double invr, double ampr, double t0b, double invb,
+                   double ampb) __attribute__((always_inline)) {
 #pragma unroll
       for (int k = 0; k < NB; ++k) {
-        const double t0 = red[k] ? b.t0[0][i] : b.t0[1][i];
-        const double inv = red[k] ? b.inv2s2[0][i] : b.inv2s2[1][i];
-        const double amp = red[k] ? b.amp_rel[0][i] : b.amp_rel[1][i];
+        const double t0 = red[k] ? t0r : t0b;
+        const double inv = red[k] ? invr : invb;
+        const double amp = red[k] ? ampr : ampb;
         const double d = tl[k] - t0;
         chi[k] = __builtin_fma(amp, exp_burst<F32ACC>(-(d * d) * inv), chi[k]);
       }
+    };
+    for (int i = 0; i < n0; ++i)
+      one(b.t0[0][i], b.inv2s2[0][i], b.amp_rel[0][i], b.t0[1][i], b.inv2s2[1][i],
+          b.amp_rel[1][i]);
+    for (int i = RJP_SGPR_BURSTS; i < nb; ++i) {
+      const double* r = b.ext + (i - RJP_SGPR_BURSTS);
+      const double* u = r + (size_t)3 * b.next;
+      one(r[0], r[2 * b.next], r[b.next], u[0], u[2 * b.next], u[b.next]);
     }
   }
 }
@@ -208,7 +266,8 @@ __device__ __forceinline__ void chi_batch(const BurstsDev& b, const bool (&red)[
 struct UnifDev {
   int on;                                   // 0 = evaluate every epoch directly
   double dt;                                // epoch spacing [s]
-  double q[2][RJP_MAX_BURSTS];              // exp(-2 inv2s2 dt^2)
+  double q[2][RJP_SGPR_BURSTS];             // exp(-2 inv2s2 dt^2)
+  const double* qext;                       // the same for the overflow bursts: qext[jet * next + i]
 };
 
 template <int ET, int UV>
@@ -227,12 +286,14 @@ __device__ __forceinline__ void chi_batch_uniform(const BurstsDev& b, const Unif
 #pragma unroll
   for (int k = 0; k < ET * UV; ++k) chi[k] = 1.0;
   const int nb = mixed ? (b.n[0] > b.n[1] ? b.n[0] : b.n[1]) : b.n[jet];
-  auto one = [&](int i, int c) __attribute__((always_inline)) {
+  // one burst (its parameters for the red and the blue jet) applied to cell c
+  auto apply = [&](int c, double t0r, double invr, double ampr, double qr, double t0b,
+                   double invb, double ampb, double qb) __attribute__((always_inline)) {
     const bool r = mixed ? red[c] : (jet == 0);
-    const double t0 = r ? b.t0[0][i] : b.t0[1][i];
-    const double inv = r ? b.inv2s2[0][i] : b.inv2s2[1][i];
-    const double amp = r ? b.amp_rel[0][i] : b.amp_rel[1][i];
-    const double q = r ? un.q[0][i] : un.q[1][i];
+    const double t0 = r ? t0r : t0b;
+    const double inv = r ? invr : invb;
+    const double amp = r ? ampr : ampb;
+    const double q = r ? qr : qb;
     const double vm = tlm[c] - t0;
     const double argm = -(vm * vm) * inv;
     const bool dead = argm < -700.0;
@@ -261,15 +322,29 @@ __device__ __forceinline__ void chi_batch_uniform(const BurstsDev& b, const Unif
       chi[j * UV + c] = __builtin_fma(a, e, chi[j * UV + c]);
     }
   };
+  auto one = [&](int i, int c) __attribute__((always_inline)) {
+    apply(c, b.t0[0][i], b.inv2s2[0][i], b.amp_rel[0][i], un.q[0][i], b.t0[1][i],
+          b.inv2s2[1][i], b.amp_rel[1][i], un.q[1][i]);
+  };
+  const int n0 = nb < RJP_SGPR_BURSTS ? nb : RJP_SGPR_BURSTS;
   // two bursts per trip: their exp chains are independent and interleave
   int i = 0;
-  for (; i + 1 < nb; i += 2) {
+  for (; i + 1 < n0; i += 2) {
 #pragma unroll
     for (int c = 0; c < UV; ++c) { one(i, c); one(i + 1, c); }
   }
-  for (; i < nb; ++i) {
+  for (; i < n0; ++i) {
 #pragma unroll
     for (int c = 0; c < UV; ++c) one(i, c);
+  }
+  for (i = RJP_SGPR_BURSTS; i < nb; ++i) {
+    const int k = i - RJP_SGPR_BURSTS;
+    const double* r = b.ext + k;
+    const double* u = r + (size_t)3 * b.next;
+    const double qr = un.qext[k], qb = un.qext[b.next + k];
+#pragma unroll
+    for (int c = 0; c < UV; ++c)
+      apply(c, r[0], r[2 * b.next], r[b.next], qr, u[0], u[2 * b.next], u[b.next], qb);
   }
 }
 

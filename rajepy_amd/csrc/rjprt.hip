@@ -7,6 +7,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <vector>
 
 #include "ff_scan.hip"
 #include "fields.hip"
@@ -133,12 +134,21 @@ static int check_fields(rjp_ctx* ctx, const rjp_fields* f, bool need_vy, bool co
 static int check_bursts(rjp_ctx* ctx, const rjp_bursts* b, const rjp_fields* f) {
   if (!b) return RJP_OK;
   for (int j = 0; j < 2; ++j) {
-    if (b->n[j] < 0 || b->n[j] > RJP_MAX_BURSTS)
-      return fail(ctx, RJP_ERR_ARG, "bursts.n out of range [0, RJP_MAX_BURSTS]");
+    if (b->n[j] < 0 || b->n[j] > (1 << 20))
+      return fail(ctx, RJP_ERR_ARG, "bursts.n must be >= 0");
+    if (b->n[j] > 0 && (!b->t0[j] || !b->amp_rel[j] || !b->inv2s2[j]))
+      return fail(ctx, RJP_ERR_ARG, "bursts: NULL parameter array for a jet with n > 0");
     if (b->n[j] > 0 && !f->d_ts)
       return fail(ctx, RJP_ERR_ARG, "fields.d_ts required when bursts are present");
   }
   return RJP_OK;
+}
+
+// host image of the overflow-burst table of a single-epoch call (parameters only)
+static std::vector<double> burst_ext_table(const rjp_bursts* b) {
+  std::vector<double> t(bursts_ext_doubles(b), 0.0);
+  if (!t.empty()) bursts_fill_ext(b, t.data());
+  return t;
 }
 
 extern "C" {
@@ -244,8 +254,20 @@ int rjp_ff_scan(rjp_ctx* ctx, const rjp_fields* fields, const rjp_bursts* bursts
   if (!d_sumA || !d_work) return fail(ctx, RJP_ERR_ARG, "d_sumA / d_work is NULL");
   if (work_bytes < rjp::ff_scan_workspace_bytes(fields->nx, fields->ny, fields->nz, n_epochs))
     return fail(ctx, RJP_ERR_WORKSPACE, "rjp_ff_scan: workspace smaller than rjp_ff_scan_workspace()");
-  RJP_HIP(ctx, rjp::ff_scan_launch(fields, bursts, h_epochs_s, n_epochs, gff_mode, d_sumA, d_em,
-                                   d_tavg, (double*)d_work, (hipStream_t)stream));
+  hipStream_t st = (hipStream_t)stream;
+  rjp::ScanPlan plan;
+  rjp::ff_scan_plan(fields, bursts, h_epochs_s, n_epochs, d_em != nullptr, plan);
+  double* d_ext = nullptr;
+  if (!plan.ext.empty()) {
+    const double* src[1] = {plan.ext.data()};
+    const size_t len[1] = {plan.ext.size()};
+    double* dev[1];
+    if (int r = stage_tables(ctx, st, src, len, 1, dev)) return r;
+    d_ext = dev[0];
+  }
+  RJP_HIP(ctx, rjp::ff_scan_run(fields, bursts, plan, d_ext, h_epochs_s, n_epochs, gff_mode,
+                                d_sumA, d_em, d_tavg, (double*)d_work, st));
+  if (d_ext) return release_tables(ctx, st);
   return RJP_OK;
 }
 
@@ -305,12 +327,13 @@ int rjp_rrl_scan(rjp_ctx* ctx, const rjp_fields* fields, const rjp_bursts* burst
   if (!line || !h_nu || n_chan < 1 || !d_tau_rrl)
     return fail(ctx, RJP_ERR_ARG, "rjp_rrl_scan: NULL line / nu / output or n_chan < 1");
   hipStream_t st = (hipStream_t)stream;
-  const double* src[1] = {h_nu};
-  const size_t len[1] = {(size_t)n_chan};
-  double* dev[1];
-  if (int r = stage_tables(ctx, st, src, len, 1, dev)) return r;
-  RJP_HIP(ctx, rjp::rrl_scan_launch(fields, bursts, time_s, line, h_nu, dev[0], n_chan,
-                                    d_tau_rrl, st));
+  const std::vector<double> ext = burst_ext_table(bursts);
+  const double* src[2] = {h_nu, ext.data()};
+  const size_t len[2] = {(size_t)n_chan, ext.size()};
+  double* dev[2];
+  if (int r = stage_tables(ctx, st, src, len, 2, dev)) return r;
+  RJP_HIP(ctx, rjp::rrl_scan_launch(fields, bursts, ext.empty() ? nullptr : dev[1], time_s, line,
+                                    h_nu, dev[0], n_chan, d_tau_rrl, st));
   return release_tables(ctx, st);
 }
 
@@ -325,11 +348,13 @@ int rjp_ff_cells(rjp_ctx* ctx, const rjp_fields* fields, const rjp_bursts* burst
   if (gff_mode != RJP_GFF_SCALAR && gff_mode != RJP_GFF_POWERLAW)
     return fail(ctx, RJP_ERR_ARG, "bad gff_mode");
   hipStream_t st = (hipStream_t)stream;
-  const double* src[1] = {h_ctau};
-  const size_t len[1] = {(size_t)n_chan};
-  double* dev[1];
-  if (int r = stage_tables(ctx, st, src, len, 1, dev)) return r;
-  RJP_HIP(ctx, rjp::ff_cells_launch(fields, bursts, time_s, gff_mode, dev[0], n_chan, d_tau_cells, st));
+  const std::vector<double> ext = burst_ext_table(bursts);
+  const double* src[2] = {h_ctau, ext.data()};
+  const size_t len[2] = {(size_t)n_chan, ext.size()};
+  double* dev[2];
+  if (int r = stage_tables(ctx, st, src, len, 2, dev)) return r;
+  RJP_HIP(ctx, rjp::ff_cells_launch(fields, bursts, ext.empty() ? nullptr : dev[1], time_s,
+                                    gff_mode, dev[0], n_chan, d_tau_cells, st));
   return release_tables(ctx, st);
 }
 
@@ -342,12 +367,13 @@ int rjp_rrl_cells(rjp_ctx* ctx, const rjp_fields* fields, const rjp_bursts* burs
   if (!line || !h_nu || n_chan < 1 || !d_tau_cells)
     return fail(ctx, RJP_ERR_ARG, "rjp_rrl_cells: NULL line / nu / output or n_chan < 1");
   hipStream_t st = (hipStream_t)stream;
-  const double* src[1] = {h_nu};
-  const size_t len[1] = {(size_t)n_chan};
-  double* dev[1];
-  if (int r = stage_tables(ctx, st, src, len, 1, dev)) return r;
-  RJP_HIP(ctx, rjp::rrl_cells_launch(fields, bursts, time_s, line, h_nu, dev[0], n_chan,
-                                     d_tau_cells, st));
+  const std::vector<double> ext = burst_ext_table(bursts);
+  const double* src[2] = {h_nu, ext.data()};
+  const size_t len[2] = {(size_t)n_chan, ext.size()};
+  double* dev[2];
+  if (int r = stage_tables(ctx, st, src, len, 2, dev)) return r;
+  RJP_HIP(ctx, rjp::rrl_cells_launch(fields, bursts, ext.empty() ? nullptr : dev[1], time_s,
+                                     line, h_nu, dev[0], n_chan, d_tau_cells, st));
   return release_tables(ctx, st);
 }
 
@@ -423,7 +449,7 @@ int rjp_build_fields(rjp_ctx* ctx, const rjp_geometry* gm, int dtype, void* d_nd
       const double amb = a - b;
       auto nonpos_int = [](double v) { return v < 0.5 && fabs(v - nearbyint(v)) < 1e-6; };
       if (nonpos_int(amb) || nonpos_int(b) || nonpos_int(b + 1.) || b == a)
-        return fail(ctx, RJP_ERR_ARG,
+        return fail(ctx, RJP_ERR_DEGENERATE,
                     "rjp_build_fields: degenerate 2F1 parameters (a-b or b a non-positive "
                     "integer); pass d_ts = NULL and upload host-computed launch times");
       g.hy_k1 = b / (b - a);

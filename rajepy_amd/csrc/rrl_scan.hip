@@ -639,10 +639,6 @@ static hipError_t rrl_launch_lf(const rjp_fields* fl, const BurstsDev& b, bool b
   return rrl_launch_t<T, 16>(fl, b, bursts, time_s, ln, d_nu, nchan, tau, st);
 }
 
-hipError_t rrl_scan_launch(const rjp_fields* fl, const rjp_bursts* hb, double time_s,
-                           const rjp_line* line, const double* h_nu, const double* d_nu,
-                           int nchan, double* tau, hipStream_t st);
-
 static void fill_line(const rjp_fields* fl, const rjp_line* line, const double* h_nu, int nchan,
                       LineDev& ln) {
   ln.nu_rest = line->nu_rest; ln.kG = line->kG; ln.kL = line->kL; ln.kappa0 = line->kappa0;
@@ -654,11 +650,11 @@ static void fill_line(const rjp_fields* fl, const rjp_line* line, const double* 
   ln.dnu_max = 0.5 * (hi - lo);
 }
 
-hipError_t rrl_cells_launch(const rjp_fields* fl, const rjp_bursts* hb, double time_s,
-                            const rjp_line* line, const double* h_nu, const double* d_nu,
-                            int nchan, double* out, hipStream_t st) {
+hipError_t rrl_cells_launch(const rjp_fields* fl, const rjp_bursts* hb, const double* d_ext,
+                            double time_s, const rjp_line* line, const double* h_nu,
+                            const double* d_nu, int nchan, double* out, hipStream_t st) {
   BurstsDev b;
-  const bool bursts = bursts_to_dev(hb, b);
+  const bool bursts = bursts_to_dev(hb, b, d_ext);
   if (bursts && !fl->d_ts) return hipErrorInvalidValue;
   LineDev ln;
   fill_line(fl, line, h_nu, nchan, ln);
@@ -679,11 +675,11 @@ hipError_t rrl_cells_launch(const rjp_fields* fl, const rjp_bursts* hb, double t
   return hipGetLastError();
 }
 
-hipError_t rrl_scan_launch(const rjp_fields* fl, const rjp_bursts* hb, double time_s,
-                           const rjp_line* line, const double* h_nu, const double* d_nu,
-                           int nchan, double* tau, hipStream_t st) {
+hipError_t rrl_scan_launch(const rjp_fields* fl, const rjp_bursts* hb, const double* d_ext,
+                           double time_s, const rjp_line* line, const double* h_nu,
+                           const double* d_nu, int nchan, double* tau, hipStream_t st) {
   BurstsDev b;
-  const bool bursts = bursts_to_dev(hb, b);
+  const bool bursts = bursts_to_dev(hb, b, d_ext);
   if (bursts && !fl->d_ts) return hipErrorInvalidValue;
   LineDev ln;
   fill_line(fl, line, h_nu, nchan, ln);

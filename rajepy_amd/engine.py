@@ -70,16 +70,19 @@ class DeviceFields:
 
 def make_bursts(red, blue):
     """Build an rjp_bursts from per-jet lists of (t0_s, amp_rel, sigma_s)
-    (classes.py:442-448: sigma = half_life * 2 / (2 sqrt(2 ln 2)))."""
+    (classes.py:442-448: sigma = half_life * 2 / (2 sqrt(2 ln 2))).  Any number per jet, as
+    the reference (classes.py:245-264)."""
     b = _lib.Bursts()
+    b._keep = []
     for j, lst in enumerate((red, blue)):
-        if len(lst) > _lib.RJP_MAX_BURSTS:
-            raise ValueError("at most %d bursts per jet are supported" % _lib.RJP_MAX_BURSTS)
-        b.n[j] = len(lst)
-        for i, (t0, amp_rel, sigma) in enumerate(lst):
-            b.t0[j][i] = float(t0)
-            b.amp_rel[j][i] = float(amp_rel)
-            b.inv2s2[j][i] = 1.0 / (2.0 * float(sigma) ** 2.0)
+        n = len(lst)
+        b.n[j] = n
+        cols = ([float(t0) for t0, _, _ in lst], [float(a) for _, a, _ in lst],
+                [1.0 / (2.0 * float(sg) ** 2.0) for _, _, sg in lst])
+        for name, col in zip(("t0", "amp_rel", "inv2s2"), cols):
+            arr = (C.c_double * max(n, 1))(*col)
+            b._keep.append(arr)
+            getattr(b, name)[j] = C.cast(arr, C.POINTER(C.c_double))
     return b
 
 
@@ -100,6 +103,7 @@ class RTEngine:
                    "rjp_ctx_create")
         self.ctx = ctx
         self._work = None
+        self.use_compact = not (_lib.DEBUG and os.environ.get("RJP_NO_COMPACT"))
 
     def close(self):
         if getattr(self, "ctx", None):
@@ -173,10 +177,11 @@ class RTEngine:
         (em0, temp, ts) instead of 5 -- bit-identical maps for f64 storage.  Fields with a
         negative path factor (nothing the reference's fill_factor / areas can produce) or,
         in f32 storage, a product outside the float range keep the wide layout.
-        RJP_NO_COMPACT=1 disables it (A/B runs)."""
+        `RTEngine.use_compact = False` keeps every model on the wide layout (A/B runs; with
+        RJP_DEBUG=1 the variable RJP_NO_COMPACT=1 sets it)."""
         torch = _torch()
         fields.em0 = None
-        if os.environ.get("RJP_NO_COMPACT"):
+        if not self.use_compact:
             return fields
         em0 = self._empty(fields.ncells, fields.dtype)
         bad = torch.empty(1, dtype=torch.int64, device=self.device)
@@ -224,7 +229,7 @@ class RTEngine:
     def _direct_em0(self, n, dtype):
         """f64 producers write the compact scan field in their own pass (f32 goes through
         rjp_compact_fields and its range check)."""
-        if dtype != RJP_F64 or os.environ.get("RJP_NO_COMPACT"):
+        if dtype != RJP_F64 or not self.use_compact:
             return None
         return self._f64(n)
 

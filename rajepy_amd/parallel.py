@@ -184,7 +184,7 @@ def xslab_local(model, epochs_s, freqs, rank, world, want_maps=True):
     them and run the map stage for every channel.  Returns (x-range, tau[E,F,nx_loc,n_z] or
     None, flux[...] or None, ftot_partial[E,F]) as device tensors."""
     from . import engine as E
-    from .classes import geometry_struct
+    from .classes import build_model_fields, geometry_struct
     from .maths import physics as mphys
     x0, x1 = SlabShards(model.nx, world).bounds[rank]
     eng = model.engine
@@ -192,10 +192,14 @@ def xslab_local(model, epochs_s, freqs, rank, world, want_maps=True):
     epochs = [float(t) for t in epochs_s]
     F, Ep = len(freqs), len(epochs)
     if x1 == x0:
-        return (x0, x1), None, None, eng._f64(Ep, F).zero_()
+        # more ranks than rows: an EMPTY slab, but well-formed -- zero-length maps and zero
+        # partial fluxes, so that this rank enters every collective of the sweep like its peers
+        empty = eng._f64(Ep, F, 0, model.nz) if want_maps else None
+        return (x0, x1), empty, (empty.clone() if want_maps else None), eng._f64(Ep, F).zero_()
     geom = geometry_struct(model.params, x1 - x0, model.ny, model.nz, ix0=x0,
                            nx_total=model.nx)
-    dev = eng.build_fields(geom, model._dtype, want_ts=True, want_vy=False, want_raw=False)
+    # same degenerate-2F1 fallback as JetModel.device_fields (host launch times of the slab)
+    dev = build_model_fields(model, geom, want_vy=False, want_raw=False)
     gv = None
     if model.gff_mode == E.RJP_GFF_SCALAR:
         gv = [mphys.gff(nu, model.params['properties']['T_0']) for nu in freqs]

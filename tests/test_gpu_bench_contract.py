@@ -11,7 +11,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 REQUIRED = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step",
             "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config",
-            "roofline", "cpu_baseline"}
+            "roofline", "cpu_baseline", "sustained", "ranks_seen"}
 
 
 @pytest.mark.parametrize("config", ["tiny", "tiny_rrl"])
@@ -33,7 +33,15 @@ def test_bench_prints_one_contract_line(config):
     assert "model" not in r["config"]
     assert r["value"] > 0 and r["ms_per_step"] > 0
     rf = r["roofline"]
-    assert {"bound", "achieved", "peak", "unit", "frac", "traffic"} <= set(rf)
+    assert {"bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_source",
+            "algorithmic_bytes", "algorithmic_bytes_8d"} <= set(rf)
+    if config == "tiny":
+        # 8(d)'s five-field byte model is priced on the kernel that moves those bytes
+        assert rf["fields_streamed_per_cell"] == 3 and rf["algorithmic_bytes_8d"] > rf["algorithmic_bytes"]
+        assert rf["wide_ms_per_launch"] > 0 and rf["layout_build_ms"] > 0 and rf["frac_8d"] > 0
+        assert r["api_level"]["ms_per_step"] >= r["ms_per_step"] * 0.5
+    assert r["sustained"]["steps"] >= 3 and r["sustained"]["ms_per_step"] > 0
+    assert r["ranks_seen"] == 1 and r["storage_dtype"] == "f64"
     assert rf["bound"] == "hbm" and rf["peak"] == 8000.0 and rf["unit"] == "GB/s"
     assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12
     cb = r["cpu_baseline"]
@@ -49,5 +57,35 @@ def test_bench_prints_one_contract_line(config):
 
 def test_bench_refuses_mismatched_world_size():
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2",
-                          "--config", "tiny"], capture_output=True, text=True, timeout=300)
+                          "--config", "tiny"], capture_output=True, text=True, timeout=300,
+                         env=dict(os.environ, WORLD_SIZE="3", RANK="0", LOCAL_RANK="0"))
     assert out.returncode == 2 and "WORLD_SIZE" in out.stderr
+
+
+@pytest.mark.parametrize("config,sharding,scaling", [("tiny", "epochs", "weak"),
+                                                     ("tiny5", "xslab", "strong")])
+def test_bench_launches_its_own_ranks(config, sharding, scaling):
+    """`python bench.py --gpus 2` with no WORLD_SIZE starts two child ranks itself and relays
+    rank 0's line (here both ranks share the one GPU of the box and talk over gloo; on an
+    8-GPU node the same path runs one rank per GPU over RCCL)."""
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2",
+                          "--steps", "3", "--warmup", "1", "--config", config, "--backend",
+                          "gloo", "--share-gpu", "--sustained-seconds", "0.05"],
+                         capture_output=True, text=True, timeout=900, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, lines
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 2 and r["ranks_seen"] == 2 and r["scaling"] == scaling
+    assert r["config"]["sharding"] == sharding and r["value"] > 0
+    assert r["n1"]["value"] > 0
+    if config == "tiny":
+        # weak (timed region) + the labelled strong and channel-sharded legs, one line
+        assert set(r["legs"]) == {"strong_xslab", "channel_sharded"}
+        for leg in r["legs"].values():
+            assert leg["scaling"] == "strong" and leg["value"] > 0 and leg["speedup_vs_n1"] > 0
+    else:
+        assert "32 epoch(s) per step" in r["config"]["workload"]
+        assert r["roofline"]["epochs_per_launch"] == 32 and r["roofline"]["grid_passes_per_launch"] == 1

@@ -1,5 +1,7 @@
-"""Full-size GPU checks at BASELINE.json's grid sizes (512x4096x512 continuum, 512x2048x512
-RRL).  The oracle cannot run a billion cells, so parity is checked (a) EXACTLY on a random
+"""Full-size GPU checks at BASELINE.json's grid sizes and channel / epoch counts (cfg2
+256x1024x256 x 32 ch; cfg3 512x2048x512 x 256 H66a channels; cfg4 512x4096x512 continuum;
+cfg5 512x4096x512 x 64 ch x 32 epochs), so that every kernel instantiation a bench
+configuration dispatches is checked at the size it runs at.  The oracle cannot run a billion cells, so parity is checked (a) EXACTLY on a random
 sample of sightlines -- sightlines are independent, so the sampled columns are regenerated on
 the host from the counter hash, stacked as a (k, n_y, 1) grid and run through the oracle --
 and (b) through size-independent properties: an 8-epoch fused pass equals eight single-epoch
@@ -114,6 +116,132 @@ def test_cfg3_rrl_full_size(eng):
     nchan = 40
     nu0 = rrls.rrl_nu_0("H", 66, 1)
     rf = orc.chan_freqs(nu0, nchan * 6e5, 6e5)            # +-12 MHz: core, wings and far field
+    line = _lib.Line(**rrls.line_constants("H66a"))
+    tau = eng.rrl_scan(fields, U.bursts_from_oracle(jet), jet.time, line, rf)
+    eng.synchronize()
+    idx = [x * nz + z for (x, z) in pix]
+    got = tau.cpu().numpy()[:, idx]
+    ref = jet.optical_depth_rrl("H66a", np.asarray(rf))[:, :, 0]
+    np.testing.assert_allclose(got, ref, rtol=1e-9)
+    assert bool(torch_all_finite(tau))
+
+
+def _edge_pixels(nx, nz, tile):
+    """Sightlines the random sample would miss by construction: the first and the last
+    workgroup of the scan kernels (K1: 256 lanes x VEC sightlines = whole x-rows; K3: `tile`
+    z-adjacent sightlines per workgroup), both sides of the red/blue jet plane (waves that
+    straddle it select burst parameters per lane) and both sides of a tile boundary.  Every
+    sightline crosses every y-split boundary (a split is a y-range of all sightlines)."""
+    return [(0, 0), (0, tile - 1), (0, tile), (0, nz - 1), (nx - 1, 0), (nx - 1, nz - tile),
+            (nx - 1, nz - tile - 1), (nx - 1, nz - 1), (nx // 2, nz // 2 - 1),
+            (nx // 2, nz // 2), (nx - 1, nz // 2 - 1), (nx - 1, nz // 2)]
+
+
+def test_cfg2_continuum_full_size(eng):
+    """BASELINE configs[1]: 256x1024x256 grid, 32 continuum channels 1-50 GHz, one epoch --
+    the two-sightlines-per-lane kernel with 16 y-splits of 64 rows.  Sampled sightlines
+    against the oracle exactly; flux totals against the cube."""
+    from rajepy_amd import engine as E
+    from rajepy_amd.maths import physics as ph
+    shape = (256, 1024, 256)
+    nx, ny, nz = shape
+    fields = eng.synth_fields(shape, SEED, 0, 8, csize_au=0.5)
+    rng = np.random.default_rng(2)
+    pix = [(int(rng.integers(nx)), int(rng.integers(nz))) for _ in range(16)]
+    pix += _edge_pixels(nx, nz, 2)
+    jet = _sample_jet(shape, pix, 0, 0.)
+    jet.time = 1.0 * orc.YEAR
+    bursts = U.bursts_from_oracle(jet)
+    freqs = np.geomspace(1e9, 5e10, 32)
+    gv = [ph.gff(nu, 1e4) for nu in freqs]
+    ctau, cflux = E.ff_channel_coeffs(freqs, 0.5, 120., E.RJP_GFF_SCALAR, gv)
+    sumA, em, tavg = eng.ff_scan(fields, bursts, [jet.time], E.RJP_GFF_SCALAR)
+    tau, flux, ftot = eng.ff_maps(sumA, tavg, ctau, cflux)
+    eng.synchronize()
+    idx = [x * nz + z for (x, z) in pix]
+    np.testing.assert_allclose(tau.cpu().numpy()[0][:, idx],
+                               jet.optical_depth_ff(freqs)[:, :, 0], rtol=1e-10)
+    np.testing.assert_allclose(flux.cpu().numpy()[0][:, idx], jet.flux_ff(freqs)[:, :, 0],
+                               rtol=1e-10)
+    np.testing.assert_allclose(em.cpu().numpy()[0][idx], jet.emission_measure()[:, 0],
+                               rtol=1e-10)
+    np.testing.assert_allclose(ftot.cpu().numpy(), flux.nansum(dim=2).cpu().numpy(), rtol=1e-12)
+    assert bool(torch_all_finite(tau)) and float(tau.min().item()) > 0.0
+
+
+def test_cfg5_epoch_sweep_full_size(eng):
+    """BASELINE configs[4]: 512x4096x512, 64 channels x 32 uniformly spaced epochs,
+    flux-vs-time output (no EM maps) -> ONE pass of the 32-epoch tile
+    (ff_scan_kernel<double,1,32,..,EM=false>).  Sampled sightlines against the oracle at
+    epochs 0/15/31; the whole [32, P] result against the same sweep done with EM maps, which
+    takes two 16-epoch tiles anchored at other epochs (same numbers to rounding, 1e-11, not
+    bit for bit: the recurrences start from different anchors); light curves against the
+    sum of the flux maps."""
+    from rajepy_amd import engine as E
+    from rajepy_amd.maths import physics as ph
+    shape = (512, 4096, 512)
+    nx, ny, nz = shape
+    fields = eng.synth_fields(shape, SEED, 0, 8, csize_au=0.5)
+    rng = np.random.default_rng(7)
+    pix = [(int(rng.integers(nx)), int(rng.integers(nz))) for _ in range(12)]
+    pix += _edge_pixels(nx, nz, 1)
+    jet = _sample_jet(shape, pix, 0, 0.)
+    bursts = U.bursts_from_oracle(jet)
+    ep = [float(t) for t in np.linspace(0., 5., 32) * orc.YEAR]
+    freqs = np.geomspace(1e9, 5e10, 64)
+    gv = [ph.gff(nu, 1e4) for nu in freqs]
+    ctau, cflux = E.ff_channel_coeffs(freqs, 0.5, 120., E.RJP_GFF_SCALAR, gv)
+    a32, none, tavg = eng.ff_scan(fields, bursts, ep, E.RJP_GFF_SCALAR, want_em=False)
+    assert none is None
+    _, _, ftot = eng.ff_maps(a32, tavg, ctau, cflux, want_tau=False, want_flux=False)
+    eng.synchronize()
+    assert tuple(ftot.shape) == (32, 64)
+    idx = [x * nz + z for (x, z) in pix]
+    a_s = a32.cpu().numpy()[:, idx]
+    t_s = tavg.cpu().numpy()[idx]
+    for e in (0, 15, 31):
+        jet.time = ep[e]
+        ref_tau = jet.optical_depth_ff(freqs)[:, :, 0]
+        ref_flux = jet.flux_ff(freqs)[:, :, 0]
+        np.testing.assert_allclose(ctau[:, None] * a_s[e][None, :], ref_tau, rtol=1e-10)
+        got_flux = cflux[:, None] * (t_s[None, :] * (1. - np.exp(-ctau[:, None] * a_s[e][None, :])))
+        np.testing.assert_allclose(got_flux, ref_flux, rtol=1e-10)
+    # light curves == sums of the flux maps (three epochs; the cubes of all 32 would be 17 GB)
+    for e in (0, 15, 31):
+        _, fl, _ = eng.ff_maps(a32[e:e + 1].contiguous(), tavg, ctau, cflux, want_tau=False,
+                               want_ftot=False)
+        np.testing.assert_allclose(ftot[e].cpu().numpy(), fl[0].nansum(dim=1).cpu().numpy(),
+                                   rtol=1e-12)
+        del fl
+    # the same sweep through the 16-epoch tiles (with EM maps)
+    a32 = a32.clone()
+    a16, em16, _ = eng.ff_scan(fields, bursts, ep, E.RJP_GFF_SCALAR, want_em=True)
+    eng.synchronize()
+    rel = ((a16 - a32).abs() / a32).max().item()
+    assert rel < 1e-11, rel
+    jet.time = ep[31]
+    np.testing.assert_allclose(em16.cpu().numpy()[31][idx], jet.emission_measure()[:, 0],
+                               rtol=1e-10)
+
+
+def test_cfg3_rrl_256_channels_full_size(eng):
+    """BASELINE configs[2] as benchmarked: 512x2048x512, 256 H66a channels of 100 kHz -> the
+    256-lane kernel (rrl_scan_kernel<double,256,true>).  Sampled sightlines, including the
+    first and last 8-sightline tiles, against the oracle (scipy's wofz)."""
+    from rajepy_amd import _lib
+    from rajepy_amd.maths import rrls
+    shape = (512, 2048, 512)
+    nx, ny, nz = shape
+    fields = eng.synth_fields(shape, SEED, 0, 8, csize_au=0.5, with_vy=True)
+    rng = np.random.default_rng(13)
+    pix = [(int(rng.integers(nx)), int(rng.integers(nz))) for _ in range(6)]
+    pix += _edge_pixels(nx, nz, 8)
+    jet = _sample_jet(shape, pix, 0, 0.)
+    jet.time = 1.0 * orc.YEAR
+    nchan = 256
+    nu0 = rrls.rrl_nu_0("H", 66, 1)
+    rf = orc.chan_freqs(nu0, nchan * 1e5, 1e5)
+    assert len(rf) == nchan
     line = _lib.Line(**rrls.line_constants("H66a"))
     tau = eng.rrl_scan(fields, U.bursts_from_oracle(jet), jet.time, line, rf)
     eng.synchronize()

@@ -1,0 +1,229 @@
+"""GPU parity tests added in round 2: any number of bursts per jet (the reference registers
+every row of params["ejection"], classes.py:245-264), helium lines through K3, the dedicated
+degenerate-2F1 status, a bounded base-map cache, and x-slab sweeps with more ranks than rows."""
+import copy
+import os
+import socket
+
+import numpy as np
+import pytest
+
+from oracle import rt_oracle as orc
+from tests import gpu_util as U
+
+pytestmark = pytest.mark.gpu
+YEAR = orc.YEAR
+
+
+@pytest.fixture(scope="module")
+def eng():
+    from rajepy_amd.engine import RTEngine
+    e = RTEngine(0)
+    yield e
+    e.close()
+
+
+def _many_bursts(n_rb=12, extra_blue=1, seed=3):
+    """n_rb bursts hitting both jets + `extra_blue` blue-only ones: 12 red / 13 blue."""
+    rng = np.random.default_rng(seed)
+    n = n_rb + extra_blue
+    return {"t_0": np.sort(rng.uniform(0.2, 3.0, n)), "hl": rng.uniform(0.1, 0.5, n),
+            "chi": rng.uniform(0.4, 6.0, n),          # some dips (chi < 1) among the bursts
+            "which": np.array(["RB"] * n_rb + ["B"] * extra_blue)}
+
+
+def _jet(shape, seed, temp_mode, q_T, ejection):
+    g = U.synth_host(shape, seed, temp_mode)
+    p = copy.deepcopy(U.load_golden("cfg1_example")[2])
+    p["ejection"] = ejection
+    p["power_laws"]["q_T"] = q_T
+    p["grid"].update(n_x=shape[0], n_y=shape[1], n_z=shape[2])
+    jet = orc.OracleJet.from_fields(p, g["nd"], g["xi"], g["temp"], g["ff"], g["areas"],
+                                    g["ts"], g["rr"], g["vy"])
+    return jet, p
+
+
+@pytest.mark.parametrize("store,tol", [(8, 1e-11), (4, 1e-5)])
+def test_more_than_eight_bursts_per_jet_k1(eng, store, tol):
+    """12 red + 13 blue bursts: the first eight of a jet travel as scalar kernel arguments,
+    the rest in the staged device table.  Direct evaluation (irregular epochs), the
+    uniform-epoch recurrence with EM maps (16-epoch tiles) and without (32-epoch tile), all
+    against the oracle's chained closures."""
+    from rajepy_amd import engine as E
+    shape = (4, 41, 16)                  # z = 8 splits the jets inside one wave: mixed lanes
+    seed = 20240521
+    ej = _many_bursts()
+    jet, p = _jet(shape, seed, 0, 0., ej)
+    assert len(jet.bursts["R"]) == 12 and len(jet.bursts["B"]) == 13
+    fields = eng.synth_fields(shape, seed, 0, store, csize_au=0.5)
+    bursts = U.bursts_from_oracle(jet)
+    assert bursts.n[0] == 12 and bursts.n[1] == 13
+    ctau, _ = E.ff_channel_coeffs([5e9], jet.csize, p["target"]["dist"], E.RJP_GFF_SCALAR,
+                                  [orc.gff(5e9, 1e4)])
+
+    def check(years, want_em):
+        ep = [y * YEAR for y in years]
+        sumA, em, _ = eng.ff_scan(fields, bursts, ep, E.RJP_GFF_SCALAR, want_em=want_em)
+        eng.synchronize()
+        got = sumA.cpu().numpy().reshape(len(ep), shape[0], shape[2]) * ctau[0]
+        pick = sorted({0, 1, len(ep) // 2, len(ep) - 1})
+        for e in pick:
+            jet.time = ep[e]
+            np.testing.assert_allclose(got[e], jet.optical_depth_ff(5e9), rtol=tol)
+            if want_em:
+                np.testing.assert_allclose(em.cpu().numpy()[e].reshape(shape[0], shape[2]),
+                                           jet.emission_measure(), rtol=tol)
+
+    check([0.0, 0.33, 0.9, 1.7, 2.95], True)              # direct: tiles of 4 + 1
+    check(list(np.linspace(0., 3., 16)), True)            # uniform recurrence, 16-epoch tile
+    check(list(np.linspace(0., 3.1, 32)), False)          # uniform recurrence, 32-epoch tile
+    check(list(np.linspace(0., 3.1, 37)), False)          # 32 + a tail of direct tiles
+
+
+def test_more_than_eight_bursts_per_jet_k3_and_cells(eng):
+    from rajepy_amd import _lib, engine as E
+    from rajepy_amd.maths import rrls
+    shape = (3, 29, 16)
+    seed = 20240522
+    jet, p = _jet(shape, seed, 1, -0.5, _many_bursts(seed=5))
+    jet.time = 1.3 * YEAR
+    fields = eng.synth_fields(shape, seed, 1, 8, csize_au=0.5, with_vy=True)
+    bursts = U.bursts_from_oracle(jet)
+    rf = orc.chan_freqs(rrls.rrl_nu_0("H", 66, 1), 20 * 4e5, 4e5)
+    line = _lib.Line(**rrls.line_constants("H66a"))
+    tau = eng.rrl_scan(fields, bursts, jet.time, line, rf)
+    cells = eng.rrl_cells(fields, bursts, jet.time, line, rf[:3])
+    ctau, _ = E.ff_channel_coeffs([5e9], jet.csize, p["target"]["dist"], E.RJP_GFF_POWERLAW)
+    ffc = eng.ff_cells(fields, bursts, jet.time, E.RJP_GFF_POWERLAW, ctau)
+    eng.synchronize()
+    ref = jet.optical_depth_rrl("H66a", np.asarray(rf))
+    np.testing.assert_allclose(tau.cpu().numpy().reshape(ref.shape), ref, rtol=1e-9)
+    np.testing.assert_allclose(cells.cpu().numpy().reshape((3,) + shape),
+                               jet.optical_depth_rrl("H66a", np.asarray(rf[:3]), collapse=False),
+                               rtol=1e-9)
+    np.testing.assert_allclose(ffc.cpu().numpy().reshape(shape),
+                               jet.optical_depth_ff(5e9, collapse=False), rtol=1e-11)
+
+
+@pytest.mark.parametrize("rrl,nchan,cw", [("He42b", 24, 4e6), ("He66a", 40, 3e5),
+                                          ("He58a", 300, 2e5)])
+def test_helium_lines_against_the_oracle(eng, rrl, nchan, cw):
+    """maths/rrls.py handles helium (Z = 2 rest frequencies and level energies, the He mass
+    in the thermal width, the He ion fraction; rrls.py:14-41, 62-83, 104-118).  K3 gets all of
+    that through `rjp_line`: 16-, 64- and 256-lane layouts against scipy's wofz."""
+    from rajepy_amd import _lib
+    from rajepy_amd.maths import rrls
+    shape = (3, 33, 16)
+    seed = 20240523
+    jet, p = _jet(shape, seed, 1, -0.5, U.example_bursts_params())
+    jet.time = 0.8 * YEAR
+    fields = eng.synth_fields(shape, seed, 1, 8, csize_au=0.5, with_vy=True)
+    el, n, dn = rrls.rrl_parser(rrl)
+    assert el == "He"
+    rf = orc.chan_freqs(rrls.rrl_nu_0(el, n, dn), nchan * cw, cw)
+    line = _lib.Line(**rrls.line_constants(rrl))
+    tau = eng.rrl_scan(fields, U.bursts_from_oracle(jet), jet.time, line, rf)
+    eng.synchronize()
+    ref = jet.optical_depth_rrl(rrl, np.asarray(rf))
+    assert np.isfinite(ref).all() and (ref > 0).all()
+    np.testing.assert_allclose(tau.cpu().numpy().reshape(ref.shape), ref, rtol=1e-9)
+
+
+def test_degenerate_2f1_has_its_own_status_and_only_it_falls_back(eng, tmp_path, monkeypatch):
+    from rajepy_amd import _lib, classes, logger
+    from rajepy_amd.classes import geometry_struct
+    z, meta, p = U.load_golden("tilted")
+    p["power_laws"]["q_v"] = 1. - p["geometry"]["epsilon"]               # -> b = a + 1
+    jet = orc.OracleJet(copy.deepcopy(p))
+    geom = geometry_struct(jet.params, jet.nx, jet.ny, jet.nz)
+    with pytest.raises(_lib.RjprtError) as ei:
+        eng.build_fields(geom, 8, want_ts=True)
+    assert ei.value.status == _lib.RJP_ERR_DEGENERATE
+    # JetModel answers exactly that status with the reference's own host integral ...
+    q = copy.deepcopy(p)
+    for k in ("q_n", "q_tau"):
+        q["power_laws"].pop(k, None)
+    q["geometry"].pop("mod_r_0", None)
+    q["properties"].pop("n_0", None)
+    log = logger.Log(str(tmp_path / "a.log"), verbose=False)
+    jm = classes.JetModel(q, log=log, engine=eng)
+    ts_dev = jm.device_fields.ts.cpu().numpy().reshape(jet.nx, jet.ny, jet.nz)
+    inside = np.isfinite(jet.nd0)
+    np.testing.assert_allclose(ts_dev[inside], jet.ts0[inside], rtol=1e-10, atol=1e-3)
+    # ... and the x-slab path takes the same fallback
+    from rajepy_amd import parallel as par
+    (x0, x1), tau, _, _ = par.xslab_local(jm, [0.5 * YEAR], [5e9], 1, 3)
+    jm.time = 0.5 * YEAR
+    np.testing.assert_array_equal(tau[0, 0].cpu().numpy(), jm.optical_depth_ff(5e9)[x0:x1])
+    # ... while any other failure of the builder surfaces unchanged
+    jm2 = classes.JetModel(copy.deepcopy(q), log=log, engine=eng)
+
+    def broken(*a, **k):
+        raise _lib.RjprtError("rjp_build_fields failed (status -2): hipErrorLaunchFailure",
+                              status=_lib.RJP_ERR_HIP)
+    monkeypatch.setattr(eng, "build_fields", broken)
+    with pytest.raises(_lib.RjprtError, match="hipErrorLaunchFailure"):
+        jm2.device_fields
+
+
+def test_base_map_cache_is_bounded(eng, tmp_path):
+    from rajepy_amd import classes, logger
+    from tests.test_host_logic import example_params
+    jm = classes.JetModel(example_params(), log=logger.Log(str(tmp_path / "a.log"),
+                                                           verbose=False), engine=eng)
+    jm.SCAN_CACHE_EPOCHS = 4
+    times = np.linspace(0., 3., 10) * YEAR
+    jm.prefetch_epochs(times)
+    assert len(jm._scan_cache) == 4 and list(jm._scan_cache) == [float(t) for t in times[:4]]
+    for t in times[[0, 5, 9, 2]]:
+        jm.time = t
+        jm.flux_ff(5e9)
+        assert len(jm._scan_cache) <= 4
+    # entries own their maps (a slice would pin the whole [E, P] result of its scan)
+    a, e = jm._scan_cache[float(times[2])]
+    assert a.numel() == jm.nx * jm.nz and a.untyped_storage().nbytes() == a.numel() * 8
+    ref = jm.flux_ff(5e9)
+    jm._invalidate()
+    np.testing.assert_array_equal(np.nan_to_num(jm.flux_ff(5e9)), np.nan_to_num(ref))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _xslab_worker(rank, world, port, ret):
+    import torch.distributed as dist
+    from rajepy_amd import classes, logger, parallel as par
+    from tests.test_host_logic import example_params
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RJP_DEVICE="0")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        p = example_params()
+        p["grid"].update(n_x=2, n_y=40, n_z=16)
+        jm = classes.JetModel(p, log=logger.Log(os.devnull, verbose=False))
+        epochs, freqs = np.array([0., 0.7]) * YEAR, np.array([2e9, 2e10])
+        ft, tau, flux = par.sweep_xslab(jm, epochs, freqs, rank, world, gather_maps=True)
+        ok = tau.shape == (2, 2, 2, 16) and flux.shape == tau.shape
+        for e, t in enumerate(epochs):
+            jm.time = t
+            ok = ok and np.array_equal(tau[e], jm.optical_depth_ff(freqs))
+            f = jm.flux_ff(freqs)
+            ok = ok and np.array_equal(np.nan_to_num(flux[e]), np.nan_to_num(f))
+            ok = ok and np.allclose(ft[e], np.nansum(f, axis=(1, 2)), rtol=1e-12)
+        ret[rank] = bool(ok)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_xslab_sweep_with_more_ranks_than_rows():
+    """3 ranks, 2 rows: the third rank's slab is empty; it must still enter the all_reduce
+    and both all_gathers (zero-length blocks) instead of raising alone and leaving its peers
+    in the collective.  Three processes share the one GPU of the box and talk over gloo."""
+    import torch.multiprocessing as mp
+    ret = mp.Manager().dict()
+    mp.spawn(_xslab_worker, args=(3, _free_port(), ret), nprocs=3, join=True)
+    assert all(ret[r] for r in range(3)), dict(ret)

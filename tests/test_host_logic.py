@@ -10,6 +10,7 @@ import re
 import numpy as np
 import pytest
 
+from rajepy_amd import _constants as con
 from rajepy_amd import _lib, classes, fits, logger
 from rajepy_amd.maths import geometry as mgeom, physics as mphys, rrls as mrrl
 from rajepy_amd.miscellaneous import functions as miscf
@@ -54,7 +55,7 @@ def test_abi_exports_every_declared_symbol():
 
 def test_abi_struct_layouts_match_header():
     assert ctypes.sizeof(_lib.Fields) == 6 * 8 + 4 * 4 + 8 + 3 * 8
-    assert ctypes.sizeof(_lib.Bursts) == 8 + 3 * 2 * 8 * 8
+    assert ctypes.sizeof(_lib.Bursts) == 8 + 3 * 2 * 8            # counts + 6 host pointers
     assert ctypes.sizeof(_lib.Line) == 6 * 8
     assert ctypes.sizeof(_lib.Geometry) == 4 * 4 + 24 * 8 + 2 * 4
     assert _lib.Geometry.rb_frac.offset == 4 * 4 + 23 * 8
@@ -302,3 +303,28 @@ def test_graft_entry_build_compiles_and_binds():
     bind every symbol (no GPU needed)."""
     import __graft_entry__ as g
     g.build()
+
+
+def test_any_number_of_bursts_and_lower_case_jet_names(tmp_path):
+    """The reference registers every row of params["ejection"] (classes.py:245-264) and takes
+    `which` in either case (which.upper(), classes.py:450-455): no cap on the burst count."""
+    p = example_params()
+    n = 11
+    p["ejection"] = {"t_0": np.linspace(0.1, 3., n), "hl": np.full(n, 0.2),
+                     "chi": np.full(n, 2.0), "which": np.array(["RB"] * n)}
+    jm = make_model(tmp_path, p)
+    assert len(jm._bursts['R']) == n and len(jm._bursts['B']) == n
+    jm.add_ejection_event(1.0 * con.year, 3. * jm.ss_jml('R'), 0.1 * con.year, which='r')
+    jm.add_ejection_event(1.0 * con.year, 3. * jm.ss_jml('B'), 0.1 * con.year, which='b')
+    assert len(jm._bursts['R']) == n + 1 and len(jm._bursts['B']) == n + 1
+    assert jm.ejections[str(2 * n + 1)]['which'] == 'R'
+    with pytest.raises(ValueError):
+        jm.add_ejection_event(0., 1., 1., which='x')
+    b = jm._rjp_bursts()                     # ctypes struct: counts + host pointers
+    assert b.n[0] == n + 1 and b.n[1] == n + 1
+    assert b.t0[0][n] == 1.0 * con.year and b.amp_rel[1][n] == pytest.approx(2.0)
+    # mdot(t) closure of the host mirror follows the same chain (classes.py:442-448)
+    t = 1.0 * con.year
+    want = jm.ss_jml('R') * (1. + sum(a * np.exp(-(t - t0) ** 2. / (2. * s ** 2.))
+                                      for t0, a, s in jm._bursts['R']))
+    assert jm.jml_t('R')(t) == pytest.approx(want, rel=1e-14)

@@ -108,3 +108,87 @@ def test_pipeline_epoch_sharding_gloo(tmp_path):
     ret = mgr.dict()
     mp.spawn(_pipeline_worker, args=(2, _free_port(), dcy, ret), nprocs=2, join=True)
     assert all(ret[r] for r in range(2)), dict(ret)
+
+
+@pytest.mark.parametrize("config,world,legs", [("tiny", 2, {"epochs", "xslab", "channels"}),
+                                               ("tiny5", 3, {"xslab"})])
+def test_bench_self_launch_rehearsal(config, world, legs):
+    """`python bench.py --gpus N` with no WORLD_SIZE in the environment must start its own N
+    ranks (children under torch.distributed.run) and relay rank 0's single JSON line.  Driven
+    here end to end without a GPU: --rehearse-cpu runs launcher, shard planners and the
+    step's collective under gloo on placeholder vectors (no kernels, no throughput)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(world),
+                          "--steps", "2", "--warmup", "1", "--config", config,
+                          "--rehearse-cpu"], capture_output=True, text=True, timeout=600,
+                         env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, lines
+    r = json.loads(lines[0])
+    assert r["rehearsal"] is True and r["value"] is None
+    assert r["n_gpus"] == world and r["ranks_seen"] == world
+    assert set(r["legs"]) == legs and all(v["ok"] for v in r["legs"].values())
+    assert r["scaling"] == ("weak" if config == "tiny" else "strong")
+
+
+def test_bench_refuses_mismatched_world_size_cpu():
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2",
+                          "--config", "tiny", "--rehearse-cpu"], capture_output=True, text=True,
+                         timeout=300, env=dict(os.environ, WORLD_SIZE="3", RANK="0"))
+    assert out.returncode == 2 and "WORLD_SIZE" in out.stderr
+
+
+def _failing_pipeline_worker(rank, world, port, dcy, ret):
+    """One rank's run raises: every rank must still reach the result gather and the barrier
+    and then raise -- not leave its peers waiting in a collective."""
+    from rajepy_amd import classes, logger
+    from tests.test_host_logic import example_params, pline_params
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        log = logger.Log(os.path.join(dcy, "rank%d.log" % rank), verbose=False)
+        pp = pline_params(dcy)
+        pp["continuum"]["times"] = np.array([0., 0.5, 1., 1.5])
+
+        class P(classes.Pipeline):
+            def _radiative_transfer(self, idx, run, clobber):
+                if rank == 1:
+                    raise ValueError("boom in run %d" % (idx + 1))
+                self.runs[idx].results["flux"] = 1.0
+
+        model = classes.JetModel(example_params(), log=log)
+        model.prefetch_epochs = lambda times: None          # no GPU here
+        pl = P(model, pp, log=log)
+        try:
+            pl.execute(simobserve=False, verbose=False, dryrun=False, resume=False, clobber=True)
+            ret[rank] = "no exception"
+        except RuntimeError as exc:
+            ok = "rank 1" in str(exc) and "boom" in str(exc) and "ValueError" in str(exc)
+            if rank == 0:
+                # rank 0 finished its own runs and wrote the state before re-raising
+                done = [r.completed for r in pl.runs]
+                ok = ok and any(done) and not all(done)
+                ok = ok and os.path.exists(os.path.join(dcy, "pipeline.save"))
+            ret[rank] = bool(ok)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_pipeline_failure_on_one_rank_does_not_hang_the_others(tmp_path):
+    dcy = str(tmp_path / "out")
+    os.makedirs(dcy)
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_failing_pipeline_worker, args=(2, _free_port(), dcy, ret), nprocs=2, join=True)
+    assert ret[0] is True and ret[1] is True, dict(ret)
