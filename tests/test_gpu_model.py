@@ -154,6 +154,28 @@ def test_maps_follow_reynolds86_analytic_optical_depth(tmp_path):
     assert slope == pytest.approx(pl["q_tau"], abs=0.3)          # tau ~ rho^q_tau
 
 
+def test_maps_follow_reynolds86_analytic_flux(tmp_path):
+    """Physics cross-check (what the reference's sed_plot draws,
+    plotting/functions.py:1194-1200): the total flux of the steady-state example jet's maps
+    follows Reynolds' (1986) exact analytic flux of the two lobes integrated to the edge of
+    the grid -- within 10-20 % (his Gaunt approximation vs van Hoof's table, half-cell
+    discretisation of the jet edge), over 1-50 GHz, i.e. from mostly thick to mostly thin."""
+    from rajepy_amd.maths import physics as mphys
+    p = example_params()
+    p["ejection"] = {k: np.array([]) for k in ("t_0", "hl", "chi", "which")}
+    jm = classes.JetModel(p, log=logger.Log(str(tmp_path / "a.log"), verbose=False))
+    half = jm.nz / 2 * jm.csize / jm.params["target"]["dist"]        # lobe length [arcsec]
+    freqs = np.array([1e9, 5e9, 2e10, 5e10])
+    tot = np.nansum(jm.flux_ff(freqs), axis=(1, 2))
+    ana = np.array([sum(mphys.flux_expected_r86(jm, nu, w, half) for w in "RB") for nu in freqs])
+    ratio = tot / ana
+    assert np.all((ratio > 0.85) & (ratio < 1.25)), ratio
+    # spectral index between 5 and 20 GHz of maps and analytic model agree
+    a_map = np.log(tot[2] / tot[1]) / np.log(4.)
+    a_ana = np.log(ana[2] / ana[1]) / np.log(4.)
+    assert a_map == pytest.approx(a_ana, abs=0.12)
+
+
 def test_collapse_false_and_vel(tmp_path):
     """collapse=False returns the un-summed per-cell optical depths whose y-sum is the map;
     vel returns all three components (tilted model: every rotation term is exercised)."""
