@@ -8,7 +8,13 @@
 set -euo pipefail
 here="$(cd "$(dirname "${BASH_SOURCE[0]}")" && pwd)"
 out="$here/../librjprt.so"
-flags=(--offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -Wall -Wno-unused-function)
+# -disable-machine-licm: the backend otherwise hoists every FP64 constant (VOP3 takes no
+# literal, so each is a register pair) out of the scan loops and then spills them -- K3 carried
+# 192-312 B/lane of scratch reloads INSIDE its channel loop that way.  Without the hoisting
+# constants are rematerialised where used: K3 -17 % (0 spills in the loop), the 32-epoch K1
+# tile 169 -> 164 VGPRs = 3 waves/SIMD instead of 2 (-3 %), the single-epoch K1 unchanged
+# (A/B in profiles/r02_build_flags_ab.md).
+flags=(--offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -Wall -Wno-unused-function -mllvm -disable-machine-licm)
 if [[ "${1:-}" == "--report" ]]; then
   hipcc "${flags[@]}" -Rpass-analysis=kernel-resource-usage -o "$out" "$here/rjprt.hip" 2> "$here/../../gpurun_out/resource_usage.txt" || { cat "$here/../../gpurun_out/resource_usage.txt"; exit 1; }
   python3 - "$here/../../gpurun_out/resource_usage.txt" <<'PY'

@@ -91,6 +91,68 @@ __device__ __forceinline__ double cos_2pi(double u) {
   return ((int)k & 1) ? -p : p;
 }
 
+// cos(2 pi u) of three arguments in lockstep: half-turn reduction, one even polynomial on
+// |w| <= pi/2 (truncation 2e-17); the coefficients are shared and live in SGPRs (see fma_k
+// below -- declared here because the pole term of the wave-uniform lattice uses it).
+__device__ __forceinline__ double fma_k(double a, double b, double K);
+__device__ __forceinline__ double kfma(double K, double b, double c);
+__device__ __forceinline__ double kadd(double K, double b);
+__device__ __forceinline__ double kmul(double K, double b);
+__device__ __forceinline__ void cos_2pi_x3(double u0, double u1, double u2, double& c0,
+                                           double& c1, double& c2) {
+  const double u[3] = {u0, u1, u2};
+  double k[3], w2[3], p[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    k[i] = __builtin_rint(2.0 * u[i]);
+    const double w = kmul(6.28318530717958647692, __builtin_fma(-0.5, k[i], u[i]));
+    w2[i] = w * w;
+  }
+  constexpr double cf[9] = {-1.5619206968586226462e-16,   // -1/18!
+                            4.7794773323873852974e-14,    //  1/16!
+                            -1.1470745597729724714e-11,   // -1/14!
+                            2.0876756987868098979e-09,    //  1/12!
+                            -2.7557319223985888276e-07,   // -1/10!
+                            2.4801587301587301566e-05,    //  1/8!
+                            -1.3888888888888889419e-03,   // -1/6!
+                            4.1666666666666664354e-02,    //  1/4!
+                            -0.5};
+#pragma unroll
+  for (int i = 0; i < 3; ++i) p[i] = kadd(cf[0], kmul(4.1103176233121648585e-19, w2[i]));   // 1/20!
+#pragma unroll
+  for (int j = 1; j < 8; ++j)
+#pragma unroll
+    for (int i = 0; i < 3; ++i) p[i] = fma_k(p[i], w2[i], cf[j]);
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    p[i] = __builtin_fma(p[i], w2[i], -0.5);
+    p[i] = __builtin_fma(p[i], w2[i], 1.0);
+  }
+  c0 = ((int)k[0] & 1) ? -p[0] : p[0];
+  c1 = ((int)k[1] & 1) ? -p[1] : p[1];
+  c2 = ((int)k[2] & 1) ? -p[2] : p[2];
+}
+
+// exp(x) for |x| <= 700 with the polynomial constants in SGPRs (same reduction and polynomial
+// as exp_any, rjp_device.h)
+__device__ __forceinline__ double exp_k(double x) {
+  const double kd = __builtin_rint(kmul(1.4426950408889634074, x));
+  double r = kfma(-6.93147180369123816490e-01, kd, x);
+  r = kfma(-1.90821492927058770002e-10, kd, r);
+  double p = kadd(2.755731922398589e-07, kmul(2.505210838544172e-08, r));
+  p = fma_k(p, r, 2.7557319223985893e-06);
+  p = fma_k(p, r, 2.48015873015873e-05);
+  p = fma_k(p, r, 1.984126984126984e-04);
+  p = fma_k(p, r, 1.388888888888889e-03);
+  p = fma_k(p, r, 8.333333333333333e-03);
+  p = fma_k(p, r, 4.1666666666666664e-02);
+  p = fma_k(p, r, 1.6666666666666666e-01);
+  p = __builtin_fma(p, r, 0.5);
+  p = __builtin_fma(p, r, 1.0);
+  p = __builtin_fma(p, r, 1.0);
+  return __builtin_ldexp(p, (int)kd);
+}
+
 __device__ __forceinline__ double rcp_fast(double d) {
 #if defined(RJP_RCP_F32)
   double r = (double)__builtin_amdgcn_rcpf((float)d);   // f32 seed (d within f32 range)
@@ -360,6 +422,143 @@ __device__ __forceinline__ double voigt_rew(double ax, double y, double q, doubl
   return s;
 }
 
+// ---- wave-uniform fast paths (kernels whose waves work on one cell) ----------------------
+// FP64 VOP3 instructions take no literal: a constant operand has to sit in a register.  Left
+// to itself the compiler materialises every polynomial / lattice constant with two
+// v_mov_b32 per use -- vector-ALU work, a fifth of the instructions of these paths -- or,
+// with the loop-invariant hoisting on, keeps ~60 of them in VGPRs and spills.  The helpers
+// below pin the constant to an SGPR pair instead (two s_mov_b32 on the scalar unit, which
+// issues beside the vector ALU).  Never fed straight from v_rcp_f64 / a transcendental op
+// (the hazard recogniser does not see through inline asm); rcp_fast() ends in ordinary ops.
+__device__ __forceinline__ double fma_k(double a, double b, double K) {      // a * b + K
+  double d;
+  asm("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "s"(K));
+  return d;
+}
+__device__ __forceinline__ double kfma(double K, double b, double c) {       // K * b + c
+  double d;
+  asm("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "s"(K), "v"(b), "v"(c));
+  return d;
+}
+__device__ __forceinline__ double kadd(double K, double b) {                 // K + b
+  double d;
+  asm("v_add_f64 %0, %1, %2" : "=v"(d) : "s"(K), "v"(b));
+  return d;
+}
+__device__ __forceinline__ double kmul(double K, double b) {                 // K * b
+  double d;
+  asm("v_mul_f64 %0, %1, %2" : "=v"(d) : "s"(K), "v"(b));
+  return d;
+}
+
+// Far field, every lane of the wave: asymptotic series of w(z) in u = 1/z^2,
+//   w(z) ~ (i / (sqrt(pi) z)) sum_k (2k-1)!!/2^k u^k,   Re w = (y Re S - x Im S) / (|z|^2 sqrt pi),
+// ONE reciprocal per evaluation (the Laplace continued fraction above needs one per level).
+// Truncation after K terms, measured against scipy.special.wofz over 1e-10 <= y <= 1e3:
+// |z|^2 > 64 (the Gaussian core exp(-x^2) <= 1.6e-28 is invisible there): K = 8 -> 8e-11;
+// |z|^2 > 144: K = 5 -> 2.5e-10.
+template <int K>
+__device__ __forceinline__ double voigt_far_series(double ax, double y) {
+  constexpr double c[9] = {1.0, 0.5, 0.75, 1.875, 6.5625, 29.53125, 162.421875, 1055.7421875,
+                           7918.06640625};
+  static_assert(K >= 2 && K <= 8, "series length");
+  const double x2 = ax * ax, y2 = y * y;
+  const double r2 = x2 + y2;
+  const double inv = rcp_fast(r2 * r2);                 // 1 / |z^2|^2
+  const double ur = (x2 - y2) * inv;                    // u = conj(z^2) / |z^2|^2
+  const double nui = 2.0 * (ax * y) * inv;              // -Im u (inline asm takes no neg modifier)
+  double pr = kadd(c[K - 1], kmul(c[K], ur));           // first Horner step (Im S = 0 before it)
+  double pi = kmul(-c[K], nui);
+#pragma unroll
+  for (int k = K - 2; k >= 0; --k) {
+    // S <- S u + c[k]:  Re: pr ur - pi ui + c[k],  Im: pr ui + pi ur,  ui = -nui
+    const double t = (c[k] == 1.0 || c[k] == 0.5)
+                         ? __builtin_fma(pr, ur, __builtin_fma(pi, nui, c[k]))
+                         : __builtin_fma(pr, ur, fma_k(pi, nui, c[k]));
+    pi = __builtin_fma(-pr, nui, pi * ur);
+    pr = t;
+  }
+  // 1/|z|^2 = |z|^2 * inv
+  return __builtin_fma(y, pr, -ax * pi) * (r2 * inv) * 0.56418958354775628695;
+}
+
+// Plain lattice (y >= 0.03), every lane of the wave: the ten node pairs over ONE common
+// denominator -- a single reciprocal per evaluation.  With m_n = |z|^2 + t_n^2 the pair
+// (+t_n, -t_n) is
+//   w_n [1/((x-t_n)^2+y^2) + 1/((x+t_n)^2+y^2)] = 2 w_n m_n / d_n,   d_n = m_n^2 - 4 t_n^2 x^2,
+// so numerator and denominator share m_n, and the node weights enter as RATIOS while the
+// fractions are merged (one constant multiply per merge instead of one per node).  The
+// d_n are >= y^4 >= 8e-7 with at most one pair near its minimum and <= ~|z|^4 each: their
+// product stays inside the FP64 range for |z| < 1e7 (path_code sends waves with larger |x|
+// to the generic path).  Near a node d_n loses digits ~ t_n^2 / y^2, as the factored form
+// of the generic path does: relative error < 1e-11 against wofz for 0.03 <= y <= 1e3,
+// 0 <= x <= 1e4, pole term included.
+template <bool POLE>
+__device__ __forceinline__ double voigt_plain_wave(double ax, double y, double q) {
+  constexpr double tau[kNPair] = {0.0, 0.36, 1.44, 3.2399999999999993, 5.76, 9.0,
+                                  12.959999999999997, 17.64, 23.04, 29.159999999999993};
+  // w2[n] = 2 exp(-tau[n]) (w2[0] = 1): ratios w2[b]/w2[a] of the pairs (0,1) (2,3) ... and
+  // of the merges
+  constexpr double w2[kNPair] = {1.0, 1.395352652142062, 0.47385551736424353,
+                                 0.0783277901979742, 0.006302223196888882,
+                                 0.0002468196081733591, 4.705150400019559e-06,
+                                 4.3659155902509556e-08, 1.9719011151983032e-10,
+                                 4.3351377652379543e-13};
+  static_assert(kNPair == 10, "five pairs of fractions below");
+  const double x2 = ax * ax;
+  const double r2 = __builtin_fma(y, y, x2);
+  const double X4 = -4.0 * x2;
+  double N[5], D[5];
+#pragma unroll
+  for (int a = 0; a < kNPair; a += 2) {
+    const double ma = a == 0 ? r2 : kadd(tau[a], r2);
+    const double mb = kadd(tau[a + 1], r2);
+    const double da = a == 0 ? ma * ma : kfma(tau[a], X4, ma * ma);
+    const double db = kfma(tau[a + 1], X4, mb * mb);
+    // true numerator = w2[a] * (ma db + rho mb da)
+    N[a / 2] = __builtin_fma(ma, db, kmul(w2[a + 1] / w2[a], mb * da));
+    D[a / 2] = da * db;
+  }
+  // merges: N01 = N0 D1 + sigma N1 D0 with sigma the ratio of the fractions' scales
+  const double N01 = __builtin_fma(N[0], D[1], kmul(w2[2] / w2[0], N[1] * D[0])), D01 = D[0] * D[1];
+  const double N23 = __builtin_fma(N[2], D[3], kmul(w2[6] / w2[4], N[3] * D[2])), D23 = D[2] * D[3];
+  const double N03 = __builtin_fma(N01, D23, kmul(w2[4] / w2[0], N23 * D01)), D03 = D01 * D23;
+  const double Nall = __builtin_fma(N03, D[4], kmul(w2[8] / w2[0], N[4] * D03)), Dall = D03 * D[4];
+  // sum = w2[0] * Nall / Dall; Re w = (h y / pi) * sum
+  double s = Nall * rcp_fast(Dall) * kmul(w2[0] * kH / 3.14159265358979323846, y);
+  if (POLE) {
+    // P = Re[ 2 exp(-z^2) q / (q - exp(-i theta)) ], theta = 2 pi x / h, for every lane (it
+    // is below 1e-11 Re w where x^2 exceeds the per-cell bound cq, and harmless there):
+    // Re[e^{-i phi} conj(q - e^{-i theta})] = q cos(phi) - cos(theta - phi), phi = 2 x y;
+    // |q - e^{-i theta}|^2 = 1 - 2 q cos(theta) + q^2 >= (1 - q)^2 >= 0.07 for y >= 0.03
+    const double e = __builtin_fma(y, y, -x2);                    // <= y^2 < (pi/h)^2 = 27.4
+    const double u = kmul(1.0 / kH, ax);
+    const double fr = u - __builtin_floor(u);                     // theta / 2 pi
+    const double ph = kmul(0.31830988618379067154, ax * y);       // phi / 2 pi
+    double cth, cph, cps;
+    cos_2pi_x3(fr, ph, fr - ph, cth, cph, cps);
+    const double den = __builtin_fma(q, q - 2.0 * cth, 1.0);
+    const double num = __builtin_fma(q, cph, -cps);
+    s = __builtin_fma(2.0 * exp_k(fmax(e, -700.0)) * q, num * rcp_fast(den), s);
+  }
+  return s;
+}
+
+// Per-(cell, wave) path codes, decided once per cell in phase 1 from the |x| range of the
+// wave's channels -- the channel loop then branches on a scalar instead of testing regimes
+// per lane.  One byte per wave of the channel block.
+enum : int {
+  kPathSkip = 0,      // C == 0: the cell contributes nothing (outside the jet, NaN, ...)
+  kPathFar8 = 1,      // every lane far field, |z|^2 > 64
+  kPathFar5 = 2,      // every lane |z|^2 > 144
+  kPathPlain = 3,     // plain lattice, pole term negligible in every lane
+  kPathPlainPole = 4, // plain lattice + pole term
+  kPathCentred = 5,   // y < 0.03: centred lattice
+  kPathGeneric = 6,   // irregular constants (inf ...) or |x| > 1e6 beside core lanes:
+                      // per-lane generic code with NumPy's NaN filter
+  kPathExpFlag = 8    // bit 3: h nu / kT is not small over the band -> exp() per lane
+};
+
 template <typename T>
 struct RrlFields {
   const T* nd;
@@ -415,15 +614,46 @@ __device__ __forceinline__ CellLine cell_line(const RrlFields<T>& f, int64_t o,
   const double lnq = -2.0 * kPiOverH * c.y;
   c.q = (c.y < kPiOverH) ? exp(lnq) : -1.0;
   const double omq = -expm1(lnq);                                  // 1 - q
-  // pole term needed iff y^2 - x^2 + ln(6 q / (1-q)^2) > ln(1e-13 y / (4 * 67)), i.e. iff
-  // x^2 < cq
+  // pole term needed iff y^2 - x^2 + ln(6 q / (1-q)^2) > ln(1e-11 y / (4 * 67)), i.e. iff
+  // x^2 < cq   (the wave-uniform kernels; the generic per-lane path keeps 1e-13)
   c.cq = c.y * c.y + lnq + 1.7917594692280550 - 2.0 * log(omq) - log(0.25 * c.y) +
-         29.9336062089226 + 4.2046926193909657;
+         (CEN ? 25.3284360229345 : 29.9336062089226) + 4.2046926193909657;
   // centred lattice (y < 0.03): |P| <= exp(y^2 - x^2) and Re w >= y / (4 (|z|^2 + 1)) with
   // |z|^2 <= 16^2 + 1: negligible iff x^2 > y^2 - ln y + ln(1e13) + ln(4 * 258)
   if (CEN && c.y < kCenYMax) c.cq = c.y * c.y - log(c.y) + 29.9336062089226 + 6.9392539460415;
   if (!(c.C == c.C) || c.C == 0.0 || !(c.y > 0.0)) c.C = 0.0;     // nansum drops NaN terms
   return c;
+}
+
+// Path code of one cell for a wave whose live channels are nu in [lo_e, hi_e] (even lanes)
+// and [lo_o, hi_o] (odd lanes; the folded channel order gives every wave two runs).  The end
+// points are lane values, and x is evaluated exactly as the lanes do, so the wave-level
+// decision agrees with what each lane would decide.
+__device__ __forceinline__ int path_code(const CellLine& c, const double (&rg)[4],
+                                         double dnu_max) {
+  if (c.C == 0.0) return kPathSkip;
+  const bool regular = (c.C - c.C == 0.0) && (c.nu0 - c.nu0 == 0.0) && (c.is2 - c.is2 == 0.0) &&
+                       (c.y - c.y == 0.0) && c.y > 0.0 && (c.a - c.a == 0.0) &&
+                       (c.E0 - c.E0 == 0.0);
+  int code;
+  double xmin = __builtin_inf(), xmax = 0.0;
+#pragma unroll
+  for (int g = 0; g < 2; ++g) {
+    const double lo = (rg[2 * g] - c.nu0) * c.is2, hi = (rg[2 * g + 1] - c.nu0) * c.is2;
+    if (!(rg[2 * g] <= rg[2 * g + 1])) continue;                  // no live lane in this run
+    const double alo = fabs(lo), ahi = fabs(hi);
+    xmin = fmin(xmin, (lo <= 0.0 && hi >= 0.0) ? 0.0 : fmin(alo, ahi));
+    xmax = fmax(xmax, fmax(alo, ahi));
+  }
+  const double x2min = xmin * xmin;
+  const double r2min = __builtin_fma(c.y, c.y, x2min);
+  if (!regular || !(xmax - xmax == 0.0)) code = kPathGeneric;
+  else if (r2min > 64.0 && (x2min > 64.0 || c.y > 1.0)) code = r2min > 144.0 ? kPathFar5 : kPathFar8;
+  else if (xmax > 1e6) code = kPathGeneric;
+  else if (c.y < kCenYMax) code = kPathCentred;
+  else code = (c.q >= 0.0 && x2min < c.cq) ? kPathPlainPole : kPathPlain;
+  if (!(c.a * dnu_max < 1e-3)) code |= kPathExpFlag;
+  return code;
 }
 
 // kappa_L * path of one (cell, channel): C * Re w * (1 - exp(-h nu / kT))   (rrls.py:383-389)
@@ -440,6 +670,17 @@ __device__ __forceinline__ double line_term(const CellLine& c, double nu_f, doub
   else
     ex = exp(-eps);
   return c.C * V * (1.0 - c.E0 * ex);
+}
+
+// Out of line: the cold generic path of the wave-uniform kernels must not cost their channel
+// loop registers.
+__device__ __attribute__((noinline)) double line_term_generic(double C, double nu0, double is2,
+                                                              double y, double a, double E0,
+                                                              double q, double cq, double nu_f,
+                                                              double dnu, double dnu_max) {
+  CellLine c;
+  c.C = C; c.nu0 = nu0; c.is2 = is2; c.y = y; c.a = a; c.E0 = E0; c.q = q; c.cq = cq;
+  return line_term<false>(c, nu_f, dnu, dnu_max, nullptr);
 }
 
 // collapse=False: the 3-D per-cell optical depths (classes.py:1176-1177, 1382-1383).  One
@@ -492,6 +733,10 @@ __global__ __launch_bounds__(kRB, RJP_K3_WAVES) void rrl_scan_kernel(
   // per-wave table of the centred Voigt lattice (kernels whose waves work on one cell)
   constexpr bool CEN = LF >= RJP_WAVE;
   __shared__ double s_tab[CEN ? kRB / RJP_WAVE : 1][RJP_WAVE];
+  // path codes (one byte per wave of the channel block) and the waves' channel ranges
+  constexpr int NWC = CEN ? LF / RJP_WAVE : 1;
+  __shared__ int s_code[CEN ? kRB : 1];
+  __shared__ double s_rng[NWC][4];
 
   const int ntz = (nz + ZT - 1) / ZT;
   const int x = blockIdx.x / ntz;
@@ -501,7 +746,7 @@ __global__ __launch_bounds__(kRB, RJP_K3_WAVES) void rrl_scan_kernel(
   const int g = tid / LF;
   // Lanes take the channels of this block folded about the block centre: lane 0 -> first,
   // lane 1 -> last, lane 2 -> second, ...  A band centred on the line then gives each wave
-  // a narrow range of |x|: the outermost wave is entirely far-field (continued fraction) and
+  // a narrow range of |x|: the outermost wave is entirely far-field (asymptotic series) and
   // only the innermost needs the pole term, instead of every wave straddling both regimes.
   const int fbase = blockIdx.y * LF;
   const int nblk = min(LF, nchan - fbase);
@@ -512,6 +757,25 @@ __global__ __launch_bounds__(kRB, RJP_K3_WAVES) void rrl_scan_kernel(
 
 #pragma unroll
   for (int j = 0; j < NZP; ++j) s_acc[j * kRB + tid] = 0.0;
+
+  if constexpr (CEN) {
+    // frequency range of this wave's even and odd lanes (its two runs of channels)
+    const double inf = __builtin_inf();
+    double r0 = (chan_live && !(fl & 1)) ? nu_f : inf, r1 = (chan_live && !(fl & 1)) ? nu_f : -inf;
+    double r2 = (chan_live && (fl & 1)) ? nu_f : inf, r3 = (chan_live && (fl & 1)) ? nu_f : -inf;
+#pragma unroll
+    for (int d = RJP_WAVE / 2; d > 0; d >>= 1) {
+      r0 = fmin(r0, __shfl_xor(r0, d, RJP_WAVE));
+      r1 = fmax(r1, __shfl_xor(r1, d, RJP_WAVE));
+      r2 = fmin(r2, __shfl_xor(r2, d, RJP_WAVE));
+      r3 = fmax(r3, __shfl_xor(r3, d, RJP_WAVE));
+    }
+    if ((tid & (RJP_WAVE - 1)) == 0) {
+      const int w = (tid % LF) / RJP_WAVE;       // LF = 64: every wave holds the same channels
+      s_rng[w][0] = r0; s_rng[w][1] = r1; s_rng[w][2] = r2; s_rng[w][3] = r3;
+    }
+    __syncthreads();
+  }
 
   const int cy = tid / ZT, cz = tid % ZT;       // this thread's cell in the slab (phase 1)
 
@@ -531,6 +795,10 @@ __global__ __launch_bounds__(kRB, RJP_K3_WAVES) void rrl_scan_kernel(
     ye = s_hi;
   }
 
+  // (a scalar: the path code must reach the branches below as a wave-uniform value)
+  const int wsel = (CEN && LF > RJP_WAVE)
+                       ? __builtin_amdgcn_readfirstlane((tid / RJP_WAVE) * 8) : 0;
+
   for (int yb = ya; yb < ye; yb += YC) {
     // ---- phase 1: per-cell line constants --------------------------------------------
     {
@@ -543,6 +811,15 @@ __global__ __launch_bounds__(kRB, RJP_K3_WAVES) void rrl_scan_kernel(
                    q = cl.q, cq = cl.cq;
       s_C[tid] = C; s_nu0[tid] = nu0; s_is2[tid] = is2; s_y[tid] = yv; s_a[tid] = a;
       s_E0[tid] = E0; s_q[tid] = q; s_cq[tid] = cq;
+      if constexpr (CEN) {
+        int code = 0;
+#pragma unroll
+        for (int w = 0; w < NWC; ++w) {
+          const double rg[4] = {s_rng[w][0], s_rng[w][1], s_rng[w][2], s_rng[w][3]};
+          code |= path_code(cl, rg, ln.dnu_max) << (8 * w);
+        }
+        s_code[tid] = code;
+      }
     }
     __syncthreads();
 
@@ -550,19 +827,53 @@ __global__ __launch_bounds__(kRB, RJP_K3_WAVES) void rrl_scan_kernel(
 #pragma unroll 1
     for (int j = 0; j < NZP; ++j) {
       double acc = s_acc[j * kRB + tid];
+      if constexpr (CEN) {
+        // the wave works on ONE cell per trip: its path was decided in phase 1
 #pragma unroll 1
-      for (int r = 0; r < YC; ++r) {
-        const int ci = r * ZT + g * NZP + j;
-        const double C = s_C[ci];
-        bool live = C != 0.0;
-        if (LF >= RJP_WAVE) live = __builtin_amdgcn_readfirstlane((int)live) != 0;
-        if (live) {
-          CellLine cl;
-          cl.C = C; cl.nu0 = s_nu0[ci]; cl.is2 = s_is2[ci]; cl.y = s_y[ci]; cl.a = s_a[ci];
-          cl.E0 = s_E0[ci]; cl.q = s_q[ci]; cl.cq = s_cq[ci];
-          const double term = line_term<CEN>(cl, nu_f, dnu, ln.dnu_max,
-                                             CEN ? s_tab[tid / RJP_WAVE] : nullptr);
-          if (term == term) acc += term;
+        for (int r = 0; r < YC; ++r) {
+          const int ci = r * ZT + g * NZP + j;
+          const int pc = (__builtin_amdgcn_readfirstlane(s_code[ci]) >> wsel) & 0xff;
+          if (pc == kPathSkip) continue;
+          const int path = pc & 7;
+          if (path == kPathGeneric) {
+            // irregular constants or absurd |x| beside core lanes: per-lane generic code,
+            // NaN terms dropped as numpy.nansum does
+            // (for y < 0.03 the generic code takes its shifted lattice, which has its own
+            // pole-term test and does not read cq; above, cq is the plain-lattice bound)
+            static_assert(kCenYMax == 0.03, "generic path assumes the centred bound ends at 0.03");
+            const double term = line_term_generic(s_C[ci], s_nu0[ci], s_is2[ci], s_y[ci], s_a[ci],
+                                                  s_E0[ci], s_q[ci], s_cq[ci], nu_f, dnu,
+                                                  ln.dnu_max);
+            if (term == term) acc += term;
+            continue;
+          }
+          const double yv = s_y[ci];
+          const double ax = fabs((nu_f - s_nu0[ci]) * s_is2[ci]);
+          double V;
+          if (path == kPathFar8) V = voigt_far_series<8>(ax, yv);
+          else if (path == kPathFar5) V = voigt_far_series<5>(ax, yv);
+          else if (path == kPathPlain) V = voigt_plain_wave<false>(ax, yv, 0.0);
+          else if (path == kPathPlainPole) V = voigt_plain_wave<true>(ax, yv, s_q[ci]);
+          else V = voigt_centred(ax, yv, s_q[ci], s_cq[ci], s_tab[tid / RJP_WAVE]);
+          // 1 - exp(-h nu / kT) = 1 - E0 * exp(-a (nu - nu_ref))
+          const double eps = s_a[ci] * dnu;
+          double ex;
+          if (pc & kPathExpFlag) ex = exp(-eps);
+          else ex = __builtin_fma(eps, __builtin_fma(eps, __builtin_fma(eps, -1.0 / 6.0, 0.5), -1.0), 1.0);
+          acc = __builtin_fma(s_C[ci] * V, __builtin_fma(-s_E0[ci], ex, 1.0), acc);
+        }
+      } else {
+#pragma unroll 1
+        for (int r = 0; r < YC; ++r) {
+          const int ci = r * ZT + g * NZP + j;
+          const double C = s_C[ci];
+          if (C != 0.0) {
+            CellLine cl;
+            cl.C = C; cl.nu0 = s_nu0[ci]; cl.is2 = s_is2[ci]; cl.y = s_y[ci]; cl.a = s_a[ci];
+            cl.E0 = s_E0[ci]; cl.q = s_q[ci]; cl.cq = s_cq[ci];
+            const double term = line_term<false>(cl, nu_f, dnu, ln.dnu_max, nullptr);
+            if (term == term) acc += term;
+          }
         }
       }
       s_acc[j * kRB + tid] = acc;
