@@ -227,3 +227,46 @@ def test_xslab_sweep_with_more_ranks_than_rows():
     ret = mp.Manager().dict()
     mp.spawn(_xslab_worker, args=(3, _free_port(), ret), nprocs=3, join=True)
     assert all(ret[r] for r in range(3)), dict(ret)
+
+
+def test_k3_generic_path_and_odd_channel_lists(eng):
+    """The wave-uniform K3 paths are chosen from the frequency range of a wave's channels, so
+    the list may come in any order; a wave whose channels sit beside the line AND absurdly
+    far from it (|x| > 1e6), and cells with infinite or zero fields, take the generic per-lane
+    path with NumPy's NaN filter.  All against the oracle."""
+    from rajepy_amd import _lib
+    from rajepy_amd.maths import rrls
+    shape = (2, 24, 16)
+    seed = 20240524
+    g = U.synth_host(shape, seed, 1)
+    g["nd"][0, 3, 2] = np.inf           # n_e = inf
+    g["temp"][0, 5, 3] = np.inf         # zero line width ...
+    g["temp"][1, 7, 4] = 0.0            # ... and infinite
+    g["xi"][1, 2, 5] = 0.0              # no electrons: y = 0, contributes exactly nothing
+    g["ff"][1, 9, 6] = np.inf
+    p = copy.deepcopy(U.load_golden("cfg1_example")[2])
+    p["ejection"] = U.example_bursts_params()
+    p["power_laws"]["q_T"] = -0.5
+    p["grid"].update(n_x=shape[0], n_y=shape[1], n_z=shape[2])
+    jet = orc.OracleJet.from_fields(p, g["nd"], g["xi"], g["temp"], g["ff"], g["areas"],
+                                    g["ts"], g["rr"], g["vy"])
+    jet.time = 0.6 * YEAR
+    fields = eng.upload_fields(g["nd"], g["xi"], g["temp"], g["ff"], g["areas"], g["ts"],
+                               g["rr"] < 0, vy=g["vy"], csize_au=jet.csize, dtype=8)
+    nu0 = rrls.rrl_nu_0("H", 66, 1)
+    band = orc.chan_freqs(nu0, 120 * 2e5, 2e5)
+    rng = np.random.default_rng(4)
+    lists = {"shuffled": rng.permutation(band),
+             "with far outliers": np.concatenate([band[:70], [nu0 + 5e13, nu0 + 2e13], band[70:]]),
+             "descending": band[::-1].copy()}
+    line = _lib.Line(**rrls.line_constants("H66a"))
+    with np.errstate(all="ignore"):
+        for name, rf in lists.items():
+            tau = eng.rrl_scan(fields, U.bursts_from_oracle(jet), jet.time, line, rf)
+            eng.synchronize()
+            ref = jet.optical_depth_rrl("H66a", np.asarray(rf))
+            got = tau.cpu().numpy().reshape(ref.shape)
+            assert np.array_equal(np.isnan(got), np.isnan(ref)), name
+            assert np.array_equal(np.isinf(got), np.isinf(ref)), name
+            ok = np.isfinite(ref)
+            np.testing.assert_allclose(got[ok], ref[ok], rtol=1e-9, err_msg=name)
