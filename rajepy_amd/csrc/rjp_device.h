@@ -263,6 +263,9 @@ __device__ __forceinline__ void chi_batch(const BurstsDev& b, const bool (&red)[
 // underflows (arg_m < -700) every epoch of the tile is negligible -- the launcher guarantees
 // that by using this path only while the tile's half-span is below 28 sigma of the
 // narrowest burst.
+#ifndef RJP_BURST_PIPELINE
+#define RJP_BURST_PIPELINE 1   /* 0: A/B build without the scalar-load pipelining */
+#endif
 struct UnifDev {
   int on;                                   // 0 = evaluate every epoch directly
   double dt;                                // epoch spacing [s]
@@ -327,8 +330,36 @@ __device__ __forceinline__ void chi_batch_uniform(const BurstsDev& b, const Unif
           b.inv2s2[1][i], b.amp_rel[1][i], un.q[1][i]);
   };
   const int n0 = nb < RJP_SGPR_BURSTS ? nb : RJP_SGPR_BURSTS;
-  // two bursts per trip: their exp chains are independent and interleave
   int i = 0;
+  if (ET >= 16 && !mixed && RJP_BURST_PIPELINE) {
+    // Wave inside one jet (the usual case): the burst parameters are scalar loads from the
+    // kernel-argument segment, and a trip of ~400 FP64 instructions used to start by waiting
+    // for them (SMEM round trip, two or three times per row).  Here the parameters of the
+    // NEXT two bursts are requested before the current pair is worked on.
+    struct BP { double t0, inv, amp, q; };
+    auto ld = [&](int k) __attribute__((always_inline)) {
+      const int kk = k < RJP_SGPR_BURSTS - 1 ? k : RJP_SGPR_BURSTS - 1;   // stay inside the table
+      return BP{b.t0[jet][kk], b.inv2s2[jet][kk], b.amp_rel[jet][kk], un.q[jet][kk]};
+    };
+    BP a0 = ld(0), a1 = ld(1);
+    for (; i < n0; i += 2) {
+      const BP p0 = ld(i + 2), p1 = ld(i + 3);
+      if (i + 1 < n0) {
+        // two bursts per trip: their exp chains are independent and interleave
+#pragma unroll
+        for (int c = 0; c < UV; ++c) {
+          apply(c, a0.t0, a0.inv, a0.amp, a0.q, a0.t0, a0.inv, a0.amp, a0.q);
+          apply(c, a1.t0, a1.inv, a1.amp, a1.q, a1.t0, a1.inv, a1.amp, a1.q);
+        }
+      } else {
+#pragma unroll
+        for (int c = 0; c < UV; ++c)
+          apply(c, a0.t0, a0.inv, a0.amp, a0.q, a0.t0, a0.inv, a0.amp, a0.q);
+      }
+      a0 = p0; a1 = p1;
+    }
+  }
+  // two bursts per trip: their exp chains are independent and interleave
   for (; i + 1 < n0; i += 2) {
 #pragma unroll
     for (int c = 0; c < UV; ++c) { one(i, c); one(i + 1, c); }

@@ -10,8 +10,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 RUNS = [("cfg2", "f64", {}, []), ("cfg5", "f64", {}, []), ("cfg3", "f64", {}, []),
         ("cfg4", "f32", {}, []), ("cfg5", "f32", {}, []),
         ("cfg4", "f64", {}, ["--gaunt", "powerlaw"]),
-        ("cfg4", "f64", {"RJP_NO_COMPACT": "1"}, []),
-        ("cfg4", "f32", {"RJP_NO_COMPACT": "1"}, [])]
+        ("cfg4", "f64", {}, ["--layout", "wide"]),
+        ("cfg4", "f32", {}, ["--layout", "wide"])]
 
 
 def main():
@@ -20,7 +20,7 @@ def main():
     rows, lines = [], []
     for cfg, storage, env, more in RUNS:
         cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--config", cfg, "--storage",
-               storage, "--steps", "5", "--warmup", "2"] + more + extra
+               storage, "--steps", "5", "--warmup", "2", "--sustained-seconds", "0.5"] + more + extra
         out = subprocess.run(cmd, env=dict(os.environ, **env), capture_output=True, text=True,
                              timeout=900)
         line = [l for l in out.stdout.splitlines() if l.startswith("{")]
@@ -31,7 +31,7 @@ def main():
         lines.append(line[-1])
         rf, cb = r["roofline"], r.get("cpu_baseline", {})
         rows.append("| %s_%s%s | %s | %s | %.3f | %.3e | %s | %.3f | %.0f | %.3f | %s |" % (
-            cfg, storage, ("_wide" if env else "") + ("_powerlaw" if more else ""),
+            cfg, storage, ("_wide" if "wide" in more else "") + ("_powerlaw" if "powerlaw" in more else ""),
             r["config"]["workload"], r["config"]["layout"],
             r["ms_per_step"], r["value"], rf["kernel"], rf["ms_per_launch"], rf["achieved"],
             rf["frac"], ("%.2f" % cb["value"]) if cb else "-"))
