@@ -737,8 +737,10 @@ def main(argv=None):
                    "storage": args.storage, "gaunt": args.gaunt,
                    "arithmetic": "f64 accumulation and transcendental functions; storage "
                                  "dtype of the 3-D fields as given",
-                   "layout": "compact (3 fields/cell)" if roof_extra.get(
-                       "fields_streamed_per_cell", 5) == 3 else "wide (5 fields/cell)",
+                   "layout": ("K3 reads the 6 wide fields; K1 compact (3 fields/cell)" if rrl else
+                              "compact (3 fields/cell)" if roof_extra.get(
+                                  "fields_streamed_per_cell", 5) == 3 else
+                              "wide (5 fields/cell)"),
                    "sharding": sharding, "gather": GATHER[sharding]},
         "ranks_seen": ranks_seen,
         "roofline": roofline,

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Runs the secondary bench configurations one after another (one process each) and writes
-profiles/<round>_other_configs.md: python tools/other_configs.py r01 [--no-cpu-baseline]"""
+gpurun_out/<round>_other_configs_table.md: python tools/other_configs.py r02 [--no-cpu-baseline]"""
 import json
 import os
 import subprocess
@@ -36,7 +36,9 @@ def main():
             r["ms_per_step"], r["value"], rf["kernel"], rf["ms_per_launch"], rf["achieved"],
             rf["frac"], ("%.2f" % cb["value"]) if cb else "-"))
         print(rows[-1], flush=True)
-    with open(os.path.join(ROOT, "profiles", tag + "_other_configs_table.md"), "w") as f:
+    # written under gpurun_out/ (the only directory a GPU box hands back); copy to profiles/
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(ROOT, "gpurun_out", tag + "_other_configs_table.md"), "w") as f:
         f.write("| config | workload | layout | ms/step | Mvoxel-freq/s | dominant kernel | "
                 "ms/launch | alg. GB/s | frac of 8 TB/s | CPU oracle (1 core) Mvoxel-freq/s |\n")
         f.write("|---|---|---|---|---|---|---|---|---|---|\n")
