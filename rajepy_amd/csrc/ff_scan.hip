@@ -504,13 +504,15 @@ hipError_t ff_cells_launch(const rjp_fields* fl, const rjp_bursts* hb, const dou
 
 // ---- launch helpers ---------------------------------------------------------------------
 // y-splits for a map of `nchunks` lanes: enough workgroups for ~16 waves per SIMD chip-wide
-// (measured optimum on cfg4: 8 splits, 6.2 TB/s vs 5.8 at 3), at least 16 rows per split, and
-// at least 64 rows once every CU already has a wave without splitting.
+// (measured optimum on cfg4: 8 splits, 6.2 TB/s vs 5.8 at 3 and 5.9 at 32), at least 16 rows
+// per split, and at least 128 rows once every CU already has a wave without splitting (cfg2,
+// 256x1024x256: 8 splits of 128 rows 0.29 ms, 16 of 64 rows 0.31-0.32 ms,
+// profiles/r02_k1_tuning_ab.md).
 static int ysplit_rule(int64_t nchunks, int ny) {
   const int64_t waves = (nchunks + RJP_WAVE - 1) / RJP_WAVE;
   const int64_t target = 256 * 64;
   int64_t s = (target + waves - 1) / waves;
-  const int64_t smax = std::max(1, waves >= 256 ? ny / 64 : ny / 16);
+  const int64_t smax = std::max(1, waves >= 256 ? ny / 128 : ny / 16);
   if (s > smax) s = smax;
   if (s < 1) s = 1;
   return (int)s;

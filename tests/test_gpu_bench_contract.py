@@ -63,7 +63,8 @@ def test_bench_refuses_mismatched_world_size():
 
 
 @pytest.mark.parametrize("config,sharding,scaling", [("tiny", "epochs", "weak"),
-                                                     ("tiny5", "xslab", "strong")])
+                                                     ("tiny5", "xslab", "strong"),
+                                                     ("tiny_rrl", "xslab", "strong")])
 def test_bench_launches_its_own_ranks(config, sharding, scaling):
     """`python bench.py --gpus 2` with no WORLD_SIZE starts two child ranks itself and relays
     rank 0's line (here both ranks share the one GPU of the box and talk over gloo; on an
@@ -86,6 +87,8 @@ def test_bench_launches_its_own_ranks(config, sharding, scaling):
         assert set(r["legs"]) == {"strong_xslab", "channel_sharded"}
         for leg in r["legs"].values():
             assert leg["scaling"] == "strong" and leg["value"] > 0 and leg["speedup_vs_n1"] > 0
-    else:
+    elif config == "tiny5":
         assert "32 epoch(s) per step" in r["config"]["workload"]
         assert r["roofline"]["epochs_per_launch"] == 32 and r["roofline"]["grid_passes_per_launch"] == 1
+    else:
+        assert r["roofline"]["kernel"] == "rrl_scan_kernel" and r["roofline"]["voigt_evals_per_s"] > 0
