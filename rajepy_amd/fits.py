@@ -5,7 +5,9 @@ The reference writes its EM / Tau / Flux products with astropy.io.fits
 astropy 4.3.1 does for the same header assignments: 80-column cards, fixed-format values,
 astropy's float formatting ('%.16G', exponent padded to two digits, clipped to 20 columns),
 long HISTORY text folded at 72 columns, big-endian float64 data, 2880-byte blocks.
-tests/test_fits_pipeline.py compares whole files against the reference's output.
+tests/test_host_logic.py::test_fits_products_byte_identical_to_reference compares whole files
+with the reference's output (SHA-256 of the files astropy wrote for the reference run,
+tests/golden/pipeline_cfg1.json).
 """
 import numpy as np
 
