@@ -270,3 +270,47 @@ def test_k3_generic_path_and_odd_channel_lists(eng):
             assert np.array_equal(np.isinf(got), np.isinf(ref)), name
             ok = np.isfinite(ref)
             np.testing.assert_allclose(got[ok], ref[ok], rtol=1e-9, err_msg=name)
+
+
+def _pipeline_worker(rank, world, port, dcy, ret):
+    import torch.distributed as dist
+    from rajepy_amd import classes, fits, logger
+    from tests.test_host_logic import example_params, pline_params
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RJP_DEVICE="0")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        log = logger.Log(os.path.join(dcy, "rank%d.log" % rank), verbose=False)
+        pp = pline_params(dcy)
+        pp["continuum"]["times"] = np.array([0., 0.5, 1., 2., 3.])
+        pl = classes.Pipeline(classes.JetModel(example_params(), log=log), pp, log=log)
+        pl.execute(simobserve=False, verbose=False, dryrun=False, resume=False, clobber=True)
+        ok = all(r.completed for r in pl.runs) and all("flux" in r.results for r in pl.runs)
+        dist.barrier()
+        if rank == 0:
+            jm = classes.JetModel(example_params(), log=log)
+            for r in pl.runs:
+                jm.time = r.year * YEAR
+                for path in (r.fits_em, r.fits_tau, r.fits_flux):
+                    ok = ok and os.path.exists(path)
+                if r.obs_type == "continuum":
+                    want = np.nansum(np.nanmean(jm.flux_ff(r.chan_freqs), axis=0))
+                    ok = ok and np.isclose(r.results["flux"], want, rtol=1e-12)
+                    data = fits.read(r.fits_flux)[0]
+                    ok = ok and np.isclose(np.nansum(np.nanmean(data, axis=0)), want, rtol=1e-12)
+            ok = ok and os.path.exists(os.path.join(dcy, "pipeline.save"))
+        ret[rank] = bool(ok)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_pipeline_execute_on_two_ranks_sharing_the_gpu(tmp_path):
+    """Pipeline.execute inside a 2-rank process group (gloo; both ranks on the one GPU of the
+    box): the epochs of the run table are dealt to the ranks, each writes the products of its
+    runs, results are exchanged and rank 0 writes the state files; every run's flux equals
+    what a single model computes."""
+    import torch.multiprocessing as mp
+    dcy = str(tmp_path / "out")
+    os.makedirs(dcy)
+    ret = mp.Manager().dict()
+    mp.spawn(_pipeline_worker, args=(2, _free_port(), dcy, ret), nprocs=2, join=True)
+    assert ret[0] is True and ret[1] is True, dict(ret)
