@@ -108,8 +108,10 @@ def parse(argv=None):
                     help="target CPU time of the bounded cpu_baseline sample")
     ap.add_argument("--no-cpu-all-cores", action="store_true",
                     help="skip the one-process-per-core leg of cpu_baseline")
-    ap.add_argument("--sustained-seconds", type=float, default=2.0,
-                    help="length of the back-to-back leg after the contract timing (0 = skip)")
+    ap.add_argument("--sustained-seconds", type=float, default=10.0,
+                    help="length of the back-to-back leg after the contract timing (0 = skip): "
+                         "long enough that clock / power droop would show and that a monitor "
+                         "sampling the GPU every few seconds sees it busy")
     ap.add_argument("--no-api-level", action="store_true",
                     help="skip the PCIe-inclusive leg (step + copy of the cubes to pinned host)")
     return ap.parse_args(argv)
@@ -559,10 +561,10 @@ def main(argv=None):
         dist.all_reduce(ones)
         ranks_seen = int(ones.item())
 
-    # ---- sustained leg: >= 2 s of back-to-back steps (clock / power droop would show) ----
+    # ---- sustained leg: ~10 s of back-to-back steps (clock / power droop would show) ----
     sustained = None
     if args.sustained_seconds > 0:
-        n_sus = int(min(20000, max(3, np.ceil(args.sustained_seconds * 1e3 / ms_step))))
+        n_sus = int(min(50000, max(3, np.ceil(args.sustained_seconds * 1e3 / ms_step))))
         dts, _ = timed(wl.step, n_sus, 0)
         sustained = {"steps": n_sus, "seconds": dts, "ms_per_step": dts / n_sus * 1e3,
                      "value": rate(dts / n_sus * 1e3, total_epochs)}

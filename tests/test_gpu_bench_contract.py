@@ -18,7 +18,7 @@ REQUIRED = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step
 def test_bench_prints_one_contract_line(config):
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1",
                           "--steps", "3", "--warmup", "1", "--config", config,
-                          "--cpu-seconds", "0.5"] +
+                          "--cpu-seconds", "0.5", "--sustained-seconds", "0.2"] +
                          (["--no-cpu-all-cores"] if config == "tiny_rrl" else []),
                          capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
