@@ -68,6 +68,37 @@ __global__ __launch_bounds__(256) void three(const d2* __restrict__ a, const d2*
   if (acc == 123.456) out[0] = acc;
 }
 
+// (d) as (c) plus NALU dependent FP64 FMAs per loaded element pair (two cells): how much
+// vector-ALU work can ride along with the three streams before the read rate drops?
+template <int UNR, int NALU>
+__global__ __launch_bounds__(256) void three_alu(const d2* __restrict__ a, const d2* __restrict__ b,
+                                                 const d2* __restrict__ c, size_t rows_per_block,
+                                                 double* out) {
+  const size_t off = (size_t)blockIdx.x * rows_per_block * 256 + threadIdx.x;
+  double acc = 0.0;
+  for (size_t r = 0; r + UNR <= rows_per_block; r += UNR) {
+    d2 va[UNR], vb[UNR], vc[UNR];
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {
+      va[u] = __builtin_nontemporal_load(a + off + (r + u) * 256);
+      vb[u] = __builtin_nontemporal_load(b + off + (r + u) * 256);
+      vc[u] = __builtin_nontemporal_load(c + off + (r + u) * 256);
+    }
+    // NALU FMAs per CELL (a lane holds two cells per row), chains of the 2*UNR cells interleave
+    double p[2 * UNR];
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) { p[2 * u] = vc[u].x; p[2 * u + 1] = vc[u].y; }
+#pragma unroll
+    for (int k = 0; k < NALU; ++k)
+#pragma unroll
+      for (int q = 0; q < 2 * UNR; ++q) p[q] = __builtin_fma(p[q], 0.999999 + 1e-9 * k, 1e-7);
+#pragma unroll
+    for (int u = 0; u < UNR; ++u)
+      acc += va[u].x * p[2 * u] + va[u].y * p[2 * u + 1] + vb[u].x * vb[u].y;
+  }
+  if (acc == 123.456) out[0] = acc;
+}
+
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); return 1; } } while (0)
 
 int main() {
@@ -116,6 +147,16 @@ int main() {
     time(nm, [&] { hipLaunchKernelGGL((three<4>), dim3(blocks), dim3(256), 0, 0, a, a + n2f, a + 2 * n2f, rows, out); });
     snprintf(nm, 96, "three arrays together, unroll 2, %d blocks", blocks);
     time(nm, [&] { hipLaunchKernelGGL((three<2>), dim3(blocks), dim3(256), 0, 0, a, a + n2f, a + 2 * n2f, rows, out); });
+  }
+  {
+    const int blocks = 4096;
+    const size_t n2f = n2 / 3;
+    const size_t rows = n2f / 256 / blocks;
+    time("three arrays + 10 FMA/cell, unroll 4, 4096 blocks", [&] { hipLaunchKernelGGL((three_alu<4, 10>), dim3(blocks), dim3(256), 0, 0, a, a + n2f, a + 2 * n2f, rows, out); });
+    time("three arrays + 20 FMA/cell, unroll 4, 4096 blocks", [&] { hipLaunchKernelGGL((three_alu<4, 20>), dim3(blocks), dim3(256), 0, 0, a, a + n2f, a + 2 * n2f, rows, out); });
+    time("three arrays + 40 FMA/cell, unroll 4, 4096 blocks", [&] { hipLaunchKernelGGL((three_alu<4, 40>), dim3(blocks), dim3(256), 0, 0, a, a + n2f, a + 2 * n2f, rows, out); });
+    time("three arrays + 75 FMA/cell, unroll 4, 4096 blocks", [&] { hipLaunchKernelGGL((three_alu<4, 75>), dim3(blocks), dim3(256), 0, 0, a, a + n2f, a + 2 * n2f, rows, out); });
+    time("three arrays + 110 FMA/cell, unroll 4, 4096 blocks", [&] { hipLaunchKernelGGL((three_alu<4, 110>), dim3(blocks), dim3(256), 0, 0, a, a + n2f, a + 2 * n2f, rows, out); });
   }
   return 0;
 }
