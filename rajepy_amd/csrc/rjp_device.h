@@ -312,17 +312,17 @@ __device__ __forceinline__ void chi_batch_uniform(const BurstsDev& b, const Unif
     const double a = dead ? 0.0 : amp;          // a dead cell adds exactly nothing ...
     const double em0 = dead ? 0.0 : em;         // ... and must not turn 0 * inf into NaN
     chi[M * UV + c] = __builtin_fma(a, em0, chi[M * UV + c]);
-    double e = em0, rr = dead ? 0.0 : rup;
+    // the chains towards later and earlier epochs advance in the same trip: two independent
+    // dependency chains per burst in program order
+    double eu = em0, ru = dead ? 0.0 : rup, ed = em0, rd = dead ? 0.0 : rdn;
 #pragma unroll
-    for (int j = M + 1; j < ET; ++j) {
-      e *= rr; rr *= q;
-      chi[j * UV + c] = __builtin_fma(a, e, chi[j * UV + c]);
-    }
-    e = em0; rr = dead ? 0.0 : rdn;
-#pragma unroll
-    for (int j = M - 1; j >= 0; --j) {
-      e *= rr; rr *= q;
-      chi[j * UV + c] = __builtin_fma(a, e, chi[j * UV + c]);
+    for (int j = 1; j <= M; ++j) {
+      if (M + j < ET) {
+        eu *= ru; ru *= q;
+        chi[(M + j) * UV + c] = __builtin_fma(a, eu, chi[(M + j) * UV + c]);
+      }
+      ed *= rd; rd *= q;
+      chi[(M - j) * UV + c] = __builtin_fma(a, ed, chi[(M - j) * UV + c]);
     }
   };
   auto one = [&](int i, int c) __attribute__((always_inline)) {
