@@ -170,7 +170,10 @@ __device__ __forceinline__ void compute_rows(const RowBatch<VEC, U>& rb, const B
 #pragma unroll
         for (int v = 0; v < VEC; ++v) {
           const int k = (e * U + u) * VEC + v;
-          tl[k] = ep.t[e] - launch_or_never(ts[u][v]);
+          // a NaN launch time needs no special care on this path: the Gaussian argument is
+          // NaN, exp's clamp max(arg, -708) returns the number, the burst adds ~1e-308 and
+          // chi stays 1; the cell is masked when it is accumulated (poison_unless below)
+          tl[k] = ep.t[e] - ts[u][v];
           red[k] = rj[u][v];
         }
     chi_batch<NB, sizeof(T) == 4>(b, red, tl, chi);
