@@ -14,7 +14,8 @@ MODE = E.RJP_GFF_POWERLAW if os.environ.get("PROBE_POWERLAW") else E.RJP_GFF_SCA
 shape = bench.CONFIGS[cfg][0]
 eng = E.RTEngine(0)
 dtype = E.RJP_F64 if storage == "f64" else E.RJP_F32
-fields = eng.synth_fields(shape, 20240504, 1 if os.environ.get("PROBE_POWERLAW") else 0, dtype, csize_au=0.5)
+fields = eng.synth_fields(shape, 20240504, 1 if os.environ.get("PROBE_POWERLAW") else 0, dtype, csize_au=0.5,
+                          wide=(cfg != "cfg4x8"))
 ej = bench.EXAMPLE_BURSTS
 red, blue = [], []
 for t0, hl, chi, which in zip(ej["t_0"], ej["hl"], ej["chi"], ej["which"]):
