@@ -206,6 +206,7 @@ class JetModel:
         self._tavg = None
         self._vxz = None
         self._rrl_cache = None
+        self._dev_product = None     # device cube of the last product, for _save_cube
 
     # ------------------------------------------------------------------ bookkeeping ----
     def __str__(self):
@@ -545,7 +546,12 @@ class JetModel:
     def _map(self, tensor, lead=()):
         return _to_host(tensor).reshape(*lead, self.nx, self.nz)
 
-    def _ff_products(self, freq, tau=False, flux=False, intensity=False, device=False):
+    FITS_DEVICE_MIN_BYTES = 8 << 20      # products from this size on are laid out for FITS on the GPU
+
+    def _ff_products(self, freq, tau=False, flux=False, intensity=False, device=False,
+                     keep=False):
+        """`keep`: remember the device cube so that a following _save_cube can build the FITS
+        payload (axis order + byte order) on the GPU instead of in three host passes."""
         from . import engine as E
         scalar = np.isscalar(freq)
         freqs = np.atleast_1d(np.asarray(freq, dtype=np.float64))
@@ -563,6 +569,7 @@ class JetModel:
         if device:
             return out.reshape(len(freqs), self.nx, self.nz)
         arr = self._map(out, (len(freqs),))
+        self._dev_product = out.reshape(len(freqs), self.nx, self.nz) if keep else None
         return arr[0] if scalar else arr
 
     def _cells(self, freq, savefits, rrl=None):
@@ -606,26 +613,26 @@ class JetModel:
         _, em, _ = self._base_maps()
         ems = self._map(em)
         if savefits:
-            self.save_fits(miscf.reorder_axes(ems, ra_axis=0, dec_axis=1), savefits, 'em')
+            self.save_fits(np.transpose(ems, (1, 0)), savefits, 'em')
         return ems
 
     def optical_depth_ff(self, freq, savefits=False, collapse=True):
         """Free-free optical depth along y (classes.py:1353-1447)."""
         if not collapse:
             return self._cells(freq, savefits)
-        tff = self._ff_products(freq, tau=True)
+        tff = self._ff_products(freq, tau=True, keep=bool(savefits))
         self._save_cube(tff, savefits, 'tau', freq)
         return tff
 
     def intensity_ff(self, freq, savefits=False):
         """Radio intensity [W m^-2 Hz^-1 sr^-1] (classes.py:1449-1496)."""
-        ints = self._ff_products(freq, intensity=True)
+        ints = self._ff_products(freq, intensity=True, keep=bool(savefits))
         self._save_cube(ints, savefits, 'intensity', freq)
         return ints
 
     def flux_ff(self, freq, savefits=False):
         """Flux density [Jy/pixel] (classes.py:1498-1541)."""
-        fluxes = self._ff_products(freq, flux=True)
+        fluxes = self._ff_products(freq, flux=True, keep=bool(savefits))
         self._save_cube(fluxes, savefits, 'flux', freq)
         return fluxes
 
@@ -648,8 +655,10 @@ class JetModel:
             return self._cells(freq, savefits, rrl=rrl)
         scalar = np.isscalar(freq)
         freqs = np.atleast_1d(np.asarray(freq, dtype=np.float64))
-        tau = self._map(self._rrl_tau_device(rrl, freqs), (len(freqs),))
+        dev = self._rrl_tau_device(rrl, freqs)
+        tau = self._map(dev, (len(freqs),))
         tau = tau[0] if scalar else tau
+        self._dev_product = dev.reshape(len(freqs), self.nx, self.nz) if savefits else None
         self._save_cube(tau, savefits, 'tau', freq)
         return tau
 
@@ -671,6 +680,7 @@ class JetModel:
         flux, _ = self.engine.rrl_maps(tau_rrl, tau_ff, self._tavg, flux_ff, cfl, hnu,
                                        want_ftot=False)
         out = self._map(flux, (F,))
+        self._dev_product = flux.reshape(F, self.nx, self.nz)
         return out[0] if scalar else out
 
     def intensity_rrl(self, rrl, freq, lte=True, savefits=False):
@@ -690,19 +700,29 @@ class JetModel:
 
     # ------------------------------------------------------------------ products ----
     def _save_cube(self, data, savefits, image_type, freq):
+        dev, self._dev_product = getattr(self, "_dev_product", None), None
         if not savefits:
             return
-        if np.ndim(data) == 3:
-            arr = miscf.reorder_axes(data, ra_axis=1, dec_axis=2, axis3=0, axis3_type='freq')
+        if (dev is not None and np.ndim(data) == 3 and tuple(dev.shape) == np.shape(data) and
+                dev.numel() * 8 >= self.FITS_DEVICE_MIN_BYTES):
+            # (F, n_x, n_z) -> FITS order (F, dec = z, ra = x), big-endian, on the GPU: the
+            # host only receives the bytes and writes them
+            import torch
+            t = dev.transpose(1, 2).contiguous()
+            be = t.view(torch.uint8).reshape(-1, 8).flip(1).contiguous()
+            arr = _fits.BigEndian(t.shape, _to_host(be.reshape(-1)))
+        elif np.ndim(data) == 3:
+            # views, not copies: the writer lays the bytes out in one pass
+            arr = np.transpose(data, (0, 2, 1))
         else:
-            arr = miscf.reorder_axes(data, ra_axis=0, dec_axis=1)
+            arr = np.transpose(data, (1, 0))
         self.save_fits(arr, savefits, image_type, freq)
 
     def save_fits(self, data, filename, image_type, freq=None):
         """Write a map/cube with the reference's header (classes.py:1543-1652)."""
         if image_type not in ('flux', 'tau', 'em', 'intensity'):
             raise ValueError("arg image_type must be one of 'flux', 'tau' or 'em'")
-        ndims = len(np.shape(data))
+        ndims = len(data.shape if isinstance(data, _fits.BigEndian) else np.shape(data))
         if ndims not in (2, 3):
             raise ValueError(f"Unexpected number of data dimensions ({ndims})")
         tg = self.params['target']

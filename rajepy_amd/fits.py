@@ -81,7 +81,7 @@ class Header:
         self.history.append(text)
 
     def render(self, data):
-        shape = data.shape
+        shape = data if isinstance(data, tuple) else data.shape
         out = [card('SIMPLE', True, 'conforms to FITS standard'),
                card('BITPIX', -64, 'array data type'),
                card('NAXIS', len(shape), 'number of array dimensions')]
@@ -97,13 +97,31 @@ class Header:
         return txt.encode('ascii')
 
 
+class BigEndian:
+    """Image data already in FITS order and byte order: `raw` = the big-endian float64 bytes
+    (any C-contiguous bytes-like object), `shape` = the array shape they stand for.  JetModel
+    builds large products this way on the GPU (transpose + byte swap at HBM speed)."""
+
+    def __init__(self, shape, raw):
+        self.shape = tuple(int(n) for n in shape)
+        self.raw = raw
+        if len(memoryview(raw).cast('B')) != 8 * int(np.prod(self.shape)):
+            raise ValueError("payload size does not match its shape")
+
+
 def writeto(filename, data, header):
-    data = np.asarray(data, dtype=np.float64)
-    raw = np.ascontiguousarray(data, dtype='>f8').tobytes()
-    raw += b'\0' * (-len(raw) % BLOCK)
+    if isinstance(data, BigEndian):
+        shape, raw = data.shape, memoryview(data.raw).cast('B')
+    else:
+        data = np.asarray(data, dtype=np.float64)
+        shape = data.shape
+        # one pass: layout (a transposed view is fine) and byte order together; written
+        # straight from the array's buffer
+        raw = memoryview(np.ascontiguousarray(data, dtype='>f8')).cast('B')
     with open(filename, 'wb') as f:
-        f.write(header.render(data))
+        f.write(header.render(shape))
         f.write(raw)
+        f.write(b'\0' * (-len(raw) % BLOCK))
 
 
 def read(filename):

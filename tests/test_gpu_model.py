@@ -260,6 +260,36 @@ def test_pipeline_execute_matches_reference_products(tmp_path):
     assert "previously completed, skipping" in open(pl2.log.filename).read()
 
 
+def test_fits_payload_built_on_the_gpu_is_byte_identical(tmp_path, monkeypatch):
+    """Large products are transposed to FITS axis order and byte-swapped on the GPU and
+    the host only writes the bytes (JetModel.FITS_DEVICE_MIN_BYTES): forced on for the
+    config-1 pipeline, every product file must equal, byte for byte, the file the host
+    path writes -- cubes (tau, flux of continuum and RRL runs) and 2-D maps alike."""
+    outs = {}
+    for tag, thr in (("host", 1 << 62), ("device", 0)):
+        monkeypatch.setattr(classes.JetModel, "FITS_DEVICE_MIN_BYTES", thr)
+        dcy = str(tmp_path / tag)
+        os.makedirs(dcy)
+        log = logger.Log(os.path.join(dcy, "model.log"), verbose=False)
+        pl = classes.Pipeline(classes.JetModel(example_params(), log=log), pline_params(dcy),
+                              log=log)
+        pl.execute(simobserve=False, verbose=False, dryrun=False, resume=False, clobber=True)
+        outs[tag] = {os.path.relpath(os.path.join(r, f), dcy):
+                     hashlib.sha256(open(os.path.join(r, f), "rb").read()).hexdigest()
+                     for r, _, fs in os.walk(dcy) for f in fs if f.endswith(".fits")}
+    assert len(outs["host"]) >= 9 and outs["host"] == outs["device"]
+    # and a multi-channel continuum cube through the public method
+    jm = classes.JetModel(example_params(), log=logger.Log(str(tmp_path / "c.log"), verbose=False))
+    freqs = np.geomspace(1e9, 5e10, 7)
+    for tag, thr in (("host", 1 << 62), ("device", 0)):
+        monkeypatch.setattr(classes.JetModel, "FITS_DEVICE_MIN_BYTES", thr)
+        jm.flux_ff(freqs, savefits=str(tmp_path / (tag + ".fits")))
+    assert open(tmp_path / "host.fits", "rb").read() == open(tmp_path / "device.fits", "rb").read()
+    data, _ = fits.read(str(tmp_path / "device.fits"))
+    np.testing.assert_array_equal(np.nan_to_num(data),
+                                  np.nan_to_num(np.transpose(jm.flux_ff(freqs), (0, 2, 1))))
+
+
 def test_pipeline_reuses_existing_products(tmp_path):
     """clobber=False with products on disk: fluxes are read back from the FITS files instead
     of being recomputed (classes.py:2393-2453) and give the same run results."""

@@ -42,6 +42,14 @@ dev.ylo, dev.yhi = keep
 t0 = time.perf_counter(); jm.time = 0.; f = jm.flux_ff(np.geomspace(1e9, 5e10, 256))
 out["jetmodel_flux_ff_256ch_512x4096x512_incl_d2h_s"] = time.perf_counter() - t0
 out["jet_filled_fraction"] = float(np.isfinite(f[0]).mean())
+# the same call writing its 0.54 GB FITS cube: payload laid out on the GPU vs on the host
+for tag, thr in (("device", 0), ("host", 1 << 62)):
+    classes.JetModel.FITS_DEVICE_MIN_BYTES = thr
+    path = os.path.join(tmp, "cube_%s.fits" % tag)
+    t0 = time.perf_counter(); jm.flux_ff(np.geomspace(1e9, 5e10, 256), savefits=path)
+    out["jetmodel_flux_ff_256ch_savefits_%s_payload_s" % tag] = time.perf_counter() - t0
+    os.remove(path)
+classes.JetModel.FITS_DEVICE_MIN_BYTES = 8 << 20
 del jm, dev, f
 # config 1 end to end (reference: 31 s incl. plots)
 dcy = os.path.join(tmp, "out"); os.makedirs(dcy)
