@@ -573,10 +573,13 @@ size_t ff_scan_workspace_bytes(int nx, int ny, int nz, int n_epochs) {
 // per-burst constants: un.q for the bursts that travel by value, `qext` (2 * next doubles,
 // may be nullptr when the model has no overflow bursts) for the rest.
 static void uniform_tile(const double* t, int et, const rjp_bursts* hb, UnifDev& un,
-                         double* qext) {
+                         double* qext, std::vector<double>* atab = nullptr) {
   un.on = 0;
+  un.nbt = 0;
   un.dt = 0.0;
   un.qext = nullptr;
+  un.atab = nullptr;
+  if (atab) atab->clear();
   const int next = bursts_overflow(hb);
   for (int j = 0; j < 2; ++j) {
     for (int i = 0; i < RJP_SGPR_BURSTS; ++i) un.q[j][i] = 1.0;
@@ -607,6 +610,17 @@ static void uniform_tile(const double* t, int et, const rjp_bursts* hb, UnifDev&
     }
   un.on = 1;
   un.dt = dt;
+  un.nbt = std::max(hb->n[0], hb->n[1]);
+  if (atab) {
+    // step table of the two-operation recurrence: q^(k (k + 1) / 2) = exp(-inv dt^2 k (k + 1));
+    // unused slots (the shorter jet) hold 1, their amplitude is 0
+    atab->assign((size_t)2 * un.nbt * RJP_STEP_TAB, 1.0);
+    for (int j = 0; j < 2; ++j)
+      for (int i = 0; i < hb->n[j]; ++i)
+        for (int k = 1; k <= RJP_STEP_TAB; ++k)
+          (*atab)[((size_t)j * un.nbt + i) * RJP_STEP_TAB + k - 1] =
+              std::exp(-hb->inv2s2[j][i] * dt * dt * (double)(k * (k + 1)));
+  }
 }
 
 template <typename T, int VEC, int ET, int MODE, bool BURSTS, bool CMP>
@@ -704,11 +718,13 @@ static bool use_tile32() {
 }
 
 // The epoch tiling of one scan, decided on the host before anything is enqueued, so that the
-// constants of bursts beyond RJP_SGPR_BURSTS (parameters + one q per tile) can travel to the
-// device in ONE small table: ext = [params: 6 * next][tile 0 q: 2 * next][tile 1 q] ...
+// constants of bursts beyond RJP_SGPR_BURSTS (parameters + one q per tile) and the step tables
+// of the uniform-epoch tiles can travel to the device in ONE small table:
+// ext = [params: 6 * next][tile 0: q (2 * next), step table (2 * nbt * 16 or 0)][tile 1 ...] ...
 struct ScanTile {
   int e0, et;
-  UnifDev un;          // un.qext is patched to the device table by ff_scan_run
+  UnifDev un;          // un.qext / un.atab are patched to the device table by ff_scan_run
+  size_t q_off, a_off; // offsets of the tile's q and step table in ScanPlan::ext
 };
 struct ScanPlan {
   bool bursts = false;
@@ -729,7 +745,7 @@ void ff_scan_plan(const rjp_fields* fl, const rjp_bursts* hb, const double* epoc
   pl.tiles.clear();
   pl.ext.assign(bursts_ext_doubles(hb), 0.0);
   if (pl.next > 0) bursts_fill_ext(hb, pl.ext.data());
-  std::vector<double> q((size_t)2 * pl.next + 1);
+  std::vector<double> q((size_t)2 * pl.next + 1), atab;
   int e0 = 0;
   while (e0 < n_epochs) {
     ScanTile tl;
@@ -750,9 +766,12 @@ void ff_scan_plan(const rjp_fields* fl, const rjp_bursts* hb, const double* epoc
       }
       // the tile's own constants (short tiles of f32 storage keep their float-accuracy exp:
       // launch_tile ignores `un` there)
-      uniform_tile(epochs + e0, tl.et, hb, tl.un, q.data());
+      uniform_tile(epochs + e0, tl.et, hb, tl.un, q.data(), &atab);
     }
+    tl.q_off = pl.ext.size();
     if (pl.next > 0) pl.ext.insert(pl.ext.end(), q.begin(), q.begin() + 2 * pl.next);
+    tl.a_off = pl.ext.size();
+    pl.ext.insert(pl.ext.end(), atab.begin(), atab.end());
     pl.tiles.push_back(tl);
     if (!pl.bursts) break;
     e0 += tl.et;
@@ -767,7 +786,7 @@ hipError_t ff_scan_run(const rjp_fields* fl, const rjp_bursts* hb, const ScanPla
   BurstsDev b;
   const bool bursts = bursts_to_dev(hb, b, d_ext);
   if (bursts && !fl->d_ts) return hipErrorInvalidValue;
-  if (pl.next > 0 && !d_ext) return hipErrorInvalidValue;
+  if (!pl.ext.empty() && !d_ext) return hipErrorInvalidValue;
   const int64_t npix = (int64_t)fl->nx * fl->nz;
   const int vec = pl.vec, nsplit = pl.nsplit, ylen = pl.ylen;
   // em = sum (n x)^2 * csize*au/pc * pf  (classes.py:1116-1118)
@@ -777,7 +796,8 @@ hipError_t ff_scan_run(const rjp_fields* fl, const rjp_bursts* hb, const ScanPla
   for (size_t k = 0; k < pl.tiles.size(); ++k) {
     const int e0 = pl.tiles[k].e0, et = pl.tiles[k].et;
     UnifDev un = pl.tiles[k].un;
-    un.qext = pl.next > 0 ? d_ext + bursts_ext_doubles(hb) + k * 2 * (size_t)pl.next : nullptr;
+    un.qext = pl.next > 0 ? d_ext + pl.tiles[k].q_off : nullptr;
+    un.atab = un.on ? d_ext + pl.tiles[k].a_off : nullptr;
     hipError_t err;
     const double* t = epochs + e0;
     if (fl->dtype == RJP_F64) {

@@ -266,11 +266,19 @@ __device__ __forceinline__ void chi_batch(const BurstsDev& b, const bool (&red)[
 #ifndef RJP_BURST_PIPELINE
 #define RJP_BURST_PIPELINE 1   /* 0: A/B build without the scalar-load pipelining */
 #endif
+#ifndef RJP_TWO_OP
+#define RJP_TWO_OP 1           /* 0: A/B build with the three-operation recurrence everywhere */
+#endif
+#define RJP_STEP_TAB 16                      /* doubles per (jet, burst) of UnifDev::atab */
 struct UnifDev {
   int on;                                   // 0 = evaluate every epoch directly
+  int nbt;                                  // bursts per jet in `atab` (= max(n[0], n[1]))
   double dt;                                // epoch spacing [s]
   double q[2][RJP_SGPR_BURSTS];             // exp(-2 inv2s2 dt^2)
   const double* qext;                       // the same for the overflow bursts: qext[jet * next + i]
+  // step table of the two-operation recurrence (waves inside one jet):
+  // atab[(jet * nbt + i) * RJP_STEP_TAB + k - 1] = q^(k (k + 1) / 2), k = 1 .. 16
+  const double* atab;
 };
 
 template <int ET, int UV>
@@ -331,6 +339,80 @@ __device__ __forceinline__ void chi_batch_uniform(const BurstsDev& b, const Unif
   };
   const int n0 = nb < RJP_SGPR_BURSTS ? nb : RJP_SGPR_BURSTS;
   int i = 0;
+#if RJP_TWO_OP
+  if (!mixed) {
+    // Wave inside one jet (the usual case): E_{m+j} = E_m rup^j q^{j(j-1)/2} and
+    // E_{m-j} = E_m rup^{-j} q^{j(j+1)/2}.  The powers of q are the same for every cell of the
+    // wave: they come from the step table by SCALAR loads (SGPR operands of the FMAs), so a
+    // step costs one multiply + one FMA per direction instead of two multiplies + one FMA.
+    // Magnitudes: the launcher keeps the half-span below 28 sigma, so rup^{+-j} E_m stays
+    // below exp(420) and the table entries above exp(-420).
+    typedef double tab8 __attribute__((ext_vector_type(8)));
+    auto apply2 = [&](int c, double t0, double inv, double amp, const double* __restrict__ tab)
+        __attribute__((always_inline)) {
+      double vm = tlm[c] - t0;
+      // The step table is requested HERE, one SMEM round trip ahead of its first use: issued
+      // by hand because the scheduler otherwise sinks the scalar loads to the recurrence (to
+      // save SGPRs during the exp() chains) and every trip then waits for them.  `vm` passes
+      // through the statement so that the exp() chains stay behind the request.
+      tab8 ta, tb;
+      if (M > 8)
+        asm volatile("s_load_dwordx16 %0, %3, 0x0\n\ts_load_dwordx16 %1, %3, 0x40"
+                     : "=&s"(ta), "=&s"(tb), "+v"(vm) : "s"(tab));
+      else
+        asm volatile("s_load_dwordx16 %0, %2, 0x0" : "=&s"(ta), "+v"(vm) : "s"(tab));
+      const double argm = -(vm * vm) * inv;
+      const bool dead = argm < -700.0;
+      const double em = exp_nonpos(argm);
+      const double idt = inv * un.dt;
+      const double xr = -__builtin_fma(2.0 * idt, vm, idt * un.dt);    // ln(E_{m+1} / E_m)
+      const double rup = exp_any(xr);
+      double ir = __builtin_amdgcn_rcp(rup);
+      ir = ir * __builtin_fma(-rup, ir, 2.0);
+      const double ae = dead ? 0.0 : amp * em;    // a dead cell adds exactly nothing
+      chi[M * UV + c] += ae;
+      double eu = ae, ed = ae;
+      const double ru = dead ? 0.0 : rup, rd = dead ? 0.0 : ir;
+      if (M > 8) asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(ta), "+s"(tb));
+      else asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(ta));
+      auto T = [&](int k) __attribute__((always_inline)) { return k < 8 ? ta[k] : tb[k - 8]; };
+#pragma unroll
+      for (int j = 1; j <= M; ++j) {
+        if (M + j < ET) {
+          eu *= ru;
+          chi[(M + j) * UV + c] = j == 1 ? chi[(M + j) * UV + c] + eu
+                                         : __builtin_fma(eu, T(j - 2), chi[(M + j) * UV + c]);
+        }
+        ed *= rd;
+        chi[(M - j) * UV + c] = __builtin_fma(ed, T(j - 1), chi[(M - j) * UV + c]);
+      }
+    };
+    // the parameters of the NEXT burst are requested before the current one is worked on (a
+    // trip is ~110 FP64 instructions and would otherwise start by waiting for the SMEM round
+    // trip); the step table of the current burst is requested at the top of its trip and
+    // first needed after the two exp() chains
+    struct BP { double t0, inv, amp; };
+    auto ld = [&](int k) __attribute__((always_inline)) {
+      const int kk = k < RJP_SGPR_BURSTS - 1 ? k : RJP_SGPR_BURSTS - 1;   // stay inside the table
+      return BP{b.t0[jet][kk], b.inv2s2[jet][kk], b.amp_rel[jet][kk]};
+    };
+    BP cur = ld(0);
+    for (; i < n0; ++i) {
+      const BP nxt = ld(i + 1);
+      const double* tab = un.atab + (size_t)(jet * un.nbt + i) * RJP_STEP_TAB;
+#pragma unroll
+      for (int c = 0; c < UV; ++c) apply2(c, cur.t0, cur.inv, cur.amp, tab);
+      cur = nxt;
+    }
+    for (i = RJP_SGPR_BURSTS; i < nb; ++i) {
+      const double* tab = un.atab + (size_t)(jet * un.nbt + i) * RJP_STEP_TAB;
+      const double* e = b.ext + (size_t)(jet * 3) * b.next + (i - RJP_SGPR_BURSTS);
+#pragma unroll
+      for (int c = 0; c < UV; ++c) apply2(c, e[0], e[2 * b.next], e[b.next], tab);
+    }
+    return;
+  }
+#endif
   if (ET >= 16 && !mixed && RJP_BURST_PIPELINE) {
     // Wave inside one jet (the usual case): the burst parameters are scalar loads from the
     // kernel-argument segment, and a trip of ~400 FP64 instructions used to start by waiting
