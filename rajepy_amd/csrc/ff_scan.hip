@@ -511,9 +511,14 @@ hipError_t ff_cells_launch(const rjp_fields* fl, const rjp_bursts* hb, const dou
 // per split, and at least 128 rows once every CU already has a wave without splitting (cfg2,
 // 256x1024x256: 8 splits of 128 rows 0.29 ms, 16 of 64 rows 0.31-0.32 ms,
 // profiles/r02_k1_tuning_ab.md).
-static int ysplit_rule(int64_t nchunks, int ny) {
+// `et` = epochs of the tile: the uniform-epoch tiles of >= 16 epochs are ALU-bound and run
+// for ~0.5 ms per epoch and block row range, 3-4 workgroups per CU at a time; with 8 y-ranges
+// (32 workgroups per CU) the last wave of workgroups leaves the chip 1/4 empty for a tenth of
+// the pass.  They get 4x the y-ranges (cfg5's 32-epoch tile 16.6 -> 16.0 ms, partial sums of
+// 2.3 GB reduced in 0.4 ms; the HBM-bound single-epoch scan is fastest at 8).
+static int ysplit_rule(int64_t nchunks, int ny, int et = 1) {
   const int64_t waves = (nchunks + RJP_WAVE - 1) / RJP_WAVE;
-  const int64_t target = 256 * 64;
+  const int64_t target = 256 * (et >= 16 ? 512 : 64);
   int64_t s = (target + waves - 1) / waves;
   const int64_t smax = std::max(1, waves >= 256 ? ny / 128 : ny / 16);
   if (s > smax) s = smax;
@@ -541,9 +546,9 @@ static int forced_ysplit() {
   return forced;
 }
 
-static int choose_ysplit(int64_t nchunks, int ny) {
+static int choose_ysplit(int64_t nchunks, int ny, int et = 1) {
   if (forced_ysplit() > 0) return std::min(forced_ysplit(), ny);
-  return ysplit_rule(nchunks, ny);
+  return ysplit_rule(nchunks, ny, et);
 }
 
 int ff_scan_vec(const rjp_fields* fl) {
@@ -561,12 +566,20 @@ int ff_scan_vec(const rjp_fields* fl) {
 
 size_t ff_scan_workspace_bytes(int nx, int ny, int nz, int n_epochs) {
   const int64_t npix = (int64_t)nx * nz;
-  const int et = n_epochs < kMaxTile ? (n_epochs < 1 ? 1 : n_epochs) : kMaxTile;
-  // worst case over the lane widths the launcher may pick (1, 2 or 4 sightlines per lane)
-  int64_t s = 1;
-  for (int vec : {1, 2, 4}) s = std::max<int64_t>(s, ysplit_rule(std::max<int64_t>(1, npix / vec), ny));
-  if (forced_ysplit() > 0) s = std::max<int64_t>(s, std::min(forced_ysplit(), ny));
-  return (size_t)s * nacc(et) * npix * sizeof(double) + 256;
+  const int etmax = n_epochs < kMaxTile ? (n_epochs < 1 ? 1 : n_epochs) : kMaxTile;
+  // worst case over the tile sizes and the lane widths the launcher may pick (1, 2 or 4
+  // sightlines per lane; one for tiles of >= 16 epochs)
+  int64_t need = 1;
+  for (int et : {1, 2, 4, 8, 16, 32}) {
+    if (et > etmax && et != 1) continue;
+    int64_t s = 1;
+    for (int vec : {1, 2, 4})
+      s = std::max<int64_t>(s, ysplit_rule(std::max<int64_t>(1, npix / vec), ny, et));
+    if (forced_ysplit() > 0) s = std::max<int64_t>(s, std::min(forced_ysplit(), ny));
+    need = std::max<int64_t>(need, s * nacc(et));
+  }
+  // (an n_epochs that is no tile size itself is cut into tiles no larger than it)
+  return (size_t)need * npix * sizeof(double) + 256;
 }
 
 // Decide whether a tile of epochs may use the uniform-spacing recurrence and fill its
@@ -725,10 +738,11 @@ struct ScanTile {
   int e0, et;
   UnifDev un;          // un.qext / un.atab are patched to the device table by ff_scan_run
   size_t q_off, a_off; // offsets of the tile's q and step table in ScanPlan::ext
+  int nsplit, ylen;    // y-ranges of this tile's launch
 };
 struct ScanPlan {
   bool bursts = false;
-  int vec = 1, nsplit = 1, ylen = 1, next = 0;
+  int vec = 1, next = 0;
   std::vector<ScanTile> tiles;
   std::vector<double> ext;       // host image of the overflow table (empty without overflow)
 };
@@ -740,8 +754,6 @@ void ff_scan_plan(const rjp_fields* fl, const rjp_bursts* hb, const double* epoc
   pl.next = bursts_overflow(hb);
   const int64_t npix = (int64_t)fl->nx * fl->nz;
   pl.vec = ff_scan_vec(fl);
-  pl.nsplit = choose_ysplit(npix / pl.vec, fl->ny);
-  pl.ylen = (fl->ny + pl.nsplit - 1) / pl.nsplit;
   pl.tiles.clear();
   pl.ext.assign(bursts_ext_doubles(hb), 0.0);
   if (pl.next > 0) bursts_fill_ext(hb, pl.ext.data());
@@ -768,6 +780,9 @@ void ff_scan_plan(const rjp_fields* fl, const rjp_bursts* hb, const double* epoc
       // launch_tile ignores `un` there)
       uniform_tile(epochs + e0, tl.et, hb, tl.un, q.data(), &atab);
     }
+    // tiles of >= 16 epochs run one sightline per lane
+    tl.nsplit = choose_ysplit(tl.et >= 16 ? npix : npix / pl.vec, fl->ny, tl.et);
+    tl.ylen = (fl->ny + tl.nsplit - 1) / tl.nsplit;
     tl.q_off = pl.ext.size();
     if (pl.next > 0) pl.ext.insert(pl.ext.end(), q.begin(), q.begin() + 2 * pl.next);
     tl.a_off = pl.ext.size();
@@ -788,13 +803,14 @@ hipError_t ff_scan_run(const rjp_fields* fl, const rjp_bursts* hb, const ScanPla
   if (bursts && !fl->d_ts) return hipErrorInvalidValue;
   if (!pl.ext.empty() && !d_ext) return hipErrorInvalidValue;
   const int64_t npix = (int64_t)fl->nx * fl->nz;
-  const int vec = pl.vec, nsplit = pl.nsplit, ylen = pl.ylen;
+  const int vec = pl.vec;
   // em = sum (n x)^2 * csize*au/pc * pf  (classes.py:1116-1118)
   const double em_scale = fl->csize_au * 149597870700.0 / 3.085677581491367e+16;
   const unsigned rblocks = (unsigned)((npix + kBlock - 1) / kBlock);
 
   for (size_t k = 0; k < pl.tiles.size(); ++k) {
     const int e0 = pl.tiles[k].e0, et = pl.tiles[k].et;
+    const int nsplit = pl.tiles[k].nsplit, ylen = pl.tiles[k].ylen;
     UnifDev un = pl.tiles[k].un;
     un.qext = pl.next > 0 ? d_ext + pl.tiles[k].q_off : nullptr;
     un.atab = un.on ? d_ext + pl.tiles[k].a_off : nullptr;

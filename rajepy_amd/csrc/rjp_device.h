@@ -294,9 +294,13 @@ __device__ __forceinline__ void chi_batch_uniform(const BurstsDev& b, const Unif
   const bool wave_blue = __builtin_amdgcn_ballot_w64(any_blue) != 0;
   const bool mixed = wave_red && wave_blue;
   const int jet = wave_red ? 0 : 1;
-#pragma unroll
-  for (int k = 0; k < ET * UV; ++k) chi[k] = 1.0;
   const int nb = mixed ? (b.n[0] > b.n[1] ? b.n[0] : b.n[1]) : b.n[jet];
+  // (a wave inside one jet starts from chi = 1 inside its first burst: the 1 is the addend of
+  // that burst's FMAs instead of ET moves per cell)
+  if (!RJP_TWO_OP || mixed || nb == 0) {
+#pragma unroll
+    for (int k = 0; k < ET * UV; ++k) chi[k] = 1.0;
+  }
   // one burst (its parameters for the red and the blue jet) applied to cell c
   auto apply = [&](int c, double t0r, double invr, double ampr, double qr, double t0b,
                    double invb, double ampb, double qb) __attribute__((always_inline)) {
@@ -348,8 +352,8 @@ __device__ __forceinline__ void chi_batch_uniform(const BurstsDev& b, const Unif
     // Magnitudes: the launcher keeps the half-span below 28 sigma, so rup^{+-j} E_m stays
     // below exp(420) and the table entries above exp(-420).
     typedef double tab8 __attribute__((ext_vector_type(8)));
-    auto apply2 = [&](int c, double t0, double inv, double amp, const double* __restrict__ tab)
-        __attribute__((always_inline)) {
+    auto apply2 = [&](int c, double t0, double inv, double amp, const double* __restrict__ tab,
+                      bool first) __attribute__((always_inline)) {
       double vm = tlm[c] - t0;
       // The step table is requested HERE, one SMEM round trip ahead of its first use: issued
       // by hand because the scheduler otherwise sinks the scalar loads to the recurrence (to
@@ -370,7 +374,7 @@ __device__ __forceinline__ void chi_batch_uniform(const BurstsDev& b, const Unif
       double ir = __builtin_amdgcn_rcp(rup);
       ir = ir * __builtin_fma(-rup, ir, 2.0);
       const double ae = dead ? 0.0 : amp * em;    // a dead cell adds exactly nothing
-      chi[M * UV + c] += ae;
+      chi[M * UV + c] = (first ? 1.0 : chi[M * UV + c]) + ae;
       double eu = ae, ed = ae;
       const double ru = dead ? 0.0 : rup, rd = dead ? 0.0 : ir;
       if (M > 8) asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(ta), "+s"(tb));
@@ -380,11 +384,11 @@ __device__ __forceinline__ void chi_batch_uniform(const BurstsDev& b, const Unif
       for (int j = 1; j <= M; ++j) {
         if (M + j < ET) {
           eu *= ru;
-          chi[(M + j) * UV + c] = j == 1 ? chi[(M + j) * UV + c] + eu
-                                         : __builtin_fma(eu, T(j - 2), chi[(M + j) * UV + c]);
+          const double cu = first ? 1.0 : chi[(M + j) * UV + c];
+          chi[(M + j) * UV + c] = j == 1 ? cu + eu : __builtin_fma(eu, T(j - 2), cu);
         }
         ed *= rd;
-        chi[(M - j) * UV + c] = __builtin_fma(ed, T(j - 1), chi[(M - j) * UV + c]);
+        chi[(M - j) * UV + c] = __builtin_fma(ed, T(j - 1), first ? 1.0 : chi[(M - j) * UV + c]);
       }
     };
     // the parameters of the NEXT burst are requested before the current one is worked on (a
@@ -396,19 +400,27 @@ __device__ __forceinline__ void chi_batch_uniform(const BurstsDev& b, const Unif
       const int kk = k < RJP_SGPR_BURSTS - 1 ? k : RJP_SGPR_BURSTS - 1;   // stay inside the table
       return BP{b.t0[jet][kk], b.inv2s2[jet][kk], b.amp_rel[jet][kk]};
     };
+    if (nb == 0) return;
     BP cur = ld(0);
-    for (; i < n0; ++i) {
+    {
+      const BP nxt = ld(1);
+      const double* tab = un.atab + (size_t)(jet * un.nbt) * RJP_STEP_TAB;
+#pragma unroll
+      for (int c = 0; c < UV; ++c) apply2(c, cur.t0, cur.inv, cur.amp, tab, true);
+      cur = nxt;
+    }
+    for (i = 1; i < n0; ++i) {
       const BP nxt = ld(i + 1);
       const double* tab = un.atab + (size_t)(jet * un.nbt + i) * RJP_STEP_TAB;
 #pragma unroll
-      for (int c = 0; c < UV; ++c) apply2(c, cur.t0, cur.inv, cur.amp, tab);
+      for (int c = 0; c < UV; ++c) apply2(c, cur.t0, cur.inv, cur.amp, tab, false);
       cur = nxt;
     }
     for (i = RJP_SGPR_BURSTS; i < nb; ++i) {
       const double* tab = un.atab + (size_t)(jet * un.nbt + i) * RJP_STEP_TAB;
       const double* e = b.ext + (size_t)(jet * 3) * b.next + (i - RJP_SGPR_BURSTS);
 #pragma unroll
-      for (int c = 0; c < UV; ++c) apply2(c, e[0], e[2 * b.next], e[b.next], tab);
+      for (int c = 0; c < UV; ++c) apply2(c, e[0], e[2 * b.next], e[b.next], tab, false);
     }
     return;
   }
