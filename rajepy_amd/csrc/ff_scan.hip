@@ -653,10 +653,14 @@ static hipError_t launch_tile(const rjp_fields* fl, const BurstsDev& b, const do
   // the recurrence pays with at least 4 epochs per tile; short tiles of f32 storage keep
   // their 9-instruction float-accuracy exp instead
   if constexpr (ET == 32) {
-    // 32 epochs per pass: recurrence only, and only without the emission-measure accumulators
-    if (ep.un.on && !want_em) {
-      hipLaunchKernelGGL((ff_scan_kernel<T, VEC, ET, MODE, true, true, CMP, false>), grid,
-                         dim3(kBlock), 0, st, f, fl->ny, fl->nz, nchunks, npix, ylen, nsplit, b, ep, ws);
+    // 32 epochs per pass: recurrence only
+    if (ep.un.on) {
+      if (want_em)
+        hipLaunchKernelGGL((ff_scan_kernel<T, VEC, ET, MODE, true, true, CMP, true>), grid,
+                           dim3(kBlock), 0, st, f, fl->ny, fl->nz, nchunks, npix, ylen, nsplit, b, ep, ws);
+      else
+        hipLaunchKernelGGL((ff_scan_kernel<T, VEC, ET, MODE, true, true, CMP, false>), grid,
+                           dim3(kBlock), 0, st, f, fl->ny, fl->nz, nchunks, npix, ylen, nsplit, b, ep, ws);
       return hipGetLastError();
     }
   } else if constexpr (BURSTS && ET >= 4 && (sizeof(T) == 8 || ET == 16)) {
@@ -724,6 +728,12 @@ static hipError_t dispatch_mode(const rjp_fields* fl, const BurstsDev& b, bool b
   return dispatch_et<T, VEC, RJP_GFF_POWERLAW, false>(fl, b, bursts, t, un, et, nsplit, ylen, ws, want_em, st);
 }
 
+static bool tile32_em() {
+  static int v = -1;
+  if (v < 0) v = debug_env("RJP_NO_TILE32_EM") ? 0 : 1;
+  return v != 0;
+}
+
 static bool use_tile32() {
   static int v = -1;
   if (v < 0) v = debug_env("RJP_NO_TILE32") ? 0 : 1;
@@ -772,7 +782,7 @@ void ff_scan_plan(const rjp_fields* fl, const rjp_bursts* hb, const double* epoc
         uniform_tile(epochs + e0, 16, hb, probe, q.data());
         if (probe.on) tl.et = 16;
       }
-      if (left >= 32 && !want_em && use_tile32()) {
+      if (left >= 32 && (!want_em || tile32_em()) && use_tile32()) {
         uniform_tile(epochs + e0, 32, hb, probe, q.data());
         if (probe.on) tl.et = 32;
       }

@@ -711,10 +711,10 @@ def test_rrl_small_voigt_y_every_lane_layout(eng, nchan, cw, thin):
 @pytest.mark.parametrize("store", ["f64", "f32"])
 @pytest.mark.parametrize("n_ep,t1", [(32, 5.0), (45, 4.0), (64, 2.0), (33, 0.6),
                                      (32, 8.0)])      # last: too wide for 32, falls back to 16
-def test_32_epoch_tiles_of_em_less_sweeps_follow_the_oracle(eng, store, n_ep, t1):
-    """d_em = NULL and >= 32 uniformly spaced epochs: one pass serves 32 epochs (recurrence
-    anchored at the tile's middle epoch).  Against the oracle at every epoch, and against the
-    16-epoch tiles of the same sweep with EM maps."""
+def test_32_epoch_tiles_follow_the_oracle(eng, store, n_ep, t1):
+    """>= 32 uniformly spaced epochs: one pass serves 32 epochs (recurrence anchored at the
+    tile's middle epoch), with the emission-measure accumulators (d_em given) or without
+    (d_em = NULL) -- two kernels.  Both against the oracle, and against each other."""
     from rajepy_amd import engine as E
     shape = (4, 37, 16)
     dtype = _store(store)
@@ -739,9 +739,11 @@ def test_32_epoch_tiles_of_em_less_sweeps_follow_the_oracle(eng, store, n_ep, t1
     np.testing.assert_allclose(a32.cpu().numpy(), a16.cpu().numpy(), rtol=tol)
     ctau, _ = E.ff_channel_coeffs([5e9], jet.csize, p["target"]["dist"], E.RJP_GFF_POWERLAW)
     got = a32.cpu().numpy().reshape(n_ep, shape[0], shape[2]) * ctau[0]
+    em_h = em16.cpu().numpy().reshape(n_ep, shape[0], shape[2])
     for e in (0, 1, n_ep // 2, 31, n_ep - 1):
         jet.time = ep[e]
         np.testing.assert_allclose(got[e], jet.optical_depth_ff(5e9), rtol=tol)
+        np.testing.assert_allclose(em_h[e], jet.emission_measure(), rtol=tol, err_msg=str(e))
 
 
 def test_per_call_tables_are_reused_only_when_equal(eng):
