@@ -514,15 +514,25 @@ hipError_t ff_cells_launch(const rjp_fields* fl, const rjp_bursts* hb, const dou
 // `et` = epochs of the tile: the uniform-epoch tiles of >= 16 epochs are ALU-bound and run
 // for ~0.5 ms per epoch and block row range, 3-4 workgroups per CU at a time; with 8 y-ranges
 // (32 workgroups per CU) the last wave of workgroups leaves the chip 1/4 empty for a tenth of
-// the pass.  They get 4x the y-ranges (cfg5's 32-epoch tile 16.6 -> 16.0 ms, partial sums of
-// 2.3 GB reduced in 0.4 ms; the HBM-bound single-epoch scan is fastest at 8).
-static int ysplit_rule(int64_t nchunks, int ny, int et = 1) {
+// the pass.  They get 4x the y-ranges (cfg5's 32-epoch tile 16.6 -> 16.0 ms including the
+// longer reduction of the partial sums; the HBM-bound single-epoch scan is fastest at 8),
+// fewer on maps so large that the partial sums would pass 6 GiB.
+static int ysplit_rule(int64_t nchunks, int ny, int et = 1, int64_t npix = 0) {
   const int64_t waves = (nchunks + RJP_WAVE - 1) / RJP_WAVE;
-  const int64_t target = 256 * (et >= 16 ? 512 : 64);
-  int64_t s = (target + waves - 1) / waves;
   const int64_t smax = std::max(1, waves >= 256 ? ny / 128 : ny / 16);
-  if (s > smax) s = smax;
-  if (s < 1) s = 1;
+  auto rule = [&](int64_t target) {
+    int64_t s = (target + waves - 1) / waves;
+    if (s > smax) s = smax;
+    return s < 1 ? (int64_t)1 : s;
+  };
+  int64_t s = rule(256 * 64);
+  if (et >= 16) {
+    // finer y-ranges while their partial sums stay below 6 GiB (4.4 GiB at cfg5's size)
+    int64_t fine = rule(256 * 512);
+    const int64_t per_range = (int64_t)nacc(et) * std::max<int64_t>(npix, nchunks) * 8;
+    while (fine > s && fine * per_range > ((int64_t)6 << 30)) fine = (fine + 1) / 2;
+    s = std::max(s, fine);
+  }
   return (int)s;
 }
 
@@ -546,9 +556,9 @@ static int forced_ysplit() {
   return forced;
 }
 
-static int choose_ysplit(int64_t nchunks, int ny, int et = 1) {
+static int choose_ysplit(int64_t nchunks, int ny, int et = 1, int64_t npix = 0) {
   if (forced_ysplit() > 0) return std::min(forced_ysplit(), ny);
-  return ysplit_rule(nchunks, ny, et);
+  return ysplit_rule(nchunks, ny, et, npix);
 }
 
 int ff_scan_vec(const rjp_fields* fl) {
@@ -574,7 +584,7 @@ size_t ff_scan_workspace_bytes(int nx, int ny, int nz, int n_epochs) {
     if (et > etmax && et != 1) continue;
     int64_t s = 1;
     for (int vec : {1, 2, 4})
-      s = std::max<int64_t>(s, ysplit_rule(std::max<int64_t>(1, npix / vec), ny, et));
+      s = std::max<int64_t>(s, ysplit_rule(std::max<int64_t>(1, npix / vec), ny, et, npix));
     if (forced_ysplit() > 0) s = std::max<int64_t>(s, std::min(forced_ysplit(), ny));
     need = std::max<int64_t>(need, s * nacc(et));
   }
@@ -791,7 +801,7 @@ void ff_scan_plan(const rjp_fields* fl, const rjp_bursts* hb, const double* epoc
       uniform_tile(epochs + e0, tl.et, hb, tl.un, q.data(), &atab);
     }
     // tiles of >= 16 epochs run one sightline per lane
-    tl.nsplit = choose_ysplit(tl.et >= 16 ? npix : npix / pl.vec, fl->ny, tl.et);
+    tl.nsplit = choose_ysplit(tl.et >= 16 ? npix : npix / pl.vec, fl->ny, tl.et, npix);
     tl.ylen = (fl->ny + tl.nsplit - 1) / tl.nsplit;
     tl.q_off = pl.ext.size();
     if (pl.next > 0) pl.ext.insert(pl.ext.end(), q.begin(), q.begin() + 2 * pl.next);
