@@ -108,19 +108,16 @@ __device__ __forceinline__ void cos_2pi_x3(double u0, double u1, double u2, doub
     const double w = kmul(6.28318530717958647692, __builtin_fma(-0.5, k[i], u[i]));
     w2[i] = w * w;
   }
-  constexpr double cf[9] = {-1.5619206968586226462e-16,   // -1/18!
-                            4.7794773323873852974e-14,    //  1/16!
-                            -1.1470745597729724714e-11,   // -1/14!
-                            2.0876756987868098979e-09,    //  1/12!
-                            -2.7557319223985888276e-07,   // -1/10!
-                            2.4801587301587301566e-05,    //  1/8!
-                            -1.3888888888888889419e-03,   // -1/6!
-                            4.1666666666666664354e-02,    //  1/4!
-                            -0.5};
+  // near-minimax on |w| <= pi/2 with the two leading coefficients kept at 1, -1/2 (inline
+  // constants): degree 14, max abs error 1e-14 (tools/minimax_fit.py) -- three FMAs per
+  // cosine fewer than the degree-20 Taylor polynomial this replaced
+  constexpr double cf[5] = {2.08632488319929278e-09, -2.75571005464740897e-07,
+                            2.48015855574161217e-05, -1.38888888828295133e-03,
+                            4.16666666666052621e-02};
 #pragma unroll
-  for (int i = 0; i < 3; ++i) p[i] = kadd(cf[0], kmul(4.1103176233121648585e-19, w2[i]));   // 1/20!
+  for (int i = 0; i < 3; ++i) p[i] = kadd(cf[0], kmul(-1.10650535275172774e-11, w2[i]));
 #pragma unroll
-  for (int j = 1; j < 8; ++j)
+  for (int j = 1; j < 5; ++j)
 #pragma unroll
     for (int i = 0; i < 3; ++i) p[i] = fma_k(p[i], w2[i], cf[j]);
 #pragma unroll
@@ -128,25 +125,30 @@ __device__ __forceinline__ void cos_2pi_x3(double u0, double u1, double u2, doub
     p[i] = __builtin_fma(p[i], w2[i], -0.5);
     p[i] = __builtin_fma(p[i], w2[i], 1.0);
   }
-  c0 = ((int)k[0] & 1) ? -p[0] : p[0];
-  c1 = ((int)k[1] & 1) ? -p[1] : p[1];
-  c2 = ((int)k[2] & 1) ? -p[2] : p[2];
+  // (-1)^k: the parity of k goes straight into the sign bit
+  auto flip = [](double v, double kk) __attribute__((always_inline)) {
+    const uint64_t sgn = (uint64_t)((uint32_t)(int)kk << 31) << 32;
+    return __builtin_bit_cast(double, __builtin_bit_cast(uint64_t, v) ^ sgn);
+  };
+  c0 = flip(p[0], k[0]);
+  c1 = flip(p[1], k[1]);
+  c2 = flip(p[2], k[2]);
 }
 
-// exp(x) for |x| <= 700 with the polynomial constants in SGPRs (same reduction and polynomial
-// as exp_any, rjp_device.h)
+// exp(x) for |x| <= 700 with the polynomial constants in SGPRs (same reduction as exp_any,
+// rjp_device.h; shorter polynomial)
 __device__ __forceinline__ double exp_k(double x) {
   const double kd = __builtin_rint(kmul(1.4426950408889634074, x));
   double r = kfma(-6.93147180369123816490e-01, kd, x);
   r = kfma(-1.90821492927058770002e-10, kd, r);
-  double p = kadd(2.755731922398589e-07, kmul(2.505210838544172e-08, r));
-  p = fma_k(p, r, 2.7557319223985893e-06);
-  p = fma_k(p, r, 2.48015873015873e-05);
-  p = fma_k(p, r, 1.984126984126984e-04);
-  p = fma_k(p, r, 1.388888888888889e-03);
-  p = fma_k(p, r, 8.333333333333333e-03);
-  p = fma_k(p, r, 4.1666666666666664e-02);
-  p = fma_k(p, r, 1.6666666666666666e-01);
+  // degree 9, near-minimax on |r| <= ln2/2 with 1, 1, 1/2 kept: relative error 1.2e-13
+  // (tools/minimax_fit.py); only the pole term uses this exp
+  double p = kadd(2.48694657480789912e-05, kmul(2.48136182542816624e-06, r));
+  p = fma_k(p, r, 1.98481138785137922e-04);
+  p = fma_k(p, r, 1.38888369809909941e-03);
+  p = fma_k(p, r, 8.33332808680723944e-03);
+  p = fma_k(p, r, 4.16666667860245560e-02);
+  p = fma_k(p, r, 1.66666666787199630e-01);
   p = __builtin_fma(p, r, 0.5);
   p = __builtin_fma(p, r, 1.0);
   p = __builtin_fma(p, r, 1.0);
