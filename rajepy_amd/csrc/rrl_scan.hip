@@ -527,23 +527,23 @@ __device__ __forceinline__ double voigt_plain_wave(double ax, double y, double q
   const double N03 = __builtin_fma(N01, D23, kmul(w2[4] / w2[0], N23 * D01)), D03 = D01 * D23;
   const double Nall = __builtin_fma(N03, D[4], kmul(w2[8] / w2[0], N[4] * D03)), Dall = D03 * D[4];
   // sum = w2[0] * Nall / Dall; Re w = (h y / pi) * sum
-  double s = Nall * rcp_fast(Dall) * kmul(w2[0] * kH / 3.14159265358979323846, y);
-  if (POLE) {
-    // P = Re[ 2 exp(-z^2) q / (q - exp(-i theta)) ], theta = 2 pi x / h, for every lane (it
-    // is below 1e-11 Re w where x^2 exceeds the per-cell bound cq, and harmless there):
-    // Re[e^{-i phi} conj(q - e^{-i theta})] = q cos(phi) - cos(theta - phi), phi = 2 x y;
-    // |q - e^{-i theta}|^2 = 1 - 2 q cos(theta) + q^2 >= (1 - q)^2 >= 0.07 for y >= 0.03
-    const double e = __builtin_fma(y, y, -x2);                    // <= y^2 < (pi/h)^2 = 27.4
-    const double u = kmul(1.0 / kH, ax);
-    const double fr = u - __builtin_floor(u);                     // theta / 2 pi
-    const double ph = kmul(0.31830988618379067154, ax * y);       // phi / 2 pi
-    double cth, cph, cps;
-    cos_2pi_x3(fr, ph, fr - ph, cth, cph, cps);
-    const double den = __builtin_fma(q, q - 2.0 * cth, 1.0);
-    const double num = __builtin_fma(q, cph, -cps);
-    s = __builtin_fma(2.0 * exp_k(fmax(e, -700.0)) * q, num * rcp_fast(den), s);
-  }
-  return s;
+  const double ky = kmul(w2[0] * kH / 3.14159265358979323846, y);
+  if (!POLE) return Nall * rcp_fast(Dall) * ky;
+  // P = Re[ 2 exp(-z^2) q / (q - exp(-i theta)) ], theta = 2 pi x / h, for every lane (it
+  // is below 1e-11 Re w where x^2 exceeds the per-cell bound cq, and harmless there):
+  // Re[e^{-i phi} conj(q - e^{-i theta})] = q cos(phi) - cos(theta - phi), phi = 2 x y;
+  // |q - e^{-i theta}|^2 = 1 - 2 q cos(theta) + q^2 >= (1 - q)^2 >= 0.07 for y >= 0.03
+  const double e = __builtin_fma(y, y, -x2);      // in (-|x|^2, (pi/h)^2 = 27.4): no clamp
+  const double u = kmul(1.0 / kH, ax);                          // theta / 2 pi (+ whole turns)
+  const double ph = kmul(0.31830988618379067154, ax * y);       // phi / 2 pi
+  double cth, cph, cps;
+  cos_2pi_x3(u, ph, u - ph, cth, cph, cps);
+  const double den = __builtin_fma(q, q - 2.0 * cth, 1.0);
+  const double num = __builtin_fma(q, cph, -cps);
+  // one reciprocal for both fractions: (Nall ky den + 2 E q num Dall) / (Dall den), with
+  // Dall <= (|z|^2 + 30)^20 < 1e40 for the |x| < 16 a wave of this path can hold
+  const double pq = 2.0 * exp_k(e) * q * num;
+  return __builtin_fma(Nall * ky, den, pq * Dall) * rcp_fast(Dall * den);
 }
 
 // Per-(cell, wave) path codes, decided once per cell in phase 1 from the |x| range of the
