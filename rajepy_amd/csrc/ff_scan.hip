@@ -600,12 +600,13 @@ static void uniform_tile(const double* t, int et, const rjp_bursts* hb, UnifDev&
   un.on = 0;
   un.nbt = 0;
   un.dt = 0.0;
+  un.hdt = 0.0;
   un.qext = nullptr;
   un.atab = nullptr;
   if (atab) atab->clear();
   const int next = bursts_overflow(hb);
   for (int j = 0; j < 2; ++j) {
-    for (int i = 0; i < RJP_SGPR_BURSTS; ++i) un.q[j][i] = 1.0;
+    for (int i = 0; i < RJP_SGPR_BURSTS; ++i) { un.q[j][i] = 1.0; un.a1[j][i] = 0.0; }
     for (int i = 0; qext && i < next; ++i) qext[j * next + i] = 1.0;
   }
   static int disabled = -1;
@@ -628,11 +629,14 @@ static void uniform_tile(const double* t, int et, const rjp_bursts* hb, UnifDev&
       const double sigma = std::sqrt(0.5 / inv);
       if (!(half_span <= 28.0 * sigma)) return;   // anchor underflow would hide live epochs
       const double q = std::exp(-2.0 * inv * dt * dt);
-      if (i < RJP_SGPR_BURSTS) un.q[j][i] = q;
-      else qext[j * next + (i - RJP_SGPR_BURSTS)] = q;
+      if (i < RJP_SGPR_BURSTS) {
+        un.q[j][i] = q;
+        un.a1[j][i] = 2.0 * (-inv * RJP_LOG2E) * dt;
+      } else qext[j * next + (i - RJP_SGPR_BURSTS)] = q;
     }
   un.on = 1;
   un.dt = dt;
+  un.hdt = 0.5 * dt;
   un.nbt = std::max(hb->n[0], hb->n[1]);
   if (atab) {
     // step table of the two-operation recurrence: q^(k (k + 1) / 2) = exp(-inv dt^2 k (k + 1));

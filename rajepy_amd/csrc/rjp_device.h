@@ -56,14 +56,15 @@ __device__ __forceinline__ void store_plain(double* __restrict__ p, const double
 // Kernel-argument copy of rjp_bursts.  The first RJP_SGPR_BURSTS bursts of each jet travel by
 // value (they live in SGPRs / the scalar cache: the fast path of every shipped example); a jet
 // with more keeps the rest in a small device table `ext`, read with wave-uniform scalar
-// loads: ext[(jet * 3 + k) * next + (i - RJP_SGPR_BURSTS)], k = 0 t0, 1 amp_rel, 2 inv2s2.
+// loads: ext[(jet * 3 + k) * next + (i - RJP_SGPR_BURSTS)], k = 0 t0, 1 amp_rel, 2 k2.
 // The reference registers any number of bursts (classes.py:245-264, 399-463).
 #define RJP_SGPR_BURSTS 8
+#define RJP_LOG2E 1.4426950408889634074
 struct BurstsDev {
   int n[2];
   double t0[2][RJP_SGPR_BURSTS];
   double amp_rel[2][RJP_SGPR_BURSTS];
-  double inv2s2[2][RJP_SGPR_BURSTS];
+  double k2[2][RJP_SGPR_BURSTS];          // -inv2s2 * log2(e): the Gaussians are evaluated in base 2
   const double* ext;      // overflow bursts (nullptr when every jet has <= RJP_SGPR_BURSTS)
   int next;               // overflow capacity per jet = max(n) - RJP_SGPR_BURSTS, or 0
 };
@@ -88,7 +89,7 @@ static inline void bursts_fill_ext(const rjp_bursts* hb, double* tab) {
       const bool live = src < hb->n[j];
       tab[(j * 3 + 0) * next + i] = live ? hb->t0[j][src] : 0.0;
       tab[(j * 3 + 1) * next + i] = live ? hb->amp_rel[j][src] : 0.0;
-      tab[(j * 3 + 2) * next + i] = live ? hb->inv2s2[j][src] : 0.0;
+      tab[(j * 3 + 2) * next + i] = live ? -hb->inv2s2[j][src] * RJP_LOG2E : 0.0;
     }
 }
 
@@ -104,7 +105,7 @@ static inline bool bursts_to_dev(const rjp_bursts* hb, BurstsDev& b,
       const bool live = hb && i < hb->n[j];
       b.t0[j][i] = live ? hb->t0[j][i] : 0.0;
       b.amp_rel[j][i] = live ? hb->amp_rel[j][i] : 0.0;   // unused slots contribute 0
-      b.inv2s2[j][i] = live ? hb->inv2s2[j][i] : 0.0;
+      b.k2[j][i] = live ? -hb->inv2s2[j][i] * RJP_LOG2E : 0.0;
     }
   }
   b.next = bursts_overflow(hb);
@@ -124,32 +125,66 @@ static inline bool bursts_to_dev(const rjp_bursts* hb, BurstsDev& b,
 #define RJP_EXP_C4 4.16666666661282964e-02
 #define RJP_EXP_C3 1.66666666665949731e-01
 
-// exp(x) for x <= 0, relative error < 1e-14 on [-708, 0] (clamped below: ~1e-308).
-// Cody-Waite reduction + the degree-10 polynomial above, |r| <= ln2/2.  About 18 DP
-// instructions, no denormal/overflow paths (the argument is a Gaussian exponent).
-__device__ __forceinline__ double exp_nonpos(double x) {
-  const double L2E = 1.4426950408889634074;
-  const double LN2_HI = 6.93147180369123816490e-01;
-  const double LN2_LO = 1.90821492927058770002e-10;
-  x = fmax(x, -708.0);
-  double kd = __builtin_rint(x * L2E);
-  double r = __builtin_fma(-kd, LN2_HI, x);
-  r = __builtin_fma(-kd, LN2_LO, r);
-  double p = RJP_EXP_C10;
-  p = __builtin_fma(p, r, RJP_EXP_C9);
-  p = __builtin_fma(p, r, RJP_EXP_C8);
-  p = __builtin_fma(p, r, RJP_EXP_C7);
-  p = __builtin_fma(p, r, RJP_EXP_C6);
-  p = __builtin_fma(p, r, RJP_EXP_C5);
-  p = __builtin_fma(p, r, RJP_EXP_C4);
-  p = __builtin_fma(p, r, RJP_EXP_C3);
-  p = __builtin_fma(p, r, 0.5);
-  p = __builtin_fma(p, r, 1.0);
-  p = __builtin_fma(p, r, 1.0);
-  return __builtin_ldexp(p, (int)kd);
+// 2^f on |f| <= 1/2: degree 10, near-minimax with the constant term kept at 1 (relative error
+// 4e-16 before rounding, tools/minimax_fit.py).  The burst Gaussians exp(-(t - t0)^2 / 2 s^2)
+// are evaluated as 2^(k2 (t - t0)^2) with k2 = -log2(e) / 2 s^2 prepared on the host: no
+// multiplication by log2(e), no Cody-Waite pair -- the fraction f = t - rint(t) is exact.
+#define RJP_EXP2_C10 7.11175884550745750e-09
+#define RJP_EXP2_C9 1.02105064723726014e-07
+#define RJP_EXP2_C8 1.32152356340024657e-06
+#define RJP_EXP2_C7 1.52526477476260911e-05
+#define RJP_EXP2_C6 1.54035308008194563e-04
+#define RJP_EXP2_C5 1.33335582464808402e-03
+#define RJP_EXP2_C4 9.61812910738071326e-03
+#define RJP_EXP2_C3 5.55041086643465811e-02
+#define RJP_EXP2_C2 2.40226506959104719e-01
+#define RJP_EXP2_C1 6.93147180559951614e-01
+
+__device__ __forceinline__ double exp2_poly(double f) {
+  double p = RJP_EXP2_C10;
+  p = __builtin_fma(p, f, RJP_EXP2_C9);
+  p = __builtin_fma(p, f, RJP_EXP2_C8);
+  p = __builtin_fma(p, f, RJP_EXP2_C7);
+  p = __builtin_fma(p, f, RJP_EXP2_C6);
+  p = __builtin_fma(p, f, RJP_EXP2_C5);
+  p = __builtin_fma(p, f, RJP_EXP2_C4);
+  p = __builtin_fma(p, f, RJP_EXP2_C3);
+  p = __builtin_fma(p, f, RJP_EXP2_C2);
+  p = __builtin_fma(p, f, RJP_EXP2_C1);
+  return __builtin_fma(p, f, 1.0);
 }
 
-// exp(x) for |x| <= 700, relative error < 1e-14 (same reduction and polynomial, no clamp)
+// 2^t for t <= 0 (NaN counts as -inf), clamped below at 2^-1021 ~ 4e-308: 15 DP instructions,
+// no denormal/overflow paths.  The relative error is that of t itself (|t| * 1.1e-16 * ln 2)
+// plus 1e-15: below 6e-15 wherever the Gaussian is above 1e-16.
+__device__ __forceinline__ double exp2_nonpos(double t) {
+  t = fmax(t, -1021.0);
+  const double kd = __builtin_rint(t);
+  return __builtin_ldexp(exp2_poly(t - kd), (int)kd);
+}
+
+// 2^t for |t| <= 1000 (no clamp)
+__device__ __forceinline__ double exp2_any(double t) {
+  const double kd = __builtin_rint(t);
+  return __builtin_ldexp(exp2_poly(t - kd), (int)kd);
+}
+
+// 2^t for t <= 0 to float accuracy (rel. err ~1e-7): 2^k by ldexp, 2^f by the hardware
+// v_exp_f32.  Used only with f32 field storage, whose inputs carry a 6e-8 rounding already.
+__device__ __forceinline__ double exp2_nonpos_f32acc(double t) {
+  t = fmax(t, -1021.0);
+  const double kd = __builtin_rint(t);
+  const float e = __builtin_amdgcn_exp2f((float)(t - kd));
+  return __builtin_ldexp((double)e, (int)kd);
+}
+
+template <bool F32ACC>
+__device__ __forceinline__ double exp2_burst(double t) {
+  return F32ACC ? exp2_nonpos_f32acc(t) : exp2_nonpos(t);
+}
+
+// exp(x) for |x| <= 700, relative error < 1e-14: Cody-Waite reduction + the degree-10
+// polynomial of exp(r) above (K3's pole term and the power-law Gaunt factor)
 __device__ __forceinline__ double exp_any(double x) {
   const double L2E = 1.4426950408889634074;
   const double LN2_HI = 6.93147180369123816490e-01;
@@ -171,22 +206,6 @@ __device__ __forceinline__ double exp_any(double x) {
   return __builtin_ldexp(p, (int)kd);
 }
 
-// exp(x) for x <= 0 to float accuracy (rel. err ~1e-7): 2^k by ldexp, 2^f by the hardware
-// v_exp_f32.  9 instructions instead of 22.  Used only with f32 field storage, whose inputs
-// carry a 6e-8 rounding already.
-__device__ __forceinline__ double exp_nonpos_f32acc(double x) {
-  x = fmax(x, -708.0);
-  const double t = x * 1.4426950408889634074;
-  const double kd = __builtin_rint(t);
-  const float e = __builtin_amdgcn_exp2f((float)(t - kd));
-  return __builtin_ldexp((double)e, (int)kd);
-}
-
-template <bool F32ACC>
-__device__ __forceinline__ double exp_burst(double x) {
-  return F32ACC ? exp_nonpos_f32acc(x) : exp_nonpos(x);
-}
-
 // chi for one cell of one jet (wave-uniform loop count; parameters come from SGPRs, those of
 // bursts beyond RJP_SGPR_BURSTS from the overflow table)
 __device__ __forceinline__ double chi_jet(const BurstsDev& b, int jet, double tl) {
@@ -195,14 +214,12 @@ __device__ __forceinline__ double chi_jet(const BurstsDev& b, int jet, double tl
   const int n0 = nb < RJP_SGPR_BURSTS ? nb : RJP_SGPR_BURSTS;
   for (int i = 0; i < n0; ++i) {
     double d = tl - b.t0[jet][i];
-    double arg = -(d * d) * b.inv2s2[jet][i];
-    chi = __builtin_fma(b.amp_rel[jet][i], exp_nonpos(arg), chi);
+    chi = __builtin_fma(b.amp_rel[jet][i], exp2_nonpos((d * d) * b.k2[jet][i]), chi);
   }
   for (int i = RJP_SGPR_BURSTS; i < nb; ++i) {
     const double* e = b.ext + (size_t)(jet * 3) * b.next + (i - RJP_SGPR_BURSTS);
     double d = tl - e[0];
-    double arg = -(d * d) * e[2 * b.next];
-    chi = __builtin_fma(e[b.next], exp_nonpos(arg), chi);
+    chi = __builtin_fma(e[b.next], exp2_nonpos((d * d) * e[2 * b.next]), chi);
   }
   return chi;
 }
@@ -229,14 +246,14 @@ __device__ __forceinline__ void chi_batch(const BurstsDev& b, const bool (&red)[
     const int jet = wave_red ? 0 : 1;
     const int nb = b.n[jet];
     const int n0 = nb < RJP_SGPR_BURSTS ? nb : RJP_SGPR_BURSTS;
-    auto one = [&](double t0, double inv, double amp) __attribute__((always_inline)) {
+    auto one = [&](double t0, double k2, double amp) __attribute__((always_inline)) {
 #pragma unroll
       for (int k = 0; k < NB; ++k) {
         const double d = tl[k] - t0;
-        chi[k] = __builtin_fma(amp, exp_burst<F32ACC>(-(d * d) * inv), chi[k]);
+        chi[k] = __builtin_fma(amp, exp2_burst<F32ACC>((d * d) * k2), chi[k]);
       }
     };
-    for (int i = 0; i < n0; ++i) one(b.t0[jet][i], b.inv2s2[jet][i], b.amp_rel[jet][i]);
+    for (int i = 0; i < n0; ++i) one(b.t0[jet][i], b.k2[jet][i], b.amp_rel[jet][i]);
     for (int i = RJP_SGPR_BURSTS; i < nb; ++i) {
       const double* e = b.ext + (size_t)(jet * 3) * b.next + (i - RJP_SGPR_BURSTS);
       one(e[0], e[2 * b.next], e[b.next]);
@@ -244,19 +261,19 @@ __device__ __forceinline__ void chi_batch(const BurstsDev& b, const bool (&red)[
   } else {
     const int nb = b.n[0] > b.n[1] ? b.n[0] : b.n[1];
     const int n0 = nb < RJP_SGPR_BURSTS ? nb : RJP_SGPR_BURSTS;
-    auto one = [&](double t0r, double invr, double ampr, double t0b, double invb,
+    auto one = [&](double t0r, double k2r, double ampr, double t0b, double k2b,
                    double ampb) __attribute__((always_inline)) {
 #pragma unroll
       for (int k = 0; k < NB; ++k) {
         const double t0 = red[k] ? t0r : t0b;
-        const double inv = red[k] ? invr : invb;
+        const double k2 = red[k] ? k2r : k2b;
         const double amp = red[k] ? ampr : ampb;
         const double d = tl[k] - t0;
-        chi[k] = __builtin_fma(amp, exp_burst<F32ACC>(-(d * d) * inv), chi[k]);
+        chi[k] = __builtin_fma(amp, exp2_burst<F32ACC>((d * d) * k2), chi[k]);
       }
     };
     for (int i = 0; i < n0; ++i)
-      one(b.t0[0][i], b.inv2s2[0][i], b.amp_rel[0][i], b.t0[1][i], b.inv2s2[1][i],
+      one(b.t0[0][i], b.k2[0][i], b.amp_rel[0][i], b.t0[1][i], b.k2[1][i],
           b.amp_rel[1][i]);
     for (int i = RJP_SGPR_BURSTS; i < nb; ++i) {
       const double* r = b.ext + (i - RJP_SGPR_BURSTS);
@@ -268,14 +285,12 @@ __device__ __forceinline__ void chi_batch(const BurstsDev& b, const bool (&red)[
 
 // Uniformly spaced epochs t_e = t_m + (e - m) dt: for one burst the Gaussian exponents of a
 // cell form a quadratic in e, so E_e = exp(arg_e) obeys E_{e+1} = E_e R_e, R_{e+1} = R_e Q
-// with Q = exp(-2 inv dt^2) the same for every cell.  Two exp() per (cell, burst) serve the
-// whole tile instead of one per epoch.  The anchor is the middle epoch m; when its Gaussian
+// with Q = exp(-2 inv dt^2) the same for every cell.  Two exponentials per (cell, burst) serve
+// the whole tile instead of one per epoch.  The anchor is the middle epoch m; when its Gaussian
 // underflows (arg_m < -700) every epoch of the tile is negligible -- the launcher guarantees
 // that by using this path only while the tile's half-span is below 28 sigma of the
-// narrowest burst.
-#ifndef RJP_BURST_PIPELINE
-#define RJP_BURST_PIPELINE 1   /* 0: A/B build without the scalar-load pipelining */
-#endif
+// narrowest burst.  Base 2 throughout: log2 E_m = k2 vm^2, log2(E_{m+1} / E_m) =
+// 2 k2 dt (vm + dt / 2) = a1 (vm + hdt).
 #ifndef RJP_TWO_OP
 #define RJP_TWO_OP 1           /* 0: A/B build with the three-operation recurrence everywhere */
 #endif
@@ -284,8 +299,10 @@ struct UnifDev {
   int on;                                   // 0 = evaluate every epoch directly
   int nbt;                                  // bursts per jet in `atab` (= max(n[0], n[1]))
   double dt;                                // epoch spacing [s]
+  double hdt;                               // dt / 2
   double q[2][RJP_SGPR_BURSTS];             // exp(-2 inv2s2 dt^2)
-  const double* qext;                       // the same for the overflow bursts: qext[jet * next + i]
+  double a1[2][RJP_SGPR_BURSTS];            // 2 k2 dt
+  const double* qext;                       // q of the overflow bursts: qext[jet * next + i]
   // step table of the two-operation recurrence (waves inside one jet):
   // atab[(jet * nbt + i) * RJP_STEP_TAB + k - 1] = q^(k (k + 1) / 2), k = 1 .. 16
   const double* atab;
@@ -297,6 +314,7 @@ __device__ __forceinline__ void chi_batch_uniform(const BurstsDev& b, const Unif
                                                   const double (&tlm)[UV],   // anchor epoch
                                                   double (&chi)[ET * UV]) {
   constexpr int M = ET / 2;
+  constexpr double kDead = -1009.0;         // log2 of the anchor Gaussian below which it is dropped
   bool any_red = false, any_blue = false;
 #pragma unroll
   for (int c = 0; c < UV; ++c) { any_red |= red[c]; any_blue |= !red[c]; }
@@ -311,46 +329,6 @@ __device__ __forceinline__ void chi_batch_uniform(const BurstsDev& b, const Unif
 #pragma unroll
     for (int k = 0; k < ET * UV; ++k) chi[k] = 1.0;
   }
-  // one burst (its parameters for the red and the blue jet) applied to cell c
-  auto apply = [&](int c, double t0r, double invr, double ampr, double qr, double t0b,
-                   double invb, double ampb, double qb) __attribute__((always_inline)) {
-    const bool r = mixed ? red[c] : (jet == 0);
-    const double t0 = r ? t0r : t0b;
-    const double inv = r ? invr : invb;
-    const double amp = r ? ampr : ampb;
-    const double q = r ? qr : qb;
-    const double vm = tlm[c] - t0;
-    const double argm = -(vm * vm) * inv;
-    const bool dead = argm < -700.0;
-    const double em = exp_nonpos(argm);
-    const double idt = inv * un.dt;
-    const double xr = -__builtin_fma(2.0 * idt, vm, idt * un.dt);    // ln(E_{m+1} / E_m)
-    const double rup = exp_any(xr);
-    // E_{m-1} / E_m = q / rup: hardware reciprocal + one Newton step (rup is a finite
-    // normal number whenever the cell is not `dead`)
-    double ir = __builtin_amdgcn_rcp(rup);
-    ir = ir * __builtin_fma(-rup, ir, 2.0);
-    const double rdn = q * ir;
-    const double a = dead ? 0.0 : amp;          // a dead cell adds exactly nothing ...
-    const double em0 = dead ? 0.0 : em;         // ... and must not turn 0 * inf into NaN
-    chi[M * UV + c] = __builtin_fma(a, em0, chi[M * UV + c]);
-    // the chains towards later and earlier epochs advance in the same trip: two independent
-    // dependency chains per burst in program order
-    double eu = em0, ru = dead ? 0.0 : rup, ed = em0, rd = dead ? 0.0 : rdn;
-#pragma unroll
-    for (int j = 1; j <= M; ++j) {
-      if (M + j < ET) {
-        eu *= ru; ru *= q;
-        chi[(M + j) * UV + c] = __builtin_fma(a, eu, chi[(M + j) * UV + c]);
-      }
-      ed *= rd; rd *= q;
-      chi[(M - j) * UV + c] = __builtin_fma(a, ed, chi[(M - j) * UV + c]);
-    }
-  };
-  auto one = [&](int i, int c) __attribute__((always_inline)) {
-    apply(c, b.t0[0][i], b.inv2s2[0][i], b.amp_rel[0][i], un.q[0][i], b.t0[1][i],
-          b.inv2s2[1][i], b.amp_rel[1][i], un.q[1][i]);
-  };
   const int n0 = nb < RJP_SGPR_BURSTS ? nb : RJP_SGPR_BURSTS;
   int i = 0;
 #if RJP_TWO_OP
@@ -362,25 +340,23 @@ __device__ __forceinline__ void chi_batch_uniform(const BurstsDev& b, const Unif
     // Magnitudes: the launcher keeps the half-span below 28 sigma, so rup^{+-j} E_m stays
     // below exp(420) and the table entries above exp(-420).
     typedef double tab8 __attribute__((ext_vector_type(8)));
-    auto apply2 = [&](int c, double t0, double inv, double amp, const double* __restrict__ tab,
-                      bool first) __attribute__((always_inline)) {
+    auto apply2 = [&](int c, double t0, double k2, double amp, double a1,
+                      const double* __restrict__ tab, bool first) __attribute__((always_inline)) {
       double vm = tlm[c] - t0;
       // The step table is requested HERE, one SMEM round trip ahead of its first use: issued
       // by hand because the scheduler otherwise sinks the scalar loads to the recurrence (to
-      // save SGPRs during the exp() chains) and every trip then waits for them.  `vm` passes
-      // through the statement so that the exp() chains stay behind the request.
+      // save SGPRs during the exponentials) and every trip then waits for them.  `vm` passes
+      // through the statement so that the exponentials stay behind the request.
       tab8 ta, tb;
       if (M > 8)
         asm volatile("s_load_dwordx16 %0, %3, 0x0\n\ts_load_dwordx16 %1, %3, 0x40"
                      : "=&s"(ta), "=&s"(tb), "+v"(vm) : "s"(tab));
       else
         asm volatile("s_load_dwordx16 %0, %2, 0x0" : "=&s"(ta), "+v"(vm) : "s"(tab));
-      const double argm = -(vm * vm) * inv;
-      const bool dead = argm < -700.0;
-      const double em = exp_nonpos(argm);
-      const double idt = inv * un.dt;
-      const double xr = -__builtin_fma(2.0 * idt, vm, idt * un.dt);    // ln(E_{m+1} / E_m)
-      const double rup = exp_any(xr);
+      const double tm = (vm * vm) * k2;
+      const bool dead = tm < kDead;
+      const double em = exp2_nonpos(tm);
+      const double rup = exp2_any((vm + un.hdt) * a1);               // E_{m+1} / E_m
       double ir = __builtin_amdgcn_rcp(rup);
       ir = ir * __builtin_fma(-rup, ir, 2.0);
       const double ae = dead ? 0.0 : amp * em;    // a dead cell adds exactly nothing
@@ -402,13 +378,13 @@ __device__ __forceinline__ void chi_batch_uniform(const BurstsDev& b, const Unif
       }
     };
     // the parameters of the NEXT burst are requested before the current one is worked on (a
-    // trip is ~110 FP64 instructions and would otherwise start by waiting for the SMEM round
+    // trip is ~100 FP64 instructions and would otherwise start by waiting for the SMEM round
     // trip); the step table of the current burst is requested at the top of its trip and
-    // first needed after the two exp() chains
-    struct BP { double t0, inv, amp; };
+    // first needed after the two exponentials
+    struct BP { double t0, k2, amp, a1; };
     auto ld = [&](int k) __attribute__((always_inline)) {
       const int kk = k < RJP_SGPR_BURSTS - 1 ? k : RJP_SGPR_BURSTS - 1;   // stay inside the table
-      return BP{b.t0[jet][kk], b.inv2s2[jet][kk], b.amp_rel[jet][kk]};
+      return BP{b.t0[jet][kk], b.k2[jet][kk], b.amp_rel[jet][kk], un.a1[jet][kk]};
     };
     if (nb == 0) return;
     BP cur = ld(0);
@@ -416,54 +392,67 @@ __device__ __forceinline__ void chi_batch_uniform(const BurstsDev& b, const Unif
       const BP nxt = ld(1);
       const double* tab = un.atab + (size_t)(jet * un.nbt) * RJP_STEP_TAB;
 #pragma unroll
-      for (int c = 0; c < UV; ++c) apply2(c, cur.t0, cur.inv, cur.amp, tab, true);
+      for (int c = 0; c < UV; ++c) apply2(c, cur.t0, cur.k2, cur.amp, cur.a1, tab, true);
       cur = nxt;
     }
     for (i = 1; i < n0; ++i) {
       const BP nxt = ld(i + 1);
       const double* tab = un.atab + (size_t)(jet * un.nbt + i) * RJP_STEP_TAB;
 #pragma unroll
-      for (int c = 0; c < UV; ++c) apply2(c, cur.t0, cur.inv, cur.amp, tab, false);
+      for (int c = 0; c < UV; ++c) apply2(c, cur.t0, cur.k2, cur.amp, cur.a1, tab, false);
       cur = nxt;
     }
     for (i = RJP_SGPR_BURSTS; i < nb; ++i) {
       const double* tab = un.atab + (size_t)(jet * un.nbt + i) * RJP_STEP_TAB;
       const double* e = b.ext + (size_t)(jet * 3) * b.next + (i - RJP_SGPR_BURSTS);
+      const double k2 = e[2 * b.next];
 #pragma unroll
-      for (int c = 0; c < UV; ++c) apply2(c, e[0], e[2 * b.next], e[b.next], tab, false);
+      for (int c = 0; c < UV; ++c) apply2(c, e[0], k2, e[b.next], 2.0 * k2 * un.dt, tab, false);
     }
     return;
   }
 #endif
-  if (ET >= 16 && !mixed && RJP_BURST_PIPELINE) {
-    // Wave inside one jet (the usual case): the burst parameters are scalar loads from the
-    // kernel-argument segment, and a trip of ~400 FP64 instructions used to start by waiting
-    // for them (SMEM round trip, two or three times per row).  Here the parameters of the
-    // NEXT two bursts are requested before the current pair is worked on.
-    struct BP { double t0, inv, amp, q; };
-    auto ld = [&](int k) __attribute__((always_inline)) {
-      const int kk = k < RJP_SGPR_BURSTS - 1 ? k : RJP_SGPR_BURSTS - 1;   // stay inside the table
-      return BP{b.t0[jet][kk], b.inv2s2[jet][kk], b.amp_rel[jet][kk], un.q[jet][kk]};
-    };
-    BP a0 = ld(0), a1 = ld(1);
-    for (; i < n0; i += 2) {
-      const BP p0 = ld(i + 2), p1 = ld(i + 3);
-      if (i + 1 < n0) {
-        // two bursts per trip: their exp chains are independent and interleave
+  // Waves that straddle the red/blue plane (and the RJP_TWO_OP = 0 build): one burst, its
+  // parameters for the red and the blue jet selected per lane, three operations per step
+  auto apply = [&](int c, double t0r, double k2r, double ampr, double qr, double a1r, double t0b,
+                   double k2b, double ampb, double qb, double a1b) __attribute__((always_inline)) {
+    const bool r = mixed ? red[c] : (jet == 0);
+    const double t0 = r ? t0r : t0b;
+    const double k2 = r ? k2r : k2b;
+    const double amp = r ? ampr : ampb;
+    const double q = r ? qr : qb;
+    const double a1 = r ? a1r : a1b;
+    const double vm = tlm[c] - t0;
+    const double tm = (vm * vm) * k2;
+    const bool dead = tm < kDead;
+    const double em = exp2_nonpos(tm);
+    const double rup = exp2_any((vm + un.hdt) * a1);                 // E_{m+1} / E_m
+    // E_{m-1} / E_m = q / rup: hardware reciprocal + one Newton step (rup is a finite
+    // normal number whenever the cell is not `dead`)
+    double ir = __builtin_amdgcn_rcp(rup);
+    ir = ir * __builtin_fma(-rup, ir, 2.0);
+    const double rdn = q * ir;
+    const double a = dead ? 0.0 : amp;          // a dead cell adds exactly nothing ...
+    const double em0 = dead ? 0.0 : em;         // ... and must not turn 0 * inf into NaN
+    chi[M * UV + c] = __builtin_fma(a, em0, chi[M * UV + c]);
+    // the chains towards later and earlier epochs advance in the same trip: two independent
+    // dependency chains per burst in program order
+    double eu = em0, ru = dead ? 0.0 : rup, ed = em0, rd = dead ? 0.0 : rdn;
 #pragma unroll
-        for (int c = 0; c < UV; ++c) {
-          apply(c, a0.t0, a0.inv, a0.amp, a0.q, a0.t0, a0.inv, a0.amp, a0.q);
-          apply(c, a1.t0, a1.inv, a1.amp, a1.q, a1.t0, a1.inv, a1.amp, a1.q);
-        }
-      } else {
-#pragma unroll
-        for (int c = 0; c < UV; ++c)
-          apply(c, a0.t0, a0.inv, a0.amp, a0.q, a0.t0, a0.inv, a0.amp, a0.q);
+    for (int j = 1; j <= M; ++j) {
+      if (M + j < ET) {
+        eu *= ru; ru *= q;
+        chi[(M + j) * UV + c] = __builtin_fma(a, eu, chi[(M + j) * UV + c]);
       }
-      a0 = p0; a1 = p1;
+      ed *= rd; rd *= q;
+      chi[(M - j) * UV + c] = __builtin_fma(a, ed, chi[(M - j) * UV + c]);
     }
-  }
-  // two bursts per trip: their exp chains are independent and interleave
+  };
+  auto one = [&](int k, int c) __attribute__((always_inline)) {
+    apply(c, b.t0[0][k], b.k2[0][k], b.amp_rel[0][k], un.q[0][k], un.a1[0][k], b.t0[1][k],
+          b.k2[1][k], b.amp_rel[1][k], un.q[1][k], un.a1[1][k]);
+  };
+  // two bursts per trip: their exponential chains are independent and interleave
   for (; i + 1 < n0; i += 2) {
 #pragma unroll
     for (int c = 0; c < UV; ++c) { one(i, c); one(i + 1, c); }
@@ -477,9 +466,11 @@ __device__ __forceinline__ void chi_batch_uniform(const BurstsDev& b, const Unif
     const double* r = b.ext + k;
     const double* u = r + (size_t)3 * b.next;
     const double qr = un.qext[k], qb = un.qext[b.next + k];
+    const double k2r = r[2 * b.next], k2b = u[2 * b.next];
 #pragma unroll
     for (int c = 0; c < UV; ++c)
-      apply(c, r[0], r[2 * b.next], r[b.next], qr, u[0], u[2 * b.next], u[b.next], qb);
+      apply(c, r[0], k2r, r[b.next], qr, 2.0 * k2r * un.dt, u[0], k2b, u[b.next], qb,
+            2.0 * k2b * un.dt);
   }
 }
 

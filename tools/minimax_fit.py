@@ -6,6 +6,7 @@ that the leading coefficients stay the inline constants 1, 1, 1/2 (VOP3 takes no
 every other coefficient costs an SGPR pair).
 
   exp(r)  = 1 + r + r^2/2 + r^3 g(r),      |r| <= ln2/2      (exp_nonpos / exp_any / exp_k)
+  2^f     = 1 + f g(f),                    |f| <= 1/2        (exp2_nonpos / exp2_any)
   cos(w)  = 1 - s/2 + s^2 g(s), s = w^2,   |w| <= pi/2       (cos_2pi_x3)
 
 Prints the coefficients (highest power first, as the Horner chains use them) and the maximum
@@ -76,6 +77,19 @@ def fit_exp(deg):
     return full, float(np.max(np.abs(got / ref - 1.0)))
 
 
+def fit_exp2(deg):
+    """2^f = 1 + f (c1 + c2 f + ...), |f| <= 1/2 (the Gaussians of the burst factor are
+    evaluated in base 2: their exponent constants carry the log2(e))."""
+    a = 0.5 * 1.0000001
+    h = lambda f: mp.mpf(2) ** f - 1
+    c = remez(h, lambda j, f: f ** (j + 1), deg, -a, a, lambda f: mp.mpf(2) ** (-f))
+    full = c[::-1] + [1.0]
+    x = np.linspace(-a, a, 200001)[::50]
+    ref = np.array([float(mp.mpf(2) ** mp.mpf(float(v))) for v in x])
+    got = horner(full, x)
+    return full, float(np.max(np.abs(got / ref - 1.0)))
+
+
 def fit_cos(terms):
     """`terms` coefficients of g(s) -> polynomial in w of degree 2 * (terms + 1)."""
     smax = float((mp.pi / 2) ** 2) * 1.0000001
@@ -92,6 +106,10 @@ if __name__ == "__main__":
     for deg in (8, 9, 10):
         c, e = fit_exp(deg)
         print("exp degree %d: max rel err %.2e" % (deg, e))
+        print("   ", ", ".join("%.17e" % v for v in c))
+    for deg in (9, 10, 11):
+        c, e = fit_exp2(deg)
+        print("exp2 degree %d: max rel err %.2e" % (deg, e))
         print("   ", ", ".join("%.17e" % v for v in c))
     for terms in (5, 6, 7):
         c, e = fit_cos(terms)
