@@ -319,6 +319,132 @@ __global__ __launch_bounds__(kBlock) void ff_scan_kernel(
   }
 }
 
+// ---- epoch tiles of >= 16 epochs with the rows prefetched by LDS-DMA ------------------------
+// These tiles are ALU-bound with ~1700 cycles of FP64 work per row and wave and 2-3 waves per
+// SIMD; with ordinary loads a wave asks for a row and waits for it (all its registers hold
+// accumulators and burst factors, none is free to hold a row in flight), so a SIMD idles
+// whenever its waves wait together (VALU issue 75 %).  Here each wave keeps the NEXT two rows
+// of its 64 sightlines in flight as `global_load_lds_dwordx4` requests -- no register
+// destination -- into its own double-buffered slice of LDS, and reads the current rows back
+// with ds_read_b64 (conflict-free, consecutive lanes).  One request moves 1 KiB = two rows of
+// one field: lanes 0-31 fetch the 64 sightlines of row y as 16-byte pairs, lanes 32-63 those
+// of row y + 1; the LDS image is wave-base + 16 * lane.  No barrier anywhere: a wave reads
+// only what it requested itself, behind its own counted s_waitcnt vmcnt.
+// Needs f64 fields, an even n_z and 16-byte aligned field pointers (what 2-wide lanes need).
+template <bool CMP> struct TileDma { static constexpr int NF = CMP ? 3 : 5; };
+
+__device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
+               "global_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+
+template <int ET, int MODE, bool CMP, bool EM>
+__global__ __launch_bounds__(kBlock) void ff_scan_tile_kernel(
+    FieldPtrs<double> f, int ny, int nz, int64_t npix, int ylen, int nsplit, BurstsDev b,
+    EpochTile<ET> ep, double* __restrict__ ws) {
+  constexpr int NF = TileDma<CMP>::NF;
+  constexpr int kWaves = kBlock / RJP_WAVE;
+  // [wave][buffer][field][row 0: 64 sightlines | row 1: 64 sightlines]
+  __shared__ double s_rows[kWaves][2][NF][2 * RJP_WAVE];
+  __shared__ int s_lo, s_hi;
+  const int split = (int)(blockIdx.x % (unsigned)nsplit);
+  const int64_t p0 = (int64_t)(blockIdx.x / (unsigned)nsplit) * kBlock + threadIdx.x;
+  const bool lane_live = p0 < npix;
+  int y0 = split * ylen;
+  int y1 = min(ny, y0 + ylen);
+  if (f.ylo) {
+    if (threadIdx.x == 0) { s_lo = ny; s_hi = 0; }
+    __syncthreads();
+    if (lane_live) {
+      const int lo = f.ylo[p0], hi = f.yhi[p0];
+      if (lo < hi) { atomicMin(&s_lo, lo); atomicMax(&s_hi, hi); }
+    }
+    __syncthreads();
+    y0 = max(y0, s_lo);
+    y1 = min(y1, s_hi);
+  }
+
+  double accA[ET][1], accE[EM ? ET : 1][1], accT[1];
+  int cnt[1];
+  accT[0] = 0.0; cnt[0] = 0;
+#pragma unroll
+  for (int e = 0; e < ET; ++e) { accA[e][0] = 0.0; if (EM) accE[e][0] = 0.0; }
+
+  const int lane = threadIdx.x & (RJP_WAVE - 1);
+  const int wave = threadIdx.x / RJP_WAVE;
+  // the pair of sightlines this lane fetches (clamped into the map: the last workgroup)
+  const int64_t pw = p0 - lane;                                   // the wave's first sightline
+  const int64_t pd = min(pw + 2 * (lane & 31), npix - 2);
+  const int64_t xd = pd / nz;
+  const int zd = (int)(pd - xd * nz);
+  const int half = lane >> 5;                                     // which of the two rows
+  const int64_t col = xd * ny * (int64_t)nz + zd;                 // + row * nz
+  const double* src[NF];
+  if (CMP) { src[0] = f.em0; src[1] = f.temp; src[2] = f.ts; }
+  else { src[0] = f.nd; src[1] = f.xi; src[2] = f.temp; src[3] = f.pf; src[4] = f.ts; }
+  typedef __attribute__((address_space(3))) double lds_double;
+  const unsigned lds0 = (unsigned)(uintptr_t)(lds_double*)&s_rows[wave][0][0][0];
+  const unsigned lds0u = __builtin_amdgcn_readfirstlane(lds0);
+  auto request = [&](int y, int buf) __attribute__((always_inline)) {
+    const int row = min(y + half, y1 - 1);                         // an odd tail re-reads a row
+    const int64_t o = col + (int64_t)row * nz;
+#pragma unroll
+    for (int k = 0; k < NF; ++k)
+      glds16(src[k] + o, lds0u + (unsigned)((buf * NF + k) * 2 * RJP_WAVE * sizeof(double)));
+  };
+  auto one_row = [&](int buf, int r) __attribute__((always_inline)) {
+    RowBatch<1, 1> rb;
+    const double* q = &s_rows[wave][buf][0][r * RJP_WAVE + lane];
+    if (CMP) {
+      const double g = q[0];
+      rb.tp[0][0] = q[2 * RJP_WAVE];
+      rb.ts[0][0] = q[4 * RJP_WAVE];
+      rb.rj[0][0] = signbit_d(g);
+      rb.g0[0][0] = fabs(g);
+    } else {
+      const double nd = q[0], xi = q[2 * RJP_WAVE], pf = q[6 * RJP_WAVE];
+      rb.tp[0][0] = q[4 * RJP_WAVE];
+      rb.ts[0][0] = q[8 * RJP_WAVE];
+      const double n0 = fabs(nd) * xi;
+      rb.g0[0][0] = n0 * n0 * pf;
+      rb.rj[0][0] = signbit_d(nd);
+    }
+    compute_rows<double, 1, ET, MODE, true, true, CMP, EM, 1>(rb, b, ep, accA, accE, accT, cnt);
+  };
+
+  if (y0 < y1) {
+    request(y0, 0);
+    int buf = 0;
+    for (int y = y0; y < y1; y += 2) {
+      if (y + 2 < y1) {
+        request(y + 2, buf ^ 1);
+        // all but the NF requests just issued have landed
+        if (NF == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      // (one copy of the row's code: the loop over the two rows is not unrolled)
+#pragma unroll 1
+      for (int r = 0; r < 2; ++r)
+        if (y + r < y1) one_row(buf, r);
+      buf ^= 1;
+    }
+  }
+
+  if (!lane_live) return;
+  double* w = ws + (int64_t)split * nacc(ET) * npix + p0;
+#pragma unroll
+  for (int e = 0; e < ET; ++e) {
+    w[(int64_t)e * npix] = accA[e][0];
+    if (EM) w[(int64_t)(ET + e) * npix] = accE[e][0];
+  }
+  w[(int64_t)(2 * ET) * npix] = accT[0];
+  w[(int64_t)(2 * ET + 1) * npix] = (double)cnt[0];
+}
+
 // Fixed-order reduction over the y-splits; writes the base maps of epochs [e0, e0+et).
 __global__ __launch_bounds__(kBlock) void ff_reduce_kernel(
     const double* __restrict__ ws, int nsplit, int et, int64_t npix, int e0, double em_scale,
@@ -650,6 +776,17 @@ static void uniform_tile(const double* t, int et, const rjp_bursts* hb, UnifDev&
   }
 }
 
+// LDS-DMA row prefetch of the long tiles: 16-byte pairs of f64 cells
+static bool tile_dma_ok(const rjp_fields* fl) {
+  static int off = -1;
+  if (off < 0) off = debug_env("RJP_NO_TILE_DMA") ? 1 : 0;
+  if (off || fl->dtype != RJP_F64 || (fl->nz % 2) != 0) return false;
+  const void* ptrs[6] = {fl->d_nd, fl->d_xi, fl->d_temp, fl->d_pf, fl->d_ts, fl->d_em0};
+  for (const void* q : ptrs)
+    if (q && ((uintptr_t)q % 16) != 0) return false;
+  return (int64_t)fl->nx * fl->nz >= 2;
+}
+
 template <typename T, int VEC, int ET, int MODE, bool BURSTS, bool CMP>
 static hipError_t launch_tile(const rjp_fields* fl, const BurstsDev& b, const double* t,
                               const UnifDev& un, int nsplit, int ylen, double* ws, bool want_em,
@@ -666,6 +803,25 @@ static hipError_t launch_tile(const rjp_fields* fl, const BurstsDev& b, const do
   dim3 grid((unsigned)(((nchunks + kBlock - 1) / kBlock) * nsplit), 1u);
   // the recurrence pays with at least 4 epochs per tile; short tiles of f32 storage keep
   // their 9-instruction float-accuracy exp instead
+  if constexpr (sizeof(T) == 8 && VEC == 1 && BURSTS && ET >= 16) {
+    // (one instantiation is slower with the DMA loop: the power-law Gaunt branch on the compact
+    // layout without EM maps needs 197 instead of 168 VGPRs there, 2 waves instead of 3:
+    // 21.6 against 21.0 ms, profiles/r02d_tile_dma_ab.log)
+    constexpr bool kDmaLoses = MODE == RJP_GFF_POWERLAW && CMP && ET == 32;
+    if (ep.un.on && tile_dma_ok(fl) && !(kDmaLoses && !want_em)) {
+      FieldPtrs<double> fd{(const double*)fl->d_nd, (const double*)fl->d_xi,
+                           (const double*)fl->d_temp, (const double*)fl->d_pf,
+                           (const double*)fl->d_ts, fl->d_ylo, fl->d_yhi,
+                           (const double*)fl->d_em0};
+      if (want_em)
+        hipLaunchKernelGGL((ff_scan_tile_kernel<ET, MODE, CMP, true>), grid, dim3(kBlock), 0, st,
+                           fd, fl->ny, fl->nz, npix, ylen, nsplit, b, ep, ws);
+      else
+        hipLaunchKernelGGL((ff_scan_tile_kernel<ET, MODE, CMP, false>), grid, dim3(kBlock), 0, st,
+                           fd, fl->ny, fl->nz, npix, ylen, nsplit, b, ep, ws);
+      return hipGetLastError();
+    }
+  }
   if constexpr (ET == 32) {
     // 32 epochs per pass: recurrence only
     if (ep.un.on) {
