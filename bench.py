@@ -593,9 +593,9 @@ def main(argv=None):
         want_em = wl.em is not None
         k_ms = eng.time_ff_scan(fields, wl.bursts, wl.my_epochs, wl.gmode, reps=5,
                                 want_em=want_em)
-        # epoch tiles share a pass over the grid: 32 uniformly spaced epochs when no EM maps
-        # are asked for, 16 with them, else 8 (f64 lanes) or 4 (f32 lanes)
-        tile = (32 if (E_loc >= 32 and not want_em) else 16 if E_loc >= 16 else
+        # epoch tiles share a pass over the grid: 32 uniformly spaced epochs, 16 below that,
+        # else 8 (f64 lanes) or 4 (f32 lanes)
+        tile = (32 if E_loc >= 32 else 16 if E_loc >= 16 else
                 (8 if args.storage == "f64" else 4))
         npass = -(-E_loc // tile) if E_loc > 1 else 1
         # fields K1 streams per cell: em0, temp, ts in the compact layout (DESIGN.md "Data
@@ -605,7 +605,12 @@ def main(argv=None):
         alg_bytes = npass * nfld * ncell_loc * dsz + base_maps
         # SURVEY 8(d)'s byte model: 5 fields per cell (per grid pass of this launch)
         alg_8d = npass * 5 * ncell_loc * dsz + base_maps
-        kname = "ff_scan_kernel"
+        # tiles of >= 16 epochs on f64 fields run the LDS-DMA variant of the scan (one
+        # instantiation excepted, ff_scan.hip launch_tile)
+        dma = (E_loc >= 16 and args.storage == "f64" and fields.shape[2] % 2 == 0 and
+               not (args.gaunt == "powerlaw" and fields.em0 is not None and tile == 32
+                    and not want_em))
+        kname = "ff_scan_tile_kernel" if dma else "ff_scan_kernel"
         roof_extra = {"grid_passes_per_launch": npass, "fields_streamed_per_cell": nfld,
                       "epochs_per_launch": E_loc}
         if n_ep_cfg:
