@@ -1118,6 +1118,13 @@ class Pipeline:
             raise RuntimeError("Pipeline run #%d failed%s: %s: %s (state saved; completed "
                                "runs are skipped on resume)" % (f[0] + 1, where, f[1], f[2]))
 
+    def radio_plot(self, run, percentile=5., savefig=False):
+        """The reference draws flux / optical depth / emission measure panels with matplotlib
+        (`classes.py:3015-3183`); plotting is outside this package: the
+        FITS products of `run` hold the same maps."""
+        raise NotImplementedError("rajepy_amd produces no plots; read the run's FITS products "
+                                  "(run.products) instead")
+
     def _radiative_transfer(self, idx, run, clobber):
         m = self.model
         self.log.add_entry("INFO", "Conducting radiative transfer at "
