@@ -644,7 +644,7 @@ def main(argv=None):
             roof_extra["frac_8d"] = alg_8d / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
     achieved = alg_bytes / (k_ms * 1e-3) / 1e9
     traffic, traffic_source = None, None
-    for rnd in ("r02", "r01"):
+    for rnd in ("r02e", "r02", "r01"):
         rel = os.path.join("profiles", "%s_%s_%s_pmc.json" % (rnd, args.config, args.storage))
         if nfld_is_wide(roof_extra):
             rel = rel.replace("_pmc.json", "_wide5_pmc.json")
