@@ -314,3 +314,63 @@ def test_pipeline_execute_on_two_ranks_sharing_the_gpu(tmp_path):
     ret = mp.Manager().dict()
     mp.spawn(_pipeline_worker, args=(2, _free_port(), dcy, ret), nprocs=2, join=True)
     assert ret[0] is True and ret[1] is True, dict(ret)
+
+
+@pytest.mark.parametrize("n_ep,want_em", [(32, False), (32, True), (16, True), (41, False)])
+@pytest.mark.parametrize("compact", [True, False])
+def test_lds_dma_tile_kernel_equals_the_register_path_bit_for_bit(eng, n_ep, want_em, compact):
+    """Tiles of >= 16 uniformly spaced epochs prefetch their rows by LDS-DMA when the f64
+    fields are 16-byte aligned and n_z is even (ff_scan_tile_kernel); fields that start 8
+    bytes off take the register-load kernel.  Same arithmetic in the same order: the maps
+    must be IDENTICAL -- odd row counts (a half-used last request), a partial last workgroup,
+    NaN cells, occupied y-ranges attached, both field layouts."""
+    import torch
+    from rajepy_amd import engine as E
+    shape = (5, 45, 38)                       # 190 sightlines: one partial workgroup
+    jet, p = _jet(shape, 20240521, 0, 0., U.example_bursts_params())
+    g = U.synth_host(shape, 20240521, 0)
+    rng = np.random.default_rng(5)
+    g["nd"].ravel()[rng.random(g["nd"].size) < 0.2] = np.nan
+    g["nd"][:, :7, :] = np.nan                 # empty leading rows: y-ranges clip them
+    fields = eng.upload_fields(g["nd"], g["xi"], g["temp"], g["ff"], g["areas"], g["ts"],
+                               g["rr"] < 0, csize_au=jet.csize, dtype=8)
+    eng.compute_y_bounds(fields)
+    if not compact:
+        fields.em0 = None
+    assert all(t is None or t.data_ptr() % 16 == 0
+               for t in (fields.nd, fields.xi, fields.temp, fields.pf, fields.ts, fields.em0))
+
+    def shifted(t):
+        if t is None:
+            return None
+        buf = torch.empty(t.numel() + 3, dtype=t.dtype, device=t.device)
+        k = 1 if buf.data_ptr() % 16 == 0 else 2          # start 8 bytes off a 16-byte line
+        v = buf[k:k + t.numel()]
+        v.copy_(t.reshape(-1))
+        assert v.data_ptr() % 16 == 8
+        return v
+
+    off = E.DeviceFields(shape, 8, fields.csize_au, shifted(fields.nd), shifted(fields.xi),
+                         shifted(fields.temp), shifted(fields.pf), shifted(fields.ts))
+    off.em0 = shifted(fields.em0)
+    off.ylo, off.yhi = fields.ylo, fields.yhi
+    bursts = U.bursts_from_oracle(jet)
+    ep = [float(y) * YEAR for y in np.linspace(0., 4., n_ep)]
+    a1, e1, t1 = (x.clone() if x is not None else None
+                  for x in eng.ff_scan(fields, bursts, ep, E.RJP_GFF_SCALAR, want_em=want_em))
+    a0, e0, t0 = eng.ff_scan(off, bursts, ep, E.RJP_GFF_SCALAR, want_em=want_em)
+    eng.synchronize()
+    assert np.array_equal(a1.cpu().numpy(), a0.cpu().numpy())
+    assert np.array_equal(t1.cpu().numpy(), t0.cpu().numpy(), equal_nan=True)
+    if want_em:
+        assert np.array_equal(e1.cpu().numpy(), e0.cpu().numpy())
+    # and both follow the oracle
+    ctau, _ = E.ff_channel_coeffs([5e9], jet.csize, p["target"]["dist"], E.RJP_GFF_SCALAR,
+                                  [orc.gff(5e9, p["properties"]["T_0"])])
+    jet2 = orc.OracleJet.from_fields(p, g["nd"], g["xi"], g["temp"], g["ff"], g["areas"],
+                                     g["ts"], g["rr"], g["vy"])
+    got = a1.cpu().numpy().reshape(n_ep, shape[0], shape[2]) * ctau[0]
+    with np.errstate(all="ignore"):
+        for e in (0, n_ep // 2, n_ep - 1):
+            jet2.time = ep[e]
+            np.testing.assert_allclose(got[e], jet2.optical_depth_ff(5e9), rtol=1e-11)
