@@ -674,12 +674,10 @@ static const char* debug_env(const char* name) {
 }
 
 static int forced_ysplit() {
-  static int forced = -1;
-  if (forced < 0) {
-    const char* s = debug_env("RJP_YSPLIT");
-    forced = s ? atoi(s) : 0;
-  }
-  return forced;
+  // (read on every call: a probe may change it between scans of one process, so that the
+  // same allocation of the fields is timed under every setting)
+  const char* s = debug_env("RJP_YSPLIT");
+  return s ? atoi(s) : 0;
 }
 
 static int choose_ysplit(int64_t nchunks, int ny, int et = 1, int64_t npix = 0) {
