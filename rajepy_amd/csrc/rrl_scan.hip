@@ -98,8 +98,21 @@ __device__ __forceinline__ double fma_k(double a, double b, double K);
 __device__ __forceinline__ double kfma(double K, double b, double c);
 __device__ __forceinline__ double kadd(double K, double b);
 __device__ __forceinline__ double kmul(double K, double b);
-__device__ __forceinline__ void cos_2pi_x3(double u0, double u1, double u2, double& c0,
-                                           double& c1, double& c2) {
+// The top coefficients of the pole term's two polynomials, held in VGPRs for the whole kernel
+// (set once through an asm statement, so the compiler can neither fold nor rematerialise
+// them): with one operand in a VGPR the first Horner step is ONE FMA with the next
+// coefficient as its SGPR operand, instead of a multiply and an add (a VOP3 instruction
+// reads at most one SGPR pair).  Four instructions per pole-term evaluation for 4 VGPRs.
+struct PoleTop { double cos_top, exp_top; };
+__device__ __forceinline__ PoleTop pole_top() {
+  PoleTop t;
+  asm volatile("v_mov_b64 %0, %1" : "=v"(t.cos_top) : "s"(-1.10650535275172774e-11));
+  asm volatile("v_mov_b64 %0, %1" : "=v"(t.exp_top) : "s"(2.48136182542816624e-06));
+  return t;
+}
+
+__device__ __forceinline__ void cos_2pi_x3(double u0, double u1, double u2, double top,
+                                           double& c0, double& c1, double& c2) {
   const double u[3] = {u0, u1, u2};
   double k[3], w2[3], p[3];
 #pragma unroll
@@ -115,7 +128,7 @@ __device__ __forceinline__ void cos_2pi_x3(double u0, double u1, double u2, doub
                             2.48015855574161217e-05, -1.38888888828295133e-03,
                             4.16666666666052621e-02};
 #pragma unroll
-  for (int i = 0; i < 3; ++i) p[i] = kadd(cf[0], kmul(-1.10650535275172774e-11, w2[i]));
+  for (int i = 0; i < 3; ++i) p[i] = fma_k(top, w2[i], cf[0]);
 #pragma unroll
   for (int j = 1; j < 5; ++j)
 #pragma unroll
@@ -137,13 +150,13 @@ __device__ __forceinline__ void cos_2pi_x3(double u0, double u1, double u2, doub
 
 // exp(x) for |x| <= 700 with the polynomial constants in SGPRs (same reduction as exp_any,
 // rjp_device.h; shorter polynomial)
-__device__ __forceinline__ double exp_k(double x) {
+__device__ __forceinline__ double exp_k(double x, double top) {
   const double kd = __builtin_rint(kmul(1.4426950408889634074, x));
   double r = kfma(-6.93147180369123816490e-01, kd, x);
   r = kfma(-1.90821492927058770002e-10, kd, r);
   // degree 9, near-minimax on |r| <= ln2/2 with 1, 1, 1/2 kept: relative error 1.2e-13
   // (tools/minimax_fit.py); only the pole term uses this exp
-  double p = kadd(2.48694657480789912e-05, kmul(2.48136182542816624e-06, r));
+  double p = fma_k(top, r, 2.48694657480789912e-05);
   p = fma_k(p, r, 1.98481138785137922e-04);
   p = fma_k(p, r, 1.38888369809909941e-03);
   p = fma_k(p, r, 8.33332808680723944e-03);
@@ -496,7 +509,8 @@ __device__ __forceinline__ double voigt_far_series(double ax, double y) {
 // of the generic path does: relative error < 1e-11 against wofz for 0.03 <= y <= 1e3,
 // 0 <= x <= 1e4, pole term included.
 template <bool POLE>
-__device__ __forceinline__ double voigt_plain_wave(double ax, double y, double q) {
+__device__ __forceinline__ double voigt_plain_wave(double ax, double y, double q,
+                                                   const PoleTop& top) {
   constexpr double tau[kNPair] = {0.0, 0.36, 1.44, 3.2399999999999993, 5.76, 9.0,
                                   12.959999999999997, 17.64, 23.04, 29.159999999999993};
   // w2[n] = 2 exp(-tau[n]) (w2[0] = 1): ratios w2[b]/w2[a] of the pairs (0,1) (2,3) ... and
@@ -537,12 +551,12 @@ __device__ __forceinline__ double voigt_plain_wave(double ax, double y, double q
   const double u = kmul(1.0 / kH, ax);                          // theta / 2 pi (+ whole turns)
   const double ph = kmul(0.31830988618379067154, ax * y);       // phi / 2 pi
   double cth, cph, cps;
-  cos_2pi_x3(u, ph, u - ph, cth, cph, cps);
+  cos_2pi_x3(u, ph, u - ph, top.cos_top, cth, cph, cps);
   const double den = __builtin_fma(q, q - 2.0 * cth, 1.0);
   const double num = __builtin_fma(q, cph, -cps);
   // one reciprocal for both fractions: (Nall ky den + 2 E q num Dall) / (Dall den), with
   // Dall <= (|z|^2 + 30)^20 < 1e40 for the |x| < 16 a wave of this path can hold
-  const double pq = 2.0 * exp_k(e) * q * num;
+  const double pq = 2.0 * exp_k(e, top.exp_top) * q * num;
   return __builtin_fma(Nall * ky, den, pq * Dall) * rcp_fast(Dall * den);
 }
 
@@ -779,6 +793,7 @@ __global__ __launch_bounds__(kRB, RJP_K3_WAVES) void rrl_scan_kernel(
     __syncthreads();
   }
 
+  const PoleTop ptop = pole_top();
   const int cy = tid / ZT, cz = tid % ZT;       // this thread's cell in the slab (phase 1)
 
   int ya = 0, ye = ny;
@@ -854,8 +869,8 @@ __global__ __launch_bounds__(kRB, RJP_K3_WAVES) void rrl_scan_kernel(
           double V;
           if (path == kPathFar8) V = voigt_far_series<8>(ax, yv);
           else if (path == kPathFar5) V = voigt_far_series<5>(ax, yv);
-          else if (path == kPathPlain) V = voigt_plain_wave<false>(ax, yv, 0.0);
-          else if (path == kPathPlainPole) V = voigt_plain_wave<true>(ax, yv, s_q[ci]);
+          else if (path == kPathPlain) V = voigt_plain_wave<false>(ax, yv, 0.0, ptop);
+          else if (path == kPathPlainPole) V = voigt_plain_wave<true>(ax, yv, s_q[ci], ptop);
           else V = voigt_centred(ax, yv, s_q[ci], s_cq[ci], s_tab[tid / RJP_WAVE]);
           // 1 - exp(-h nu / kT) = 1 - E0 * exp(-a (nu - nu_ref))
           const double eps = s_a[ci] * dnu;
