@@ -238,15 +238,39 @@ __global__ __launch_bounds__(kFB) void build_fields_kernel(GeomDev g, T* nd, T* 
   const double x0 = g.cs * (g.ix0 + ix - g.nx_total / 2), y0 = g.cs * (iy - g.ny / 2),
                z0 = g.cs * (iz - g.nz / 2);
 
+  // centroid coordinates (classes.py:521-525)
+  const double h = g.cs / 2.0;
+  double rr, ww, xa, ya;
+  xyz_to_rw(g, x0 + h, y0 + h, z0 + h, rr, ww, xa, ya);
+  const double ar_ = fabs(rr);
+
+  // Most cells of a jet model lie far outside the jet (99.6 % of the example's grid), and the
+  // vertex test below costs eight pow().  The rotation preserves lengths, so every vertex has
+  // |r| <= |r_c| + d and w >= w_c - d with d = half the cell diagonal; for eps >= 0 and
+  // mod_r_0 > 0 the jet width w_0 rho(r)^eps does not decrease with |r|, so a cell whose
+  // centroid is further out than the width at |r_c| + d (or wholly inside |r| < r_0) has no
+  // vertex inside -- decided with one pow() and a 1e-9 margin that dwarfs the rounding of
+  // either side.  Cells that pass, and every other geometry, take the reference's test.
+  bool may_touch = true;
+  if (g.eps >= 0.0 && g.mr0 > 0.0) {
+    const double d = g.cs * 0.86602540378443865 * (1.0 + 1e-9);
+    if (ar_ + d < g.r_0) may_touch = false;
+    else {
+      const double wmax = g.w_0 * pow(rho_mod(g, ar_ + d), g.eps);
+      if (wmax * (1.0 + 1e-9) < ww - d) may_touch = false;      // false for NaN: keeps the test
+    }
+  }
   int n_in = 0;
+  if (may_touch) {
 #pragma unroll
-  for (int v = 0; v < 8; ++v) {
-    const double dx = (v & 1) ? g.cs : 0.0, dy = (v & 2) ? g.cs : 0.0,
-                 dz = (v & 4) ? g.cs : 0.0;
-    double r, w, xa, ya;
-    xyz_to_rw(g, x0 + dx, y0 + dy, z0 + dz, r, w, xa, ya);
-    const double wr = g.w_0 * pow(rho_mod(g, r), g.eps);            // geometry.py:118
-    if (wr >= w && fabs(r) >= g.r_0) ++n_in;                       // classes.py:665
+    for (int v = 0; v < 8; ++v) {
+      const double dx = (v & 1) ? g.cs : 0.0, dy = (v & 2) ? g.cs : 0.0,
+                   dz = (v & 4) ? g.cs : 0.0;
+      double r, w, xv, yv;
+      xyz_to_rw(g, x0 + dx, y0 + dy, z0 + dz, r, w, xv, yv);
+      const double wr = g.w_0 * pow(rho_mod(g, r), g.eps);            // geometry.py:118
+      if (wr >= w && fabs(r) >= g.r_0) ++n_in;                       // classes.py:665
+    }
   }
   const double nan = __builtin_nan("");
   const double ff = n_in == 8 ? 1.0 : (n_in > 0 ? 0.5 : nan);
@@ -254,12 +278,6 @@ __global__ __launch_bounds__(kFB) void build_fields_kernel(GeomDev g, T* nd, T* 
   if (ff_raw) ff_raw[i] = ff;
   if (areas_raw) areas_raw[i] = ar;
   const bool jet = n_in > 0;
-
-  // centroid coordinates (classes.py:521-525)
-  const double h = g.cs / 2.0;
-  double rr, ww, xa, ya;
-  xyz_to_rw(g, x0 + h, y0 + h, z0 + h, rr, ww, xa, ya);
-  const double ar_ = fabs(rr);
   // classes.py:884-886 (same clamp in ion_fraction / vel / ts)
   const double rc = (ar_ < g.r_0 && (ar_ + h) >= g.r_0) ? (g.r_0 + ar_ + h) / 2.0 : ar_;
   // classes.py:549-555: r_eff uses |rr| (unclamped)
