@@ -44,13 +44,16 @@ def _jet(shape, seed, temp_mode, q_T, ejection):
 
 
 @pytest.mark.parametrize("store,tol", [(8, 1e-11), (4, 1e-5)])
-def test_more_than_eight_bursts_per_jet_k1(eng, store, tol):
+@pytest.mark.parametrize("shape", [(4, 41, 16), (2, 41, 256)])
+def test_more_than_eight_bursts_per_jet_k1(eng, store, tol, shape):
     """12 red + 13 blue bursts: the first eight of a jet travel as scalar kernel arguments,
     the rest in the staged device table.  Direct evaluation (irregular epochs), the
     uniform-epoch recurrence with EM maps (16-epoch tiles) and without (32-epoch tile), all
     against the oracle's chained closures."""
     from rajepy_amd import engine as E
-    shape = (4, 41, 16)                  # z = 8 splits the jets inside one wave: mixed lanes
+    # (4, 41, 16): z = 8 splits the jets inside one wave (mixed lanes, three-operation
+    # recurrence); (2, 41, 256): whole waves inside one jet (two-operation recurrence, the
+    # overflow bursts' step tables and parameters by scalar loads)
     seed = 20240521
     ej = _many_bursts()
     jet, p = _jet(shape, seed, 0, 0., ej)
@@ -318,15 +321,19 @@ def test_pipeline_execute_on_two_ranks_sharing_the_gpu(tmp_path):
 
 @pytest.mark.parametrize("n_ep,want_em", [(32, False), (32, True), (16, True), (41, False)])
 @pytest.mark.parametrize("compact", [True, False])
-def test_lds_dma_tile_kernel_equals_the_register_path_bit_for_bit(eng, n_ep, want_em, compact):
+@pytest.mark.parametrize("shape", [(5, 45, 38), (2, 21, 256)])
+def test_lds_dma_tile_kernel_equals_the_register_path_bit_for_bit(eng, n_ep, want_em, compact,
+                                                                  shape):
     """Tiles of >= 16 uniformly spaced epochs prefetch their rows by LDS-DMA when the f64
     fields are 16-byte aligned and n_z is even (ff_scan_tile_kernel); fields that start 8
     bytes off take the register-load kernel.  Same arithmetic in the same order: the maps
     must be IDENTICAL -- odd row counts (a half-used last request), a partial last workgroup,
-    NaN cells, occupied y-ranges attached, both field layouts."""
+    NaN cells, occupied y-ranges attached, both field layouts.  The first shape has 190
+    sightlines (one partial workgroup, every wave straddles the red/blue plane: the
+    three-operation recurrence); the second has waves that lie inside one jet (the
+    two-operation recurrence with its step table in SGPRs)."""
     import torch
     from rajepy_amd import engine as E
-    shape = (5, 45, 38)                       # 190 sightlines: one partial workgroup
     jet, p = _jet(shape, 20240521, 0, 0., U.example_bursts_params())
     g = U.synth_host(shape, 20240521, 0)
     rng = np.random.default_rng(5)
