@@ -25,6 +25,11 @@ def eng():
 
 def _random_model(rng, with_vy):
     shape = (int(rng.integers(1, 6)), int(rng.integers(3, 70)), int(rng.integers(1, 41)))
+    if not with_vy and rng.random() < 0.3:
+        # wide in z: whole waves inside one jet (the red/blue flag of the synthetic fields is
+        # i_z < n_z / 2), which is what the two-operation burst recurrence needs
+        shape = (int(rng.integers(1, 3)), int(rng.integers(3, 40)),
+                 int(rng.choice([128, 130, 192, 256])))
     plaw = bool(rng.integers(2))
     g = U.synth_host(shape, int(rng.integers(1 << 30)), 1 if plaw else 0)
     # sprinkle "outside the jet" cells and odd values into individual fields
