@@ -61,6 +61,29 @@ def test_abi_struct_layouts_match_header():
     assert _lib.Geometry.rb_frac.offset == 4 * 4 + 23 * 8
 
 
+def test_workspace_queries_are_host_arithmetic():
+    """The workspace sizes are plain host arithmetic of the launcher's tiling rules (no GPU):
+    one plane set per y-range, 2 E + 2 planes per set; tiles of >= 16 epochs are cut into 4x
+    the y-ranges of the HBM-bound scans while their partial sums stay below 6 GiB."""
+    lib = _lib.load()
+    npix = 512 * 512
+    # worst case over the lane widths the launcher may pick: 4 sightlines per lane (f32
+    # storage) leave a quarter of the lanes, hence 16 y-ranges where 2-wide f64 lanes take 8
+    one = lib.rjp_ff_scan_workspace(512, 4096, 512, 1)
+    assert one == 16 * (2 * 1 + 2) * npix * 8 + 256
+    eight = lib.rjp_ff_scan_workspace(512, 4096, 512, 8)
+    assert eight == 16 * (2 * 8 + 2) * npix * 8 + 256
+    tile32 = lib.rjp_ff_scan_workspace(512, 4096, 512, 32)
+    assert tile32 == 32 * (2 * 32 + 2) * npix * 8 + 256            # 32 y-ranges of 128 rows
+    assert lib.rjp_ff_scan_workspace(512, 4096, 512, 1000) == tile32   # tiles never exceed 32
+    # 4x the sightlines: 32 ranges of a 32-epoch tile would need 17.7 GB -> halved until < 6 GiB
+    big = lib.rjp_ff_scan_workspace(1024, 4096, 1024, 32)
+    assert big == 16 * (2 * 16 + 2) * 4 * npix * 8 + 256           # its 16-epoch tiles decide
+    assert lib.rjp_ff_scan_workspace(0, 4, 4, 1) == 0
+    assert lib.rjp_ff_maps_workspace(npix, 1, 256) > 0
+    assert lib.rjp_ff_maps_workspace(0, 1, 1) == 0
+
+
 def test_no_gpu_fails_loudly_not_silently():
     import torch
     if torch.cuda.is_available():
