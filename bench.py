@@ -605,11 +605,8 @@ def main(argv=None):
         alg_bytes = npass * nfld * ncell_loc * dsz + base_maps
         # SURVEY 8(d)'s byte model: 5 fields per cell (per grid pass of this launch)
         alg_8d = npass * 5 * ncell_loc * dsz + base_maps
-        # tiles of >= 16 epochs on f64 fields run the LDS-DMA variant of the scan (one
-        # instantiation excepted, ff_scan.hip launch_tile)
-        dma = (E_loc >= 16 and args.storage == "f64" and fields.shape[2] % 2 == 0 and
-               not (args.gaunt == "powerlaw" and fields.em0 is not None and tile == 32
-                    and not want_em))
+        # tiles of >= 16 epochs on f64 fields run the LDS-DMA variant of the scan
+        dma = E_loc >= 16 and args.storage == "f64" and fields.shape[2] % 2 == 0
         kname = "ff_scan_tile_kernel" if dma else "ff_scan_kernel"
         roof_extra = {"grid_passes_per_launch": npass, "fields_streamed_per_cell": nfld,
                       "epochs_per_launch": E_loc}

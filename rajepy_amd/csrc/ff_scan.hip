@@ -76,10 +76,11 @@ __host__ __device__ constexpr int unroll_for(int vec, int et, bool compact, int 
 }
 // The fast T^-1.35 (power-law Gaunt mode) is a property of the KERNEL, not of a row batch:
 // the unrolled body and the row tail must evaluate a cell identically, or a scan would depend
-// on where its y-range starts.  The 16- and 32-epoch tiles are register-bound and keep
-// T^-1.5 * pow(T, 0.15), whose libm call lives out of line.
+// on where its y-range starts.  Every tile uses it (the Halley form needs ~8 live registers,
+// so the 16- and 32-epoch tiles afford it too; they used to call libm's pow out of line).
 __host__ __device__ constexpr bool fast_power_law(int vec, int et, bool compact, int mode) {
-  return mode == RJP_GFF_POWERLAW && et <= 8 && unroll_for(vec, et, compact, mode) * vec <= 8;
+  (void)vec; (void)et; (void)compact;
+  return mode == RJP_GFF_POWERLAW;
 }
 
 // number of accumulator planes a tile of ET epochs writes per y-split
@@ -802,11 +803,7 @@ static hipError_t launch_tile(const rjp_fields* fl, const BurstsDev& b, const do
   // the recurrence pays with at least 4 epochs per tile; short tiles of f32 storage keep
   // their 9-instruction float-accuracy exp instead
   if constexpr (sizeof(T) == 8 && VEC == 1 && BURSTS && ET >= 16) {
-    // (one instantiation is slower with the DMA loop: the power-law Gaunt branch on the compact
-    // layout without EM maps needs 197 instead of 168 VGPRs there, 2 waves instead of 3:
-    // 21.6 against 21.0 ms, profiles/r02d_tile_dma_ab.log)
-    constexpr bool kDmaLoses = MODE == RJP_GFF_POWERLAW && CMP && ET == 32;
-    if (ep.un.on && tile_dma_ok(fl) && !(kDmaLoses && !want_em)) {
+    if (ep.un.on && tile_dma_ok(fl)) {
       FieldPtrs<double> fd{(const double*)fl->d_nd, (const double*)fl->d_xi,
                            (const double*)fl->d_temp, (const double*)fl->d_pf,
                            (const double*)fl->d_ts, fl->d_ylo, fl->d_yhi,
