@@ -463,7 +463,7 @@ def test_uniform_epoch_sweeps_use_the_recurrence_correctly(eng, dtype, n_ep, t1)
         np.testing.assert_allclose(em_h[e], jet.emission_measure(), rtol=tol, err_msg=str(e))
 
 
-@pytest.mark.parametrize("seed", range(10))
+@pytest.mark.parametrize("seed", range(24))
 def test_field_builder_random_geometries_vs_oracle(eng, seed):
     """K4 fuzz: random inclinations / position angles / opening angles / power laws / rotation
     sense on a small grid.  The device jet mask must equal the oracle builder's exactly (the
