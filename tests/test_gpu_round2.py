@@ -381,3 +381,24 @@ def test_lds_dma_tile_kernel_equals_the_register_path_bit_for_bit(eng, n_ep, wan
         for e in (0, n_ep // 2, n_ep - 1):
             jet2.time = ep[e]
             np.testing.assert_allclose(got[e], jet2.optical_depth_ff(5e9), rtol=1e-11)
+
+
+def test_field_builder_mask_on_a_grid_where_most_cells_take_the_early_out(eng):
+    """The example jet on 100 x 800 x 100 cells (0.4 % filled): the builder skips the
+    eight-vertex test for cells a conservative bound puts outside the jet; fill factor and
+    areas must still equal the oracle builder's (the reference's vertex test) cell for cell."""
+    from rajepy_amd.classes import geometry_struct
+    p = copy.deepcopy(U.load_golden("cfg1_example")[2])
+    p["grid"].update(n_x=100, n_y=800, n_z=100)
+    jet = orc.OracleJet(p)
+    geom = geometry_struct(jet.params, jet.nx, jet.ny, jet.nz)
+    f = eng.build_fields(geom, 8, want_ts=False, want_vxz=False)
+    eng.synchronize()
+    ff = f.ff_raw.cpu().numpy().reshape(jet.nx, jet.ny, jet.nz)
+    ar = f.areas_raw.cpu().numpy().reshape(ff.shape)
+    ref_ff, ref_ar = jet.fill_factor, jet.areas
+    assert np.array_equal(np.isnan(ff), np.isnan(ref_ff))
+    assert np.array_equal(np.nan_to_num(ff), np.nan_to_num(ref_ff))
+    assert np.array_equal(np.nan_to_num(ar), np.nan_to_num(ref_ar))
+    filled = np.isfinite(ref_ff).mean()
+    assert 0.001 < filled < 0.02, filled
