@@ -54,6 +54,10 @@ def build_model_fields(model, geom, **kw):
     launch-time exponent differ by an integer) is answered with the host evaluation of the
     launch times; every other failure (bad geometry, HIP error, ABI mismatch) propagates."""
     eng = model.engine
+    # fill factor and areas as separate arrays are redundant for a model (areas is 1 wherever
+    # it is not NaN, so the path factor ff/areas IS the fill factor: the accessors read `pf`):
+    # two grid-sized f64 arrays less to allocate and to write
+    kw.setdefault("want_raw", False)
     try:
         return eng.build_fields(geom, model._dtype, want_ts=True, **kw)
     except _lib.RjprtError as exc:
