@@ -13,7 +13,13 @@ Workload (BASELINE.json, the configuration its metric is quoted on): a 512x4096x
 dense synthetic fields (generated on the device), 256 continuum channels
 1-50 GHz, with the example model's four ejection bursts.  One "step" = one pass of the hot
 path over one epoch: K1 (grid scan -> base maps) + K2 (tau and flux cubes for all 256
-channels + per-channel total flux), fields already resident in HBM.
+channels + per-channel total flux), fields already resident in HBM.  Default layout "tau": K1
+streams the two fields that are left once everything independent of frequency and epoch has been
+evaluated per model (a0 = (n x)^2 pf T^-1.5 and the launch time ts, 16 B/cell); the T_avg map
+is per-model state as well (rjp_tavg, timed and reported, not part of a step).  `--em` adds the
+emission-measure map to the step (a third field, em0: 24 B/cell); `--layout compact|wide` scan
+3 / 5 fields per cell (the line always prices SURVEY 8(d)'s five-field byte model on the wide
+kernel, live, as `frac_8d`).
 
 N > 1 (no data-path collective, one gather/reduce per step over RCCL):
   cfg4 / cfg2  timed region: burst-time epochs shard embarrassingly -- every rank holds the
@@ -44,6 +50,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+CPU_MEM_BUDGET = 96 * 2 ** 30    # host bytes the all-cores CPU leg may hold in total
+MAX_CPU_PROCS = 96               # cap of the all-cores CPU leg (host memory, see there)
 HBM_PEAK_GBS = 8000.0            # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 YEAR = 31536000.0
 SEED = 20240504
@@ -78,9 +86,13 @@ def parse(argv=None):
     ap.add_argument("--config", default=os.environ.get("RJP_BENCH_CONFIG", "cfg4"),
                     choices=sorted(CONFIGS))
     ap.add_argument("--storage", default="f64", choices=("f64", "f32"))
-    ap.add_argument("--layout", default="compact", choices=("compact", "wide"),
-                    help="compact = K1 streams em0, temp, ts (3 fields/cell, the default); "
+    ap.add_argument("--layout", default="tau", choices=("tau", "compact", "wide"),
+                    help="tau = K1 streams a0, ts (2 fields/cell, the default; em0 as a third "
+                         "with --em); compact = em0, temp, ts (3 fields/cell); "
                          "wide = nd, xi, temp, pf, ts (5 fields/cell, SURVEY 8(d)'s byte model)")
+    ap.add_argument("--em", action="store_true",
+                    help="the step also produces the emission-measure map of its epoch "
+                         "(JetModel.emission_measure); default: optical depths and fluxes only")
     ap.add_argument("--gaunt", default="scalar", choices=("scalar", "powerlaw"),
                     help="scalar = the q_T == 0 branch (T = 1e4 K, one van Hoof Gaunt factor per "
                          "channel: the headline); powerlaw = the q_T != 0 branch "
@@ -201,12 +213,19 @@ def cpu_baseline(shape, freqs, seed, target_s, rrl=None, all_cores=True, plaw=Fa
     ncell = nx * nyb * nz
     what = "optical_depth_rrl+flux_rrl(contsub=False)" if rrl else "optical_depth_ff+flux_ff"
     out = {"value": ncell * nch / dt / 1e6, "unit": "Mvoxel-freq/s", "cores": 1,
-           "kind": "port",
+           "kind": "port", "host": host_description(),
            "sample": "oracle %s on a %dx%dx%d y-truncated block of the same synthetic grid x "
                      "%d of the channels (%.1f s)" % (what, nx, nyb, nz, nch, dt)}
     if all_cores:
         out["all_cores"] = cpu_baseline_all_cores((nx, max(2, nyb // 4), nz), sel, seed, rrl,
                                                   plaw)
+    # provenance: the REFERENCE itself (unmodified, imported under its own pins) timed in the
+    # build container for SURVEY.md section 6 -- another host, quoted, not measured here
+    out["reference_proper"] = {
+        "host": "build container, 8-core Intel Xeon @ 2.1 GHz, NumPy single-threaded",
+        "optical_depth_ff+flux_ff, 4 channels, 128x512x128": 3.72,
+        "optical_depth_rrl (9.26 s) + flux_rrl(contsub=False) (32.2 s), 4 channels, 128x512x128": 0.81,
+        "unit": "Mvoxel-freq/s", "source": "BASELINE.md / SURVEY.md section 6"}
     return out
 
 
@@ -219,26 +238,81 @@ sub, seed, sel, rrl, t_start = %(sub)r, %(seed)r, np.array(%(sel)r), %(rrl)r, %(
 jet = bench._oracle_jet(sub, seed, %(plaw)r)
 ready = time.time()
 time.sleep(max(0.0, t_start - ready))
-if rrl:
-    jet.optical_depth_rrl(rrl, sel); jet.flux_rrl(rrl, sel, contsub=False)
-else:
-    jet.optical_depth_ff(sel); jet.flux_ff(sel)
+for _ in range(%(reps)d):
+    if rrl:
+        jet.optical_depth_rrl(rrl, sel); jet.flux_rrl(rrl, sel, contsub=False)
+    else:
+        jet.optical_depth_ff(sel); jet.flux_ff(sel)
 print(json.dumps({"late": ready > t_start, "end": time.time() - t_start}))
 """
+
+
+def host_description():
+    """What the CPU figures ran on: logical CPUs of the box, the CPUs this job
+    may use (affinity / cgroup quota) and the `lscpu` model string."""
+    d = {"os_cpu_count": os.cpu_count()}
+    try:
+        d["affinity"] = len(os.sched_getaffinity(0))
+    except AttributeError:
+        d["affinity"] = None
+    d["cgroup_cpus"] = None                # CPU quota of the container, if any (cgroup v2, v1)
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        d["cgroup_cpus"] = None if q == "max" else float(q) / float(per)
+    except Exception:
+        try:
+            q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            d["cgroup_cpus"] = q / per if q > 0 else None
+        except Exception:
+            pass
+    model = None
+    try:
+        txt = subprocess.run(["lscpu"], capture_output=True, text=True, timeout=10).stdout
+        for line in txt.splitlines():
+            if line.startswith("Model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except Exception:
+        pass
+    if model is None:
+        try:
+            for line in open("/proc/cpuinfo"):
+                if line.startswith("model name"):
+                    model = line.split(":", 1)[1].strip()
+                    break
+        except Exception:
+            pass
+    d["lscpu_model"] = model
+    return d
+
+
+def usable_cores():
+    """Cores the all-cores leg may occupy: the affinity mask, cut to the cgroup quota when one
+    is set."""
+    h = host_description()
+    n = h["affinity"] or h["os_cpu_count"] or 1
+    if h["cgroup_cpus"]:
+        n = min(n, max(1, int(h["cgroup_cpus"])))
+    return max(1, n)
 
 
 def cpu_baseline_all_cores(sub, sel, seed, rrl, plaw=False):
     """The same oracle calls in one process per host core of this job's CPU share, each on its
     own copy of a (smaller) block, started together: aggregate rate = what a channel-sharded
     process pool of the reference path would reach on this host."""
-    try:
-        cores = len(os.sched_getaffinity(0))
-    except AttributeError:
-        cores = os.cpu_count() or 1
-    cores = max(1, min(cores, 16))           # one GPU's share of the box
-    t_start = time.time() + 25.0             # children import, build their block, then wait
+    avail = usable_cores()
+    # every core the job may use (at most MAX_CPU_PROCS processes)
+    cores = max(1, min(avail, MAX_CPU_PROCS))
+    # host memory: every process holds its own block + the oracle's ~25 grid-sized arrays and
+    # temporaries of it; the blocks shrink with the process count (CPU_MEM_BUDGET in total) and
+    # the calls repeat so that a process still works for about as long
+    rows = max(2, min(sub[1], int(CPU_MEM_BUDGET / (cores * sub[0] * sub[2] * 8 * 25))))
+    reps = max(1, sub[1] // rows)
+    sub = (sub[0], rows, sub[2])
+    t_start = time.time() + 25.0 + 0.25 * cores   # children import, build their block, then wait
     code = _CHILD % {"root": ROOT, "sub": tuple(sub), "seed": seed, "sel": [float(x) for x in sel],
-                     "rrl": rrl, "t_start": t_start, "plaw": bool(plaw)}
+                     "rrl": rrl, "t_start": t_start, "plaw": bool(plaw), "reps": reps}
     env = dict(os.environ, OMP_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1", MKL_NUM_THREADS="1")
     procs = [subprocess.Popen([sys.executable, "-c", code], stdout=subprocess.PIPE,
                               stderr=subprocess.DEVNULL, text=True, env=env)
@@ -255,11 +329,14 @@ def cpu_baseline_all_cores(sub, sel, seed, rrl, plaw=False):
                 q.kill()
             return {"error": "%s: %s" % (type(exc).__name__, exc)}
     ncell = sub[0] * sub[1] * sub[2]
-    return {"value": cores * ncell * len(sel) / max(ends) / 1e6, "unit": "Mvoxel-freq/s",
-            "cores": cores, "late_start": late,
-            "sample": "%d processes, each the same calls on its own %dx%dx%d block x %d "
-                      "channels, started together (%.1f s)" % (cores, sub[0], sub[1], sub[2],
-                                                               len(sel), max(ends))}
+    return {"value": cores * reps * ncell * len(sel) / max(ends) / 1e6, "unit": "Mvoxel-freq/s",
+            "cores": cores, "cores_available": avail,
+            "cap": None if cores == avail else
+            "%d processes (process count per job on the GPU boxes)" % MAX_CPU_PROCS,
+            "late_start": late,
+            "sample": "%d processes, each the same calls %d time(s) on its own %dx%dx%d block "
+                      "x %d channels, started together (%.1f s)"
+                      % (cores, reps, sub[0], sub[1], sub[2], len(sel), max(ends))}
 
 
 # ---------------------------------------------------------------------------------------
@@ -317,12 +394,13 @@ GATHER = {"none": "none", "epochs": "all_gather of flux-vs-time [E,F]",
           "channels": "all_gather of per-channel fluxes along F"}
 
 
-def collect(res, pl, rank, world, backend):
-    """The one collective of a step: per-rank flux vectors -> the whole job's [E, F]."""
+def collect(res, pl, rank, world, backend, force=False):
+    """The one collective of a step: per-rank flux vectors -> the whole job's [E, F].
+    `force`: issue the collective in a one-rank group too (the RCCL test on a one-GPU box)."""
     import torch.distributed as dist
     from rajepy_amd.parallel import all_gather_blocks, gather_flux_vs_time
     sh = pl["sharding"]
-    if world == 1 or sh == "none":
+    if (world == 1 and not force) or sh == "none":
         return res
     if sh == "channels":                  # [E, F/N] per rank -> [E, F]
         return all_gather_blocks(res, pl["cshards"], rank, axis=1)
@@ -407,9 +485,11 @@ class Workload:
         self.P = lshape[0] * lshape[2]
         self.ncell_loc = lshape[0] * lshape[1] * lshape[2]
         lean = args.config == "cfg4x8"            # generate em0, temp, ts only (24 B/cell)
+        tau = args.layout == "tau" and self.dtype == E.RJP_F64 and not (lean and args.em)
         self.fields = eng.synth_fields(lshape, SEED, 1 if self.plaw else 0, self.dtype,
                                        csize_au=0.5, with_vy=self.rrl, cell0=pl["cell0"],
-                                       wide=not lean)
+                                       wide=not lean, tau_mode=self.gmode if tau else None,
+                                       with_em0=not (lean and tau))
         self._em0 = self.fields.em0
         if args.layout == "wide":
             self.fields.em0 = None
@@ -432,10 +512,20 @@ class Workload:
         self.my_epochs = pl["my_epochs"]
         E_loc = self.E_loc = len(self.my_epochs)
         self.sumA = eng._f64(E_loc, self.P)
-        # flux-vs-time sweeps (cfg5) ask for no emission-measure maps, as
-        # parallel.sweep_flux_vs_time
-        self.em = None if pl["n_ep_cfg"] else eng._f64(E_loc, self.P)
-        self.tavg = eng._f64(self.P)
+        # the step produces optical depths and fluxes; the emission-measure map of the epoch
+        # only with --em (flux-vs-time sweeps, cfg5, never ask for it, as
+        # parallel.sweep_flux_vs_time)
+        self.em = eng._f64(E_loc, self.P) if (args.em and not pl["n_ep_cfg"]) else None
+        # T_avg depends on neither frequency nor epoch: per-model state, like the fields
+        # (JetModel._model_tavg); its one-off pass is timed for the record
+        import torch
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        eng.tavg(self.fields)
+        ev0.record()
+        self.tavg = eng.tavg(self.fields)
+        ev1.record()
+        torch.cuda.synchronize()
+        self.tavg_ms = ev0.elapsed_time(ev1)
         self.ftot = eng._f64(E_loc, self.nchan)
         if pl["n_ep_cfg"]:
             self.tau = self.flux = None       # flux-vs-time output: maps reduced on the device
@@ -452,7 +542,7 @@ class Workload:
         """The hot path on this rank's shard; returns its per-channel fluxes [E_loc, F_loc]."""
         eng = self.eng
         eng.ff_scan(self.fields, self.bursts, self.my_epochs, self.gmode,
-                    out=(self.sumA, self.em, self.tavg))
+                    out=(self.sumA, self.em, None))
         eng.ff_maps(self.sumA, self.tavg, self.ctau, self.cflux,
                     out=(self.tau, self.flux, self.ftot))
         res = self.ftot
@@ -472,6 +562,21 @@ class Workload:
         self.fields = self._em0 = self.sumA = self.em = self.tau = self.flux = None
         import torch
         torch.cuda.empty_cache()
+
+
+def device_identity(torch, index):
+    """What physically distinguishes the GPU behind cuda:<index>: UUID and PCI address (plus the
+    host name, so that the ids of a multi-node job could not collide)."""
+    pr = torch.cuda.get_device_properties(index)
+    uuid = str(getattr(pr, "uuid", "")) or None
+    pci = None
+    if hasattr(pr, "pci_bus_id"):
+        pci = "%04x:%02x:%02x" % (int(getattr(pr, "pci_domain_id", 0)), int(pr.pci_bus_id),
+                                  int(getattr(pr, "pci_device_id", 0)))
+    host = socket.gethostname()
+    ident = "%s/%s" % (host, uuid or pci or "cuda:%d" % index)
+    return {"id": ident, "uuid": uuid, "pci": pci, "host": host, "index": int(index),
+            "name": pr.name, "arch": getattr(pr, "gcnArchName", None)}
 
 
 def main(argv=None):
@@ -497,6 +602,10 @@ def main(argv=None):
     from rajepy_amd import engine as E
 
     if args.share_gpu:
+        if args.backend == "nccl" and world > 1:
+            print("bench.py: --share-gpu puts several ranks on ONE device; RCCL needs one device "
+                  "per rank (use --backend gloo for that rehearsal)", file=sys.stderr)
+            sys.exit(2)
         local = 0
     ndev = torch.cuda.device_count()
     if local >= ndev:
@@ -560,6 +669,23 @@ def main(argv=None):
                           device=eng.device if args.backend == "nccl" else "cpu")
         dist.all_reduce(ones)
         ranks_seen = int(ones.item())
+    # ... each on a GPU of its own: the physical identity of every rank's device, gathered over
+    # the same group.  A line whose ranks shared devices is a rehearsal of the plumbing, not a
+    # multi-GPU result: it says so and carries no `value`.
+    me = device_identity(torch, local)
+    devices = [me]
+    if world > 1:
+        devices = [None] * world
+        dist.all_gather_object(devices, me)
+    distinct_devices = len({d["id"] for d in devices})
+    rehearsal = bool(args.share_gpu or distinct_devices < world or
+                     (world > 1 and args.backend != "nccl"))
+    if world > 1 and args.backend == "nccl" and distinct_devices < world:
+        if rank == 0:
+            print("bench.py: %d ranks over RCCL but only %d distinct device(s): %s"
+                  % (world, distinct_devices, json.dumps(devices)), file=sys.stderr)
+        dist.destroy_process_group()
+        sys.exit(3)
 
     # ---- sustained leg: ~10 s of back-to-back steps (clock / power droop would show) ----
     sustained = None
@@ -592,59 +718,87 @@ def main(argv=None):
     else:
         want_em = wl.em is not None
         k_ms = eng.time_ff_scan(fields, wl.bursts, wl.my_epochs, wl.gmode, reps=5,
-                                want_em=want_em)
+                                want_em=want_em, want_tavg=False)
         # epoch tiles share a pass over the grid: 32 uniformly spaced epochs, 16 below that,
         # else 8 (f64 lanes) or 4 (f32 lanes)
         tile = (32 if E_loc >= 32 else 16 if E_loc >= 16 else
                 (8 if args.storage == "f64" else 4))
         npass = -(-E_loc // tile) if E_loc > 1 else 1
-        # fields K1 streams per cell: em0, temp, ts in the compact layout (DESIGN.md "Data
-        # layout"), else nd, xi, temp, pf, ts
-        nfld = 3 if fields.em0 is not None else 5
-        base_maps = E_loc * P * 2 * 8
+        # fields K1 streams per cell (DESIGN.md "Data layout"): a0, ts on the tau layout (+ em0
+        # with EM maps), em0, temp, ts on the compact one, else nd, xi, temp, pf, ts
+        nfld = fields.scan_fields(wl.gmode, want_em)
+        base_maps = E_loc * P * (2 if want_em else 1) * 8
         alg_bytes = npass * nfld * ncell_loc * dsz + base_maps
-        # SURVEY 8(d)'s byte model: 5 fields per cell (per grid pass of this launch)
-        alg_8d = npass * 5 * ncell_loc * dsz + base_maps
+        # SURVEY 8(d)'s byte model: 5 fields per cell (per grid pass of this launch), tau and
+        # EM base maps
+        alg_8d = npass * 5 * ncell_loc * dsz + E_loc * P * 2 * 8
         # tiles of >= 16 epochs on f64 fields run the LDS-DMA variant of the scan
         dma = E_loc >= 16 and args.storage == "f64" and fields.shape[2] % 2 == 0
         kname = "ff_scan_tile_kernel" if dma else "ff_scan_kernel"
         roof_extra = {"grid_passes_per_launch": npass, "fields_streamed_per_cell": nfld,
-                      "epochs_per_launch": E_loc}
+                      "epochs_per_launch": E_loc, "timed_step_asks_for_em": want_em,
+                      "tavg": {"ms": wl.tavg_ms, "bytes": ncell_loc * dsz,
+                               "what": "T_avg = nanmean_y(T > 0) is independent of frequency "
+                                       "and epoch: one rjp_tavg pass per MODEL, not part of "
+                                       "a step"}}
         if n_ep_cfg:
             # 8(d) prices one grid pass PER EPOCH; the fused tiles make `npass` passes serve
             # E_loc epochs -- both figures, as 8(d) asks
-            roof_extra["algorithmic_bytes_8d_unfused"] = E_loc * 5 * ncell_loc * dsz + base_maps
-        if nfld == 3 and fields.nd is not None:
+            roof_extra["algorithmic_bytes_8d_unfused"] = (E_loc * 5 * ncell_loc * dsz +
+                                                          E_loc * P * 2 * 8)
+        if nfld == 2 and fields.em0 is not None:
+            # the same launch WITH the emission-measure map of the epoch (a third field, em0)
+            em_ms = eng.time_ff_scan(fields, wl.bursts, wl.my_epochs, wl.gmode, reps=3,
+                                     want_em=True, want_tavg=False)
+            b3 = npass * 3 * ncell_loc * dsz + E_loc * P * 2 * 8
+            roof_extra["with_em"] = {"ms_per_launch": em_ms, "fields_streamed_per_cell": 3,
+                                     "algorithmic_bytes": b3,
+                                     "frac": b3 / (em_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+        if nfld < 5 and fields.nd is not None:
             # the 8(d) bytes are what the WIDE layout moves: time that kernel on the same
-            # fields, and the one-off pass that derives the compact field from them
-            em0, fields.em0 = fields.em0, None
+            # fields (with the EM and T_avg sums 8(d)'s model includes), and the one-off
+            # passes that derive the scan fields from the wide ones
+            em0, a0 = fields.em0, fields.a0
+            fields.em0 = fields.a0 = None
             wide_ms = eng.time_ff_scan(fields, wl.bursts, wl.my_epochs, wl.gmode, reps=3,
-                                       want_em=want_em)
-            ev0, ev1 = (torch.cuda.Event(enable_timing=True),
-                        torch.cuda.Event(enable_timing=True))
-            eng.compact(fields)
-            torch.cuda.synchronize()
-            ev0.record()
-            eng.compact(fields)
-            ev1.record()
-            torch.cuda.synchronize()
-            build_ms = ev0.elapsed_time(ev1)
-            fields.em0 = em0
+                                       want_em=True)
+
+            def ev_ms(fn):
+                ev0, ev1 = (torch.cuda.Event(enable_timing=True),
+                            torch.cuda.Event(enable_timing=True))
+                fn()
+                torch.cuda.synchronize()
+                ev0.record()
+                fn()
+                ev1.record()
+                torch.cuda.synchronize()
+                return ev0.elapsed_time(ev1)
+            build_ms = ev_ms(lambda: eng.compact(fields))
+            if a0 is not None:
+                build_ms += ev_ms(lambda: eng.tau_layout(fields, wl.gmode))
+            fields.em0, fields.a0 = em0, a0
             roof_extra.update({
                 "wide_ms_per_launch": wide_ms, "layout_build_ms": build_ms,
                 "frac_8d": alg_8d / (wide_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                "frac_8d_kernel": "the wide-layout ff_scan_kernel (5 fields/cell), timed live "
-                                  "on the same fields",
-                "first_epoch_from_wide_fields_ms": {"compact": build_ms + k_ms,
+                "frac_8d_kernel": "the wide-layout ff_scan_kernel (5 fields/cell, tau + EM + "
+                                  "T_avg sums), timed live on the same fields",
+                "first_epoch_from_wide_fields_ms": {"scan_layout": build_ms + wl.tavg_ms + k_ms,
                                                     "wide": wide_ms}})
         elif nfld == 5:
             roof_extra["frac_8d"] = alg_8d / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
     achieved = alg_bytes / (k_ms * 1e-3) / 1e9
     traffic, traffic_source = None, None
-    for rnd in ("r02e", "r02", "r01"):
-        rel = os.path.join("profiles", "%s_%s_%s_pmc.json" % (rnd, args.config, args.storage))
-        if nfld_is_wide(roof_extra):
-            rel = rel.replace("_pmc.json", "_wide5_pmc.json")
+    has_tau = wl.fields.a0 is not None
+    nf = roof_extra.get("fields_streamed_per_cell")
+    lay_tag = {2: "_tau2", 3: "_tau3" if has_tau else "", 5: "_wide5"}.get(nf, "")
+    k1_layout = {2: "tau (a0, ts: 2 fields/cell)", 5: "wide (5 fields/cell)",
+                 3: "tau + EM (a0, em0, ts: 3 fields/cell)" if has_tau
+                 else "compact (3 fields/cell)"}.get(nf)
+    layout_desc = k1_layout if not rrl else \
+        "K3 reads the 6 wide fields; K1 %s" % ("tau" if has_tau else "compact")
+    for rnd in ("r03", "r02e", "r02", "r01"):
+        rel = os.path.join("profiles", "%s_%s_%s%s_pmc.json" % (rnd, args.config, args.storage,
+                                                                lay_tag))
         if os.path.exists(os.path.join(ROOT, rel)):
             try:
                 traffic = json.load(open(os.path.join(ROOT, rel))).get("hbm_bytes_per_launch")
@@ -737,18 +891,37 @@ def main(argv=None):
                                    "continuum channels 1-50 GHz", total_epochs,
                                    "K3 RRL scan + K1/K2 continuum + line flux cube" if rrl else
                                    "K1 scan + K2 flux-vs-time" if n_ep_cfg else
-                                   "K1 scan + K2 tau/flux cubes")),
+                                   "K1 scan + K2 tau/flux cubes" +
+                                   (" + EM map" if args.em else ""))),
                    "storage": args.storage, "gaunt": args.gaunt,
                    "arithmetic": "f64 accumulation and transcendental functions; storage "
                                  "dtype of the 3-D fields as given",
-                   "layout": ("K3 reads the 6 wide fields; K1 compact (3 fields/cell)" if rrl else
-                              "compact (3 fields/cell)" if roof_extra.get(
-                                  "fields_streamed_per_cell", 5) == 3 else
-                              "wide (5 fields/cell)"),
+                   "layout": layout_desc,
                    "sharding": sharding, "gather": GATHER[sharding]},
         "ranks_seen": ranks_seen,
+        "backend": (args.backend if world > 1 else None),
+        "devices": devices, "distinct_devices": distinct_devices,
         "roofline": roofline,
     }
+    if world > 1 and "strong_xslab" in legs:
+        # the figure that answers "how much faster is ONE model on N GPUs": the x-slab leg
+        # (`value` above is the weak, epoch-sharded aggregate)
+        result["strong_value"] = legs["strong_xslab"]["value"]
+        result["strong_speedup_vs_n1"] = legs["strong_xslab"].get("speedup_vs_n1")
+    elif world > 1 and result["scaling"] == "strong":
+        result["strong_value"] = value
+        result["strong_speedup_vs_n1"] = value / n1["value"] if n1 else None
+    if rehearsal:
+        # several ranks on one device and / or gloo instead of RCCL: plumbing only
+        result["rehearsal"] = True
+        result["rehearsal_value"] = result["value"]
+        result["value"] = None
+        if "strong_value" in result:
+            result["rehearsal_strong_value"] = result.pop("strong_value")
+        result["rehearsal_why"] = ("--share-gpu" if args.share_gpu else
+                                   "%d distinct device(s) for %d ranks" % (distinct_devices, world)
+                                   if distinct_devices < world else
+                                   "backend %s, not RCCL" % args.backend)
     if sustained:
         result["sustained"] = sustained
     if api_level:
@@ -767,10 +940,6 @@ def main(argv=None):
         print(json.dumps(result), flush=True)
     if world > 1:
         dist.destroy_process_group()
-
-
-def nfld_is_wide(roof_extra):
-    return roof_extra.get("fields_streamed_per_cell") == 5
 
 
 if __name__ == "__main__":

@@ -28,8 +28,8 @@
 extern "C" {
 #endif
 
-#define RJP_VERSION 103          /* 0.1.3 */
-#define RJP_MAX_EPOCH_TILE 32    /* most epochs evaluated per grid pass: 32 uniformly spaced ones when d_em is NULL, 16 uniformly spaced ones with d_em, else 8 */
+#define RJP_VERSION 104          /* 0.1.4 */
+#define RJP_MAX_EPOCH_TILE 32    /* most epochs evaluated per grid pass: 32 uniformly spaced ones (with or without d_em), 16 when only 16-31 are left, else tiles of 8, 4, 2, 1 */
 
 enum rjp_status {
   RJP_OK = 0,
@@ -87,6 +87,19 @@ typedef struct rjp_fields {
    * read d_em0 and ignore d_nd / d_xi / d_pf (which may then be NULL for those two calls);
    * the RRL and collapse=False entry points always read the wide fields. */
   const void* d_em0;
+  /* Optional tau scan layout (RJP_F64 storage only), written by rjp_tau_field() or by the
+   * producers: d_a0[cell] = em0 * T^-1.5 (a0_mode = RJP_GFF_SCALAR) or em0 * T^-1.35
+   * (RJP_GFF_POWERLAW) -- every factor of a cell's free-free optical depth that depends on
+   * neither frequency nor epoch (classes.py:1395-1397; the temperature grid is static,
+   * classes.py:942-969) -- formed exactly as the scan forms it from em0 and temp, red-jet flag
+   * in the SIGN BIT.  When non-NULL and a0_mode equals the gff_mode of the call, rjp_ff_scan
+   * streams d_a0 and d_ts = 16 B/cell (plus d_em0, 24 B/cell, only when d_em is asked for) and
+   * never reads d_temp; maps are bit-identical to the compact and wide layouts'.  T_avg, which
+   * depends on neither frequency nor epoch either (classes.py:1471-1472), then comes from
+   * rjp_tavg() once per model (a d_tavg passed to rjp_ff_scan is served by that pass). */
+  const void* d_a0;
+  int32_t a0_mode;          /* enum rjp_gff_mode d_a0 was built for */
+  int32_t reserved_;        /* 0 */
 } rjp_fields;
 
 /* Ejection bursts (classes.py:399-463): mdot(t)/mdot_ss = 1 + sum_b amp_rel_b *
@@ -135,6 +148,19 @@ int rjp_pack_field(rjp_ctx* ctx, const double* d_src, const double* d_den,
 int rjp_compact_fields(rjp_ctx* ctx, const rjp_fields* fields, void* d_em0,
                        int64_t* d_n_bad, void* stream);
 
+/* Builds the tau scan field (see rjp_fields.d_a0) for `gff_mode` from fields->d_em0 and
+ * fields->d_temp in one pass over all cells.  RJP_F64 storage with the compact field attached
+ * (a model that has to stay on the wide layout -- negative path factors -- has no tau layout). */
+int rjp_tau_field(rjp_ctx* ctx, const rjp_fields* fields, int32_t gff_mode, void* d_a0,
+                  void* stream);
+
+/* T_avg map of the model: d_tavg[p] = nanmean_y(T where T > 0) [K], NaN on empty sightlines
+ * (classes.py:1471-1472, 1484-1485, 1254-1256).  One pass over fields->d_temp (the only field
+ * read; d_ylo / d_yhi are honoured), bit-identical to the map a single-epoch rjp_ff_scan
+ * derives.  d_work: at least rjp_ff_scan_workspace(nx, ny, nz, 1) bytes. */
+int rjp_tavg(rjp_ctx* ctx, const rjp_fields* fields, double* d_tavg, void* d_work,
+             size_t work_bytes, void* stream);
+
 /* Per-sightline occupied y-range of a packed field set: d_ylo[p] = first row, d_yhi[p] = one
  * past the last row whose cell can contribute to any product of the path, i.e. T > 0 (counts
  * in the nanmean of intensity_ff, classes.py:1471) or n, x and ff/areas all non-NaN (emission
@@ -151,7 +177,8 @@ int rjp_y_bounds(rjp_ctx* ctx, const rjp_fields* fields, int32_t* d_ylo, int32_t
  *   d_sumA [E*P]  sum_y T^-1.5 (n x)^2 pf          (RJP_GFF_SCALAR)
  *                 sum_y T^-1.35 (n x)^2 pf         (RJP_GFF_POWERLAW)   [cm^-6 K^-1.5|-1.35]
  *   d_em   [E*P]  emission measure [pc cm^-6]      (may be NULL)
- *   d_tavg [P]    nanmean_y(T where T > 0) [K], NaN on empty sightlines (may be NULL)
+ *   d_tavg [P]    nanmean_y(T where T > 0) [K], NaN on empty sightlines (may be NULL; on the
+ *                 tau layout it costs a separate pass over d_temp: ask once, see rjp_tavg)
  * h_epochs_s: model times [s] (JetModel.time), E >= 1.
  * d_work: scratch of at least rjp_ff_scan_workspace() bytes. */
 size_t rjp_ff_scan_workspace(int32_t nx, int32_t ny, int32_t nz, int32_t n_epochs);
@@ -239,23 +266,26 @@ typedef struct rjp_geometry {
  * d_ts != NULL.
  * d_em0 (optional, RJP_F64 only): the compact scan field of rjp_fields.d_em0 written in the
  * same pass, bit-identical to what rjp_compact_fields derives from nd, xi, pf -- with d_nd,
- * d_xi, d_pf NULL a continuum-only model occupies 24 B/cell (12e9 cells per 288 GB GPU). */
+ * d_xi, d_pf NULL a continuum-only model occupies 24 B/cell (12e9 cells per 288 GB GPU).
+ * d_a0 (optional, RJP_F64 only): the tau scan field of rjp_fields.d_a0 for gff mode `a0_mode`,
+ * bit-identical to rjp_tau_field's. */
 int rjp_build_fields(rjp_ctx* ctx, const rjp_geometry* geom, int dtype,
                      void* d_nd, void* d_xi, void* d_temp, void* d_pf, void* d_ts,
                      void* d_vy, double* d_ff_raw, double* d_areas_raw,
-                     double* d_vx_raw, double* d_vz_raw, void* d_em0, void* stream);
+                     double* d_vx_raw, double* d_vz_raw, void* d_em0, void* d_a0,
+                     int32_t a0_mode, void* stream);
 
 /* ---- measurement harness: synthetic dense fields ---------------------
  * Counter-based: u = splitmix64(seed ^ field_id<<60 ^ linear_cell_index) -> [0,1).
  *   n = 10^(5+2.5u), x = 0.05+0.45u, T = 1e4 (temp_mode 0) or 5e3+1.5e4u (temp_mode 1),
  *   pf = 0.5 w.p. 0.25 else 1, ts = 5u yr, red = i_z < n_z/2, vy = 6.2+60(u-0.5) km/s.
  * Generates cells [cell0, cell0+n) of the flattened grid so a host restatement can
- * regenerate any sub-block.  Any output may be NULL; d_em0 (optional, RJP_F64 only) receives
- * the compact scan field of the same cells, as for rjp_build_fields. */
+ * regenerate any sub-block.  Any output may be NULL; d_em0 / d_a0 (optional, RJP_F64 only)
+ * receive the compact and tau scan fields of the same cells, as for rjp_build_fields. */
 int rjp_synth_fields(rjp_ctx* ctx, uint64_t seed, int32_t temp_mode, int32_t nz,
                      int64_t cell0, int64_t n, int dtype, void* d_nd, void* d_xi,
                      void* d_temp, void* d_pf, void* d_ts, void* d_vy, void* d_em0,
-                     void* stream);
+                     void* d_a0, int32_t a0_mode, void* stream);
 
 /* Device-time probe used by bench.py: average duration [ms] of `reps` back-to-back
  * rjp_ff_scan launches measured with HIP events on `stream`. */

@@ -2,11 +2,14 @@
 (reference: classes.py) for the radiative-transfer path: same constructor arguments,
 method names, argument meaning, return shapes/dtypes, file names and error behaviour.
 
-What is different underneath: the 3-D grids live in HBM as five/six packed fields
-(`engine.DeviceFields`), are BUILT on the GPU (`rjp_build_fields`) and every line-of-sight
-reduction runs in librjprt's HIP kernels through the C-ABI of include/rjprt.h.  One grid pass
-serves every continuum channel of an epoch (the reference re-streams the grid per channel),
-and up to sixteen epochs share a pass.  There is no CPU fallback for any of it.
+What is different underneath: the 3-D grids live in HBM as five/six packed fields plus two
+derived scan fields (`engine.DeviceFields`), are BUILT on the GPU (`rjp_build_fields`) and
+every line-of-sight reduction runs in librjprt's HIP kernels through the C-ABI of
+include/rjprt.h.  One grid pass serves every continuum channel of an epoch (the reference
+re-streams the grid per channel), up to 32 uniformly spaced epochs share a pass (16 when
+fewer are left, else tiles of 8 / 4 / 2 / 1), and everything that depends on neither
+frequency nor epoch -- the temperature factor of the optical depth, the T_avg map -- is
+evaluated once per model.  There is no CPU fallback for any of it.
 """
 import collections
 import os
@@ -58,6 +61,8 @@ def build_model_fields(model, geom, **kw):
     # it is not NaN, so the path factor ff/areas IS the fill factor: the accessors read `pf`):
     # two grid-sized f64 arrays less to allocate and to write
     kw.setdefault("want_raw", False)
+    # the tau scan field for the model's Gaunt branch is written in K4's own pass
+    kw.setdefault("tau_mode", model.gff_mode)
     try:
         return eng.build_fields(geom, model._dtype, want_ts=True, **kw)
     except _lib.RjprtError as exc:
@@ -515,8 +520,30 @@ class JetModel:
             self._vxz = (self._grid(tmp.vx_raw), self._grid(tmp.vz_raw))
         return self._vxz[0], self._grid(self.device_fields.vy), self._vxz[1]
 
+    @vel.setter
+    def vel(self, new_vs):
+        """Install caller-supplied velocity grids (v_x, v_y, v_z) [km/s] (classes.py:1097-1099).
+        The line-of-sight component feeds `optical_depth_rrl` (classes.py:1160-1161) and goes to
+        the device; the transverse ones are kept for the getter."""
+        vx, vy, vz = new_vs
+        shape = (self.nx, self.ny, self.nz)
+        vx, vy, vz = (np.asarray(v, dtype=np.float64) for v in (vx, vy, vz))
+        if not (vx.shape == vy.shape == vz.shape == shape):
+            raise ValueError("velocity grids must have the model's shape {}".format(shape))
+        self.engine.replace_field(self.device_fields, "vy", vy)
+        self._vxz = (vx.copy(), vz.copy())
+        self._invalidate()
+
     # ------------------------------------------------------------------ K1 cache ----
     SCAN_CACHE_EPOCHS = 64       # base-map pairs kept on the device (2 x P x 8 B each)
+
+    def _model_tavg(self):
+        """T_avg = nanmean_y(T where T > 0) (classes.py:1471-1472, 1254-1256): depends on
+        neither frequency nor epoch, so it is evaluated once per model (and again after the
+        temperature grid is replaced through its setter)."""
+        if self._tavg is None:
+            self._tavg = self.engine.tavg(self.device_fields)
+        return self._tavg
 
     def prefetch_epochs(self, times_s):
         """Scan the grid for several model times at once (8-32 epochs share one pass over
@@ -530,7 +557,9 @@ class JetModel:
         # keeps its FIRST epochs, the ones a caller walking the list in order needs next
         todo = todo[:self.SCAN_CACHE_EPOCHS]
         dev = self.device_fields
-        sumA, em, tavg = self.engine.ff_scan(dev, self._rjp_bursts(), todo, self.gff_mode)
+        self._model_tavg()
+        sumA, em, _ = self.engine.ff_scan(dev, self._rjp_bursts(), todo, self.gff_mode,
+                                          want_tavg=False)
         for i, t in enumerate(todo):
             # own copies: a slice would keep the whole [E, P] result alive
             self._scan_cache[t] = (sumA[i:i + 1].clone(), em[i:i + 1].clone())
@@ -539,13 +568,12 @@ class JetModel:
             if old in todo:
                 break
             del self._scan_cache[old]
-        self._tavg = tavg
 
     def _base_maps(self):
         t = float(self.time)
         if t not in self._scan_cache:
             self.prefetch_epochs([t])
-        return self._scan_cache[t] + (self._tavg,)
+        return self._scan_cache[t] + (self._model_tavg(),)
 
     def _map(self, tensor, lead=()):
         return _to_host(tensor).reshape(*lead, self.nx, self.nz)
@@ -681,7 +709,7 @@ class JetModel:
         cfl, hnu = E.rrl_channel_coeffs(freqs, self.csize, self.params["target"]["dist"])
         if intensity:
             cfl = cfl / (E.solid_angle(self.csize, self.params["target"]["dist"]) / 1e-26)
-        flux, _ = self.engine.rrl_maps(tau_rrl, tau_ff, self._tavg, flux_ff, cfl, hnu,
+        flux, _ = self.engine.rrl_maps(tau_rrl, tau_ff, self._model_tavg(), flux_ff, cfl, hnu,
                                        want_ftot=False)
         out = self._map(flux, (F,))
         self._dev_product = flux.reshape(F, self.nx, self.nz)
@@ -1076,10 +1104,12 @@ class Pipeline:
                 if not dryrun and run.radiative_transfer:
                     t_now = float(self.model.time)
                     if t_now in pending:
-                        # one pass over HBM serves up to 32 of the epochs still to come
+                        # one pass over HBM serves up to 32 of the epochs still to come; the
+                        # whole chunk leaves the list, so the next pass starts where this one
+                        # ended (ceil(N / 32) scans for N epochs)
                         k = pending.index(t_now)
                         self.model.prefetch_epochs(pending[k:k + 32])
-                        del pending[:k + 1]
+                        del pending[:k + 32]
                     self._radiative_transfer(idx, run, clobber)
             except KeyboardInterrupt:
                 self.log.add_entry("ERROR", "Pipeline interrupted by user, saving state")
@@ -1095,7 +1125,9 @@ class Pipeline:
             run.completed = True                                   # classes.py:2853
 
         failures = [failure] if failure else []
-        if world > 1:
+        if dist is not None:
+            # (inside an initialised group of ANY size, so that a one-rank RCCL group exercises
+            # exactly the collectives an eight-rank one does)
             # one small object gather: {run index: (results, completed)} + the failure (if
             # any) of every rank
             local = {"runs": {i: (self.runs[i].results, self.runs[i].completed) for i in mine},
@@ -1112,7 +1144,7 @@ class Pipeline:
         if rank == 0:
             self.save(self.save_file)
             self.model.save(self.model_file)
-        if world > 1:
+        if dist is not None:
             dist.barrier()
         if failures:
             f = failures[0]

@@ -9,11 +9,16 @@
 // registers and keeps FP64 accumulators.  The y-range is split over workgroups so small maps
 // still fill 256 CUs; partial sums go to a workspace and a tiny second kernel reduces them in
 // a fixed order (bitwise reproducible, no atomics).
-// HBM-bound: algorithmic bytes = 5 fields * sizeof(T) per cell per epoch tile in the wide
-// layout, 3 fields * sizeof(T) in the compact layout (rjp_fields.d_em0 = (n x)^2 pf with the
-// jet flag in its sign bit, temp, ts).
+// HBM-bound: algorithmic bytes per cell and epoch tile = 5 fields * sizeof(T) in the wide layout,
+// 3 fields in the compact layout (rjp_fields.d_em0 = (n x)^2 pf with the jet flag in its sign
+// bit, temp, ts) and 2 fields in the tau layout (rjp_fields.d_a0 = em0 T^-1.5|-1.35 -- every
+// factor of a cell's optical depth that depends on neither frequency nor epoch -- and ts; a
+// third, em0, only when emission-measure maps are asked for as well).  The tau layout never
+// touches the temperature: T_avg = nanmean_y(T > 0) does not depend on the epoch either
+// (classes.py:1471-1472) and has its own one-off pass, tavg_kernel.
 #include <algorithm>
 #include <cmath>
+#include <type_traits>
 #include <vector>
 
 #include "rjp_device.h"
@@ -30,6 +35,14 @@ struct FieldPtrs {
   const int32_t* ylo;      // optional occupied y-range per sightline (nullptr = all rows)
   const int32_t* yhi;
   const T* em0;            // compact layout: (|nd| xi)^2 pf, sign bit = red jet
+  const T* a0;             // tau layout: em0 * T^-1.5 (or T^-1.35), sign bit = red jet
+};
+
+// which fields a scan kernel streams
+enum : int {
+  LAY_WIDE = 0,            // nd, xi, temp, pf, ts
+  LAY_CMP = 1,             // em0, temp, ts
+  LAY_TAU = 2              // a0, ts (+ em0 with emission-measure maps); no T_avg sums
 };
 
 // A NaN launch time never reaches the jet: its cell is given chi = 1 here (a launch at
@@ -69,17 +82,21 @@ constexpr int kMaxTile = 32;     // largest epoch tile (uniformly spaced epochs,
 // 4-wide (f32) lanes on the wide layout: 2 rows (8 cells per batch, 166 VGPRs; 4 rows need
 // 256 + AGPR spills); on the compact layout 4 rows still fit 3 waves/SIMD and are 3 % faster
 // ... and 2 rows in the power-law Gaunt mode, whose T^-1.35 chains are batched by eight cells
-__host__ __device__ constexpr int unroll_for(int vec, int et, bool compact, int mode) {
+#ifndef RJP_UNROLL_TAU
+#define RJP_UNROLL_TAU 4      /* rows in flight of the single-epoch scan on the tau layout */
+#endif
+__host__ __device__ constexpr int unroll_for(int vec, int et, int lay, int mode) {
   return vec * et >= 16 ? 1
          : vec * et >= 8 ? 2
-         : vec == 4 && (!compact || mode == RJP_GFF_POWERLAW) ? 2 : RJP_UNROLL_BASE;
+         : lay == LAY_TAU ? (vec * et >= 4 ? 2 : RJP_UNROLL_TAU)
+         : vec == 4 && (lay == LAY_WIDE || mode == RJP_GFF_POWERLAW) ? 2 : RJP_UNROLL_BASE;
 }
 // The fast T^-1.35 (power-law Gaunt mode) is a property of the KERNEL, not of a row batch:
 // the unrolled body and the row tail must evaluate a cell identically, or a scan would depend
 // on where its y-range starts.  Every tile uses it (the Halley form needs ~8 live registers,
 // so the 16- and 32-epoch tiles afford it too; they used to call libm's pow out of line).
-__host__ __device__ constexpr bool fast_power_law(int vec, int et, bool compact, int mode) {
-  (void)vec; (void)et; (void)compact;
+__host__ __device__ constexpr bool fast_power_law(int vec, int et, int lay, int mode) {
+  (void)vec; (void)et; (void)lay;
   return mode == RJP_GFF_POWERLAW;
 }
 
@@ -94,17 +111,35 @@ __host__ __device__ constexpr int nacc(int et) { return 2 * et + 2; }
 template <int VEC, int U>
 struct RowBatch {
   double g0[U][VEC];     // (n x)^2 * ff/areas at chi = 1
-  double tp[U][VEC];     // temperature
+  double a[U][VEC];      // tau layout: g0 * T^-1.5|-1.35 as stored
+  double tp[U][VEC];     // temperature (wide and compact layouts)
   double ts[U][VEC];     // launch time
   bool rj[U][VEC];       // red-jet flag
 };
 
-template <typename T, int VEC, bool BURSTS, bool CMP, int U>
+template <typename T, int VEC, bool BURSTS, int LAY, bool EM, int U>
 __device__ __forceinline__ void load_rows(const FieldPtrs<T>& f, int64_t off, int64_t stride,
                                           RowBatch<VEC, U>& rb) {
   auto& g0 = rb.g0; auto& tp = rb.tp; auto& ts = rb.ts; auto& rj = rb.rj;
   // g and the jet flag: from three wide fields or from the one compact field
-  if constexpr (CMP) {
+  if constexpr (LAY == LAY_TAU) {
+    auto& a = rb.a;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t o = off + u * stride;
+      load_vec(f.a0 + o, a[u]);
+      if (EM) load_vec(f.em0 + o, g0[u]);
+      if (BURSTS) load_vec(f.ts + o, ts[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) {
+        rj[u][v] = signbit_d(a[u][v]);
+        a[u][v] = fabs(a[u][v]);
+        if (EM) g0[u][v] = fabs(g0[u][v]);
+      }
+  } else if constexpr (LAY == LAY_CMP) {
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const int64_t o = off + u * stride;
@@ -141,7 +176,7 @@ __device__ __forceinline__ void load_rows(const FieldPtrs<T>& f, int64_t off, in
   }
 }
 
-template <typename T, int VEC, int ET, int MODE, bool BURSTS, bool UNIF, bool CMP, bool EM, int U>
+template <typename T, int VEC, int ET, int MODE, bool BURSTS, bool UNIF, int LAY, bool EM, int U>
 __device__ __forceinline__ void compute_rows(const RowBatch<VEC, U>& rb, const BurstsDev& b,
                                              const EpochTile<ET>& ep, double (&accA)[ET][VEC],
                                              double (&accE)[EM ? ET : 1][VEC],
@@ -180,9 +215,38 @@ __device__ __forceinline__ void compute_rows(const RowBatch<VEC, U>& rb, const B
     chi_batch<NB, sizeof(T) == 4>(b, red, tl, chi);
   }
 
+  if constexpr (LAY == LAY_TAU) {
+    // the temperature power is part of the stored field (exactly the product the other
+    // layouts form below: g0 * tpow), T_avg has its own pass: what is left per cell is the
+    // mask and one FMA per epoch and sum
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) {
+        if (BURSTS) {
+          const bool ok = ts[u][v] == ts[u][v];
+          const double am = nan_to_zero<true>(poison_unless(rb.a[u][v], ok));
+          const double gm = EM ? nan_to_zero<true>(poison_unless(g0[u][v], ok)) : 0.0;
+#pragma unroll
+          for (int e = 0; e < ET; ++e) {
+            const double c = chi[(e * U + u) * VEC + v];
+            const double c2 = c * c;
+            if (EM) accE[e][v] = __builtin_fma(gm, c2, accE[e][v]);
+            accA[e][v] = __builtin_fma(am, c2, accA[e][v]);
+          }
+        } else {
+          if (EM) accE[0][v] += nan_to_zero<true>(g0[u][v]);
+          accA[0][v] += nan_to_zero<true>(rb.a[u][v]);
+        }
+      }
+    }
+    return;
+  }
+
   // temperature powers of the whole batch: T^-1.5 (scalar Gaunt) or T^-1.35 = T^-1.5 * T^0.15
   // (power law)
-  constexpr bool kFastPowerLaw = fast_power_law(VEC, ET, CMP, MODE);
+  constexpr bool kFastPowerLaw = fast_power_law(VEC, ET, LAY, MODE);
+  constexpr bool CMP = LAY != LAY_WIDE;
   double tpw[U][VEC];
   if constexpr (kFastPowerLaw && (U * VEC) % 4 == 0 && U * VEC > 4) {
     // groups of four: the log/exp chains are long, interleaving all eight costs a wave of
@@ -233,24 +297,24 @@ __device__ __forceinline__ void compute_rows(const RowBatch<VEC, U>& rb, const B
   }
 }
 
-template <typename T, int VEC, int ET, int MODE, bool BURSTS, bool UNIF, bool CMP, bool EM, int U>
+template <typename T, int VEC, int ET, int MODE, bool BURSTS, bool UNIF, int LAY, bool EM, int U>
 __device__ __forceinline__ void scan_rows(const FieldPtrs<T>& f, int64_t off, int64_t stride,
                                           const BurstsDev& b, const EpochTile<ET>& ep,
                                           double (&accA)[ET][VEC],
                                           double (&accE)[EM ? ET : 1][VEC],
                                           double (&accT)[VEC], int (&cnt)[VEC]) {
   RowBatch<VEC, U> rb;
-  load_rows<T, VEC, BURSTS, CMP, U>(f, off, stride, rb);
-  compute_rows<T, VEC, ET, MODE, BURSTS, UNIF, CMP, EM, U>(rb, b, ep, accA, accE, accT, cnt);
+  load_rows<T, VEC, BURSTS, LAY, EM, U>(f, off, stride, rb);
+  compute_rows<T, VEC, ET, MODE, BURSTS, UNIF, LAY, EM, U>(rb, b, ep, accA, accE, accT, cnt);
 }
 
 // EM = false (flux-vs-time sweeps: no emission-measure maps wanted) drops the second
 // accumulator set: fewer registers, one more wave per SIMD on the 16-epoch tiles.
-template <typename T, int VEC, int ET, int MODE, bool BURSTS, bool UNIF, bool CMP, bool EM>
+template <typename T, int VEC, int ET, int MODE, bool BURSTS, bool UNIF, int LAY, bool EM>
 __global__ __launch_bounds__(kBlock) void ff_scan_kernel(
     FieldPtrs<T> f, int ny, int nz, int64_t nchunks, int64_t npix, int ylen, int nsplit,
     BurstsDev b, EpochTile<ET> ep, double* __restrict__ ws) {
-  constexpr int kUnroll = unroll_for(VEC, ET, CMP, MODE);
+  constexpr int kUnroll = unroll_for(VEC, ET, LAY, MODE);
   // 1-D grid with the y-split index fastest: workgroups that run together stream consecutive
   // y-ranges of the same sightlines, i.e. neighbouring memory, instead of ranges 16 MiB apart
   // (n_y n_z elements) -- +5 % on cfg4 (6.0 -> 6.3 TB/s)
@@ -295,11 +359,11 @@ __global__ __launch_bounds__(kBlock) void ff_scan_kernel(
   // (issuing the next half-batch's loads before computing the current one was tried: 165
   // VGPRs, 3 waves/SIMD, 7 % slower)
   for (; y + kUnroll <= y1; y += kUnroll) {
-    scan_rows<T, VEC, ET, MODE, BURSTS, UNIF, CMP, EM, kUnroll>(f, off, stride, b, ep, accA, accE, accT, cnt);
+    scan_rows<T, VEC, ET, MODE, BURSTS, UNIF, LAY, EM, kUnroll>(f, off, stride, b, ep, accA, accE, accT, cnt);
     off += kUnroll * stride;
   }
   for (; y < y1; ++y) {
-    scan_rows<T, VEC, ET, MODE, BURSTS, UNIF, CMP, EM, 1>(f, off, stride, b, ep, accA, accE, accT, cnt);
+    scan_rows<T, VEC, ET, MODE, BURSTS, UNIF, LAY, EM, 1>(f, off, stride, b, ep, accA, accE, accT, cnt);
     off += stride;
   }
 
@@ -313,10 +377,12 @@ __global__ __launch_bounds__(kBlock) void ff_scan_kernel(
       if (EM) w[(int64_t)(ET + e) * npix + v] = accE[e][v];
     }
   }
+  if constexpr (LAY != LAY_TAU) {     // (the tau layout keeps no temperature sums)
 #pragma unroll
-  for (int v = 0; v < VEC; ++v) {
-    w[(int64_t)(2 * ET) * npix + v] = accT[v];
-    w[(int64_t)(2 * ET + 1) * npix + v] = (double)cnt[v];
+    for (int v = 0; v < VEC; ++v) {
+      w[(int64_t)(2 * ET) * npix + v] = accT[v];
+      w[(int64_t)(2 * ET + 1) * npix + v] = (double)cnt[v];
+    }
   }
 }
 
@@ -332,7 +398,9 @@ __global__ __launch_bounds__(kBlock) void ff_scan_kernel(
 // of row y + 1; the LDS image is wave-base + 16 * lane.  No barrier anywhere: a wave reads
 // only what it requested itself, behind its own counted s_waitcnt vmcnt.
 // Needs f64 fields, an even n_z and 16-byte aligned field pointers (what 2-wide lanes need).
-template <bool CMP> struct TileDma { static constexpr int NF = CMP ? 3 : 5; };
+template <int LAY, bool EM> struct TileDma {
+  static constexpr int NF = LAY == LAY_TAU ? (EM ? 3 : 2) : LAY == LAY_CMP ? 3 : 5;
+};
 
 __device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst) {
   unsigned keep;
@@ -341,11 +409,11 @@ __device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst) {
                : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
 }
 
-template <int ET, int MODE, bool CMP, bool EM>
+template <int ET, int MODE, int LAY, bool EM>
 __global__ __launch_bounds__(kBlock) void ff_scan_tile_kernel(
     FieldPtrs<double> f, int ny, int nz, int64_t npix, int ylen, int nsplit, BurstsDev b,
     EpochTile<ET> ep, double* __restrict__ ws) {
-  constexpr int NF = TileDma<CMP>::NF;
+  constexpr int NF = TileDma<LAY, EM>::NF;
   constexpr int kWaves = kBlock / RJP_WAVE;
   // [wave][buffer][field][row 0: 64 sightlines | row 1: 64 sightlines]
   __shared__ double s_rows[kWaves][2][NF][2 * RJP_WAVE];
@@ -383,7 +451,8 @@ __global__ __launch_bounds__(kBlock) void ff_scan_tile_kernel(
   const int half = lane >> 5;                                     // which of the two rows
   const int64_t col = xd * ny * (int64_t)nz + zd;                 // + row * nz
   const double* src[NF];
-  if (CMP) { src[0] = f.em0; src[1] = f.temp; src[2] = f.ts; }
+  if constexpr (LAY == LAY_TAU) { src[0] = f.a0; src[1] = f.ts; if constexpr (EM) src[2] = f.em0; }
+  else if constexpr (LAY == LAY_CMP) { src[0] = f.em0; src[1] = f.temp; src[2] = f.ts; }
   else { src[0] = f.nd; src[1] = f.xi; src[2] = f.temp; src[3] = f.pf; src[4] = f.ts; }
   typedef __attribute__((address_space(3))) double lds_double;
   const unsigned lds0 = (unsigned)(uintptr_t)(lds_double*)&s_rows[wave][0][0][0];
@@ -398,7 +467,13 @@ __global__ __launch_bounds__(kBlock) void ff_scan_tile_kernel(
   auto one_row = [&](int buf, int r) __attribute__((always_inline)) {
     RowBatch<1, 1> rb;
     const double* q = &s_rows[wave][buf][0][r * RJP_WAVE + lane];
-    if (CMP) {
+    if constexpr (LAY == LAY_TAU) {
+      const double a = q[0];
+      rb.ts[0][0] = q[2 * RJP_WAVE];
+      rb.rj[0][0] = signbit_d(a);
+      rb.a[0][0] = fabs(a);
+      if constexpr (EM) rb.g0[0][0] = fabs(q[4 * RJP_WAVE]);
+    } else if constexpr (LAY == LAY_CMP) {
       const double g = q[0];
       rb.tp[0][0] = q[2 * RJP_WAVE];
       rb.ts[0][0] = q[4 * RJP_WAVE];
@@ -412,7 +487,7 @@ __global__ __launch_bounds__(kBlock) void ff_scan_tile_kernel(
       rb.g0[0][0] = n0 * n0 * pf;
       rb.rj[0][0] = signbit_d(nd);
     }
-    compute_rows<double, 1, ET, MODE, true, true, CMP, EM, 1>(rb, b, ep, accA, accE, accT, cnt);
+    compute_rows<double, 1, ET, MODE, true, true, LAY, EM, 1>(rb, b, ep, accA, accE, accT, cnt);
   };
 
   if (y0 < y1) {
@@ -422,7 +497,8 @@ __global__ __launch_bounds__(kBlock) void ff_scan_tile_kernel(
       if (y + 2 < y1) {
         request(y + 2, buf ^ 1);
         // all but the NF requests just issued have landed
-        if (NF == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+        if (NF == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        else if (NF == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
       } else {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -442,8 +518,93 @@ __global__ __launch_bounds__(kBlock) void ff_scan_tile_kernel(
     w[(int64_t)e * npix] = accA[e][0];
     if (EM) w[(int64_t)(ET + e) * npix] = accE[e][0];
   }
-  w[(int64_t)(2 * ET) * npix] = accT[0];
-  w[(int64_t)(2 * ET + 1) * npix] = (double)cnt[0];
+  if constexpr (LAY != LAY_TAU) {
+    w[(int64_t)(2 * ET) * npix] = accT[0];
+    w[(int64_t)(2 * ET + 1) * npix] = (double)cnt[0];
+  }
+}
+
+// ---- T_avg = nanmean_y(T where T > 0) (classes.py:1471-1472, 1484-1485) ----------------------
+// Depends on neither frequency nor epoch: one pass over the temperature field per MODEL (the
+// tau layout's scans never read T).  Same lane / y-range structure and the same summation
+// order as the single-epoch ff_scan_kernel, so the map is bit-identical to the one that kernel
+// derives on the wide and compact layouts.  Partials: ws[split][0|1][pixel].
+template <typename T, int VEC>
+__global__ __launch_bounds__(kBlock) void tavg_kernel(FieldPtrs<T> f, int ny, int nz,
+                                                      int64_t nchunks, int64_t npix, int ylen,
+                                                      int nsplit, double* __restrict__ ws) {
+  constexpr int U = 8;
+  const int split = (int)(blockIdx.x % (unsigned)nsplit);
+  const int64_t c = (int64_t)(blockIdx.x / (unsigned)nsplit) * kBlock + threadIdx.x;
+  const bool lane_live = c < nchunks;
+  const int64_t p0 = c * VEC;
+  int y0 = split * ylen;
+  int y1 = min(ny, y0 + ylen);
+  if (f.ylo) {
+    __shared__ int s_lo, s_hi;
+    if (threadIdx.x == 0) { s_lo = ny; s_hi = 0; }
+    __syncthreads();
+    if (lane_live) {
+      int lo = ny, hi = 0;
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) { lo = min(lo, f.ylo[p0 + v]); hi = max(hi, f.yhi[p0 + v]); }
+      if (lo < hi) { atomicMin(&s_lo, lo); atomicMax(&s_hi, hi); }
+    }
+    __syncthreads();
+    y0 = max(y0, s_lo);
+    y1 = min(y1, s_hi);
+  }
+  if (!lane_live) return;
+  const int64_t x = p0 / nz;
+  const int z = (int)(p0 - x * nz);
+  double accT[VEC];
+  int cnt[VEC];
+#pragma unroll
+  for (int v = 0; v < VEC; ++v) { accT[v] = 0.0; cnt[v] = 0; }
+  int64_t off = (x * ny + y0) * (int64_t)nz + z;
+  int y = y0;
+  for (; y + U <= y1; y += U) {
+    double tp[U][VEC];
+#pragma unroll
+    for (int u = 0; u < U; ++u) load_vec(f.temp + off + (int64_t)u * nz, tp[u]);
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) {
+        accT[v] += __builtin_fmax(tp[u][v], 0.0);
+        cnt[v] += tp[u][v] > 0.0 ? 1 : 0;
+      }
+    off += (int64_t)U * nz;
+  }
+  for (; y < y1; ++y) {
+    double tp[VEC];
+    load_vec(f.temp + off, tp);
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) {
+      accT[v] += __builtin_fmax(tp[v], 0.0);
+      cnt[v] += tp[v] > 0.0 ? 1 : 0;
+    }
+    off += nz;
+  }
+  double* w = ws + (int64_t)split * 2 * npix + p0;
+#pragma unroll
+  for (int v = 0; v < VEC; ++v) {
+    w[v] = accT[v];
+    w[npix + v] = (double)cnt[v];
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void tavg_reduce_kernel(const double* __restrict__ ws,
+                                                             int nsplit, int64_t npix,
+                                                             double* __restrict__ tavg) {
+  const int64_t p = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (p >= npix) return;
+  double t = 0.0, n = 0.0;
+  for (int s = 0; s < nsplit; ++s) {
+    t += ws[((int64_t)s * 2) * npix + p];
+    n += ws[((int64_t)s * 2 + 1) * npix + p];
+  }
+  tavg[p] = t / n;              // 0/0 = NaN on empty sightlines = nanmean of all-NaN
 }
 
 // Fixed-order reduction over the y-splits; writes the base maps of epochs [e0, e0+et).
@@ -573,14 +734,15 @@ hipError_t y_bounds_launch(const rjp_fields* fl, int32_t* ylo, int32_t* yhi, hip
   if (fl->dtype == RJP_F64) {
     FieldPtrs<double> f{(const double*)fl->d_nd, (const double*)fl->d_xi,
                         (const double*)fl->d_temp, (const double*)fl->d_pf, nullptr, nullptr,
-                        nullptr, (const double*)fl->d_em0};
+                        nullptr, (const double*)fl->d_em0, nullptr};
     if (fl->d_em0)
       hipLaunchKernelGGL((y_bounds_kernel<double, true>), grid, blk, 0, st, f, fl->ny, fl->nz, npix, ylo, yhi);
     else
       hipLaunchKernelGGL((y_bounds_kernel<double, false>), grid, blk, 0, st, f, fl->ny, fl->nz, npix, ylo, yhi);
   } else {
     FieldPtrs<float> f{(const float*)fl->d_nd, (const float*)fl->d_xi, (const float*)fl->d_temp,
-                       (const float*)fl->d_pf, nullptr, nullptr, nullptr, (const float*)fl->d_em0};
+                       (const float*)fl->d_pf, nullptr, nullptr, nullptr, (const float*)fl->d_em0,
+                       nullptr};
     if (fl->d_em0)
       hipLaunchKernelGGL((y_bounds_kernel<float, true>), grid, blk, 0, st, f, fl->ny, fl->nz, npix, ylo, yhi);
     else
@@ -619,7 +781,7 @@ hipError_t ff_cells_launch(const rjp_fields* fl, const rjp_bursts* hb, const dou
   auto go = [&](auto tag) {
     using T = decltype(tag);
     FieldPtrs<T> f{(const T*)fl->d_nd, (const T*)fl->d_xi, (const T*)fl->d_temp,
-                   (const T*)fl->d_pf, (const T*)fl->d_ts, nullptr, nullptr, nullptr};
+                   (const T*)fl->d_pf, (const T*)fl->d_ts, nullptr, nullptr, nullptr, nullptr};
     if (mode == RJP_GFF_SCALAR) {
       if (bursts) hipLaunchKernelGGL((ff_cells_kernel<T, 0, true>), grid, blk, 0, st, f, n, b, time_s, d_ctau, nchan, out);
       else hipLaunchKernelGGL((ff_cells_kernel<T, 0, false>), grid, blk, 0, st, f, n, b, time_s, d_ctau, nchan, out);
@@ -690,7 +852,7 @@ int ff_scan_vec(const rjp_fields* fl) {
   const int full = fl->dtype == RJP_F64 ? 2 : 4;
   const size_t esz = (size_t)fl->dtype;
   bool ok = (fl->nz % full) == 0;
-  const void* ptrs[6] = {fl->d_nd, fl->d_xi, fl->d_temp, fl->d_pf, fl->d_ts, fl->d_em0};
+  const void* ptrs[7] = {fl->d_nd, fl->d_xi, fl->d_temp, fl->d_pf, fl->d_ts, fl->d_em0, fl->d_a0};
   for (const void* p : ptrs)
     if (p && ((uintptr_t)p % 16) != 0) ok = false;
   (void)esz;
@@ -780,19 +942,27 @@ static bool tile_dma_ok(const rjp_fields* fl) {
   static int off = -1;
   if (off < 0) off = debug_env("RJP_NO_TILE_DMA") ? 1 : 0;
   if (off || fl->dtype != RJP_F64 || (fl->nz % 2) != 0) return false;
-  const void* ptrs[6] = {fl->d_nd, fl->d_xi, fl->d_temp, fl->d_pf, fl->d_ts, fl->d_em0};
+  const void* ptrs[7] = {fl->d_nd, fl->d_xi, fl->d_temp, fl->d_pf, fl->d_ts, fl->d_em0, fl->d_a0};
   for (const void* q : ptrs)
     if (q && ((uintptr_t)q % 16) != 0) return false;
   return (int64_t)fl->nx * fl->nz >= 2;
 }
 
-template <typename T, int VEC, int ET, int MODE, bool BURSTS, bool CMP>
+// The layout a scan of `fl` in Gaunt mode `mode` uses: the tau layout when its field was built
+// for that mode (f64 storage; with EM maps it also needs em0), else compact, else wide.
+static int scan_layout(const rjp_fields* fl, int mode, bool want_em) {
+  if (fl->d_a0 && fl->a0_mode == mode && fl->dtype == RJP_F64 && (!want_em || fl->d_em0))
+    return LAY_TAU;
+  return fl->d_em0 ? LAY_CMP : LAY_WIDE;
+}
+
+template <typename T, int VEC, int ET, int MODE, bool BURSTS, int LAY>
 static hipError_t launch_tile(const rjp_fields* fl, const BurstsDev& b, const double* t,
                               const UnifDev& un, int nsplit, int ylen, double* ws, bool want_em,
                               hipStream_t st) {
   FieldPtrs<T> f{(const T*)fl->d_nd, (const T*)fl->d_xi, (const T*)fl->d_temp,
                  (const T*)fl->d_pf, (const T*)fl->d_ts, fl->d_ylo, fl->d_yhi,
-                 (const T*)fl->d_em0};
+                 (const T*)fl->d_em0, (const T*)fl->d_a0};
   EpochTile<ET> ep;
   for (int e = 0; e < ET; ++e) ep.t[e] = t[e];
   ep.un = un;
@@ -807,12 +977,12 @@ static hipError_t launch_tile(const rjp_fields* fl, const BurstsDev& b, const do
       FieldPtrs<double> fd{(const double*)fl->d_nd, (const double*)fl->d_xi,
                            (const double*)fl->d_temp, (const double*)fl->d_pf,
                            (const double*)fl->d_ts, fl->d_ylo, fl->d_yhi,
-                           (const double*)fl->d_em0};
+                           (const double*)fl->d_em0, (const double*)fl->d_a0};
       if (want_em)
-        hipLaunchKernelGGL((ff_scan_tile_kernel<ET, MODE, CMP, true>), grid, dim3(kBlock), 0, st,
+        hipLaunchKernelGGL((ff_scan_tile_kernel<ET, MODE, LAY, true>), grid, dim3(kBlock), 0, st,
                            fd, fl->ny, fl->nz, npix, ylen, nsplit, b, ep, ws);
       else
-        hipLaunchKernelGGL((ff_scan_tile_kernel<ET, MODE, CMP, false>), grid, dim3(kBlock), 0, st,
+        hipLaunchKernelGGL((ff_scan_tile_kernel<ET, MODE, LAY, false>), grid, dim3(kBlock), 0, st,
                            fd, fl->ny, fl->nz, npix, ylen, nsplit, b, ep, ws);
       return hipGetLastError();
     }
@@ -821,59 +991,60 @@ static hipError_t launch_tile(const rjp_fields* fl, const BurstsDev& b, const do
     // 32 epochs per pass: recurrence only
     if (ep.un.on) {
       if (want_em)
-        hipLaunchKernelGGL((ff_scan_kernel<T, VEC, ET, MODE, true, true, CMP, true>), grid,
+        hipLaunchKernelGGL((ff_scan_kernel<T, VEC, ET, MODE, true, true, LAY, true>), grid,
                            dim3(kBlock), 0, st, f, fl->ny, fl->nz, nchunks, npix, ylen, nsplit, b, ep, ws);
       else
-        hipLaunchKernelGGL((ff_scan_kernel<T, VEC, ET, MODE, true, true, CMP, false>), grid,
+        hipLaunchKernelGGL((ff_scan_kernel<T, VEC, ET, MODE, true, true, LAY, false>), grid,
                            dim3(kBlock), 0, st, f, fl->ny, fl->nz, nchunks, npix, ylen, nsplit, b, ep, ws);
       return hipGetLastError();
     }
   } else if constexpr (BURSTS && ET >= 4 && (sizeof(T) == 8 || ET == 16)) {
     if (ep.un.on) {
       if (want_em)
-        hipLaunchKernelGGL((ff_scan_kernel<T, VEC, ET, MODE, true, true, CMP, true>), grid,
+        hipLaunchKernelGGL((ff_scan_kernel<T, VEC, ET, MODE, true, true, LAY, true>), grid,
                            dim3(kBlock), 0, st, f, fl->ny, fl->nz, nchunks, npix, ylen, nsplit, b, ep, ws);
       else
-        hipLaunchKernelGGL((ff_scan_kernel<T, VEC, ET, MODE, true, true, CMP, false>), grid,
+        hipLaunchKernelGGL((ff_scan_kernel<T, VEC, ET, MODE, true, true, LAY, false>), grid,
                            dim3(kBlock), 0, st, f, fl->ny, fl->nz, nchunks, npix, ylen, nsplit, b, ep, ws);
       return hipGetLastError();
     }
   }
   if constexpr (ET <= 8) {
     // single-epoch and generic tiles always carry the emission measure (cheap there)
-    if (want_em || ET < 4)
-      hipLaunchKernelGGL((ff_scan_kernel<T, VEC, ET, MODE, BURSTS, false, CMP, true>), grid,
+    // (on the tau layout the EM accumulators cost a third field: never carried unasked)
+    if (want_em || (ET < 4 && LAY != LAY_TAU))
+      hipLaunchKernelGGL((ff_scan_kernel<T, VEC, ET, MODE, BURSTS, false, LAY, true>), grid,
                          dim3(kBlock), 0, st, f, fl->ny, fl->nz, nchunks, npix, ylen, nsplit, b, ep, ws);
     else
-      hipLaunchKernelGGL((ff_scan_kernel<T, VEC, ET, MODE, BURSTS, false, CMP, false>), grid,
+      hipLaunchKernelGGL((ff_scan_kernel<T, VEC, ET, MODE, BURSTS, false, LAY, false>), grid,
                          dim3(kBlock), 0, st, f, fl->ny, fl->nz, nchunks, npix, ylen, nsplit, b, ep, ws);
     return hipGetLastError();
   }
   return hipErrorInvalidValue;       // a 16-epoch tile that is not uniform: launcher bug
 }
 
-template <typename T, int VEC, int MODE, bool CMP>
+template <typename T, int VEC, int MODE, int LAY>
 static hipError_t dispatch_et(const rjp_fields* fl, const BurstsDev& b, bool bursts,
                               const double* t, const UnifDev& un, int et, int nsplit, int ylen,
                               double* ws, bool want_em, hipStream_t st) {
-  if (!bursts) return launch_tile<T, VEC, 1, MODE, false, CMP>(fl, b, t, un, nsplit, ylen, ws, want_em, st);
+  if (!bursts) return launch_tile<T, VEC, 1, MODE, false, LAY>(fl, b, t, un, nsplit, ylen, ws, want_em, st);
   switch (et) {
-    case 1: return launch_tile<T, VEC, 1, MODE, true, CMP>(fl, b, t, un, nsplit, ylen, ws, want_em, st);
-    case 2: return launch_tile<T, VEC, 2, MODE, true, CMP>(fl, b, t, un, nsplit, ylen, ws, want_em, st);
-    case 4: return launch_tile<T, VEC, 4, MODE, true, CMP>(fl, b, t, un, nsplit, ylen, ws, want_em, st);
+    case 1: return launch_tile<T, VEC, 1, MODE, true, LAY>(fl, b, t, un, nsplit, ylen, ws, want_em, st);
+    case 2: return launch_tile<T, VEC, 2, MODE, true, LAY>(fl, b, t, un, nsplit, ylen, ws, want_em, st);
+    case 4: return launch_tile<T, VEC, 4, MODE, true, LAY>(fl, b, t, un, nsplit, ylen, ws, want_em, st);
     case 8:
       // 4 sightlines x 8 epochs x 2 sums does not fit 256 VGPRs: the launcher caps the
       // epoch tile at 4 for 4-wide (f32) lanes
       if constexpr (VEC == 4) return hipErrorInvalidValue;
-      else return launch_tile<T, VEC, 8, MODE, true, CMP>(fl, b, t, un, nsplit, ylen, ws, want_em, st);
+      else return launch_tile<T, VEC, 8, MODE, true, LAY>(fl, b, t, un, nsplit, ylen, ws, want_em, st);
     case 16:
       // only the uniform-epoch recurrence keeps 16 epochs of state in registers
       if constexpr (VEC == 1)
-        return launch_tile<T, VEC, 16, MODE, true, CMP>(fl, b, t, un, nsplit, ylen, ws, want_em, st);
+        return launch_tile<T, VEC, 16, MODE, true, LAY>(fl, b, t, un, nsplit, ylen, ws, want_em, st);
       else return hipErrorInvalidValue;
     case 32:
       if constexpr (VEC == 1)
-        return launch_tile<T, VEC, 32, MODE, true, CMP>(fl, b, t, un, nsplit, ylen, ws, want_em, st);
+        return launch_tile<T, VEC, 32, MODE, true, LAY>(fl, b, t, un, nsplit, ylen, ws, want_em, st);
       else return hipErrorInvalidValue;
   }
   return hipErrorInvalidValue;
@@ -883,14 +1054,20 @@ template <typename T, int VEC>
 static hipError_t dispatch_mode(const rjp_fields* fl, const BurstsDev& b, bool bursts,
                                 int mode, const double* t, const UnifDev& un, int et,
                                 int nsplit, int ylen, double* ws, bool want_em, hipStream_t st) {
-  if (fl->d_em0) {                                  // compact layout attached
+  const int lay = scan_layout(fl, mode, want_em);
+  if constexpr (sizeof(T) == 8 && VEC <= 2) {
+    // tau layout: the Gaunt mode is baked into the field, one kernel serves both
+    if (lay == LAY_TAU)
+      return dispatch_et<T, VEC, RJP_GFF_SCALAR, LAY_TAU>(fl, b, bursts, t, un, et, nsplit, ylen, ws, want_em, st);
+  }
+  if (lay == LAY_CMP) {                             // compact layout attached
     if (mode == RJP_GFF_SCALAR)
-      return dispatch_et<T, VEC, RJP_GFF_SCALAR, true>(fl, b, bursts, t, un, et, nsplit, ylen, ws, want_em, st);
-    return dispatch_et<T, VEC, RJP_GFF_POWERLAW, true>(fl, b, bursts, t, un, et, nsplit, ylen, ws, want_em, st);
+      return dispatch_et<T, VEC, RJP_GFF_SCALAR, LAY_CMP>(fl, b, bursts, t, un, et, nsplit, ylen, ws, want_em, st);
+    return dispatch_et<T, VEC, RJP_GFF_POWERLAW, LAY_CMP>(fl, b, bursts, t, un, et, nsplit, ylen, ws, want_em, st);
   }
   if (mode == RJP_GFF_SCALAR)
-    return dispatch_et<T, VEC, RJP_GFF_SCALAR, false>(fl, b, bursts, t, un, et, nsplit, ylen, ws, want_em, st);
-  return dispatch_et<T, VEC, RJP_GFF_POWERLAW, false>(fl, b, bursts, t, un, et, nsplit, ylen, ws, want_em, st);
+    return dispatch_et<T, VEC, RJP_GFF_SCALAR, LAY_WIDE>(fl, b, bursts, t, un, et, nsplit, ylen, ws, want_em, st);
+  return dispatch_et<T, VEC, RJP_GFF_POWERLAW, LAY_WIDE>(fl, b, bursts, t, un, et, nsplit, ylen, ws, want_em, st);
 }
 
 static bool tile32_em() {
@@ -968,6 +1145,37 @@ void ff_scan_plan(const rjp_fields* fl, const rjp_bursts* hb, const double* epoc
   }
 }
 
+// T_avg map of the model (one pass over the temperature field).  `ws`: 2 * nsplit * npix doubles
+// (never more than the scan's own workspace: the same y-ranges, 2 planes instead of 4).
+hipError_t tavg_launch(const rjp_fields* fl, double* tavg, double* ws, hipStream_t st) {
+  const int64_t npix = (int64_t)fl->nx * fl->nz;
+  const int vec = ff_scan_vec(fl);
+  const int64_t nchunks = npix / vec;
+  const int nsplit = choose_ysplit(nchunks, fl->ny, 1, npix);
+  const int ylen = (fl->ny + nsplit - 1) / nsplit;
+  dim3 grid((unsigned)(((nchunks + kBlock - 1) / kBlock) * nsplit), 1u);
+  auto go = [&](auto tag, auto vtag) {
+    using T = decltype(tag);
+    constexpr int VEC = decltype(vtag)::value;
+    FieldPtrs<T> f{nullptr, nullptr, (const T*)fl->d_temp, nullptr, nullptr, fl->d_ylo,
+                   fl->d_yhi, nullptr, nullptr};
+    hipLaunchKernelGGL((tavg_kernel<T, VEC>), grid, dim3(kBlock), 0, st, f, fl->ny, fl->nz,
+                       nchunks, npix, ylen, nsplit, ws);
+  };
+  if (fl->dtype == RJP_F64) {
+    if (vec == 2) go(double{}, std::integral_constant<int, 2>{});
+    else go(double{}, std::integral_constant<int, 1>{});
+  } else {
+    if (vec == 4) go(float{}, std::integral_constant<int, 4>{});
+    else go(float{}, std::integral_constant<int, 1>{});
+  }
+  hipError_t err = hipGetLastError();
+  if (err != hipSuccess) return err;
+  hipLaunchKernelGGL(tavg_reduce_kernel, dim3((unsigned)((npix + kBlock - 1) / kBlock)),
+                     dim3(kBlock), 0, st, ws, nsplit, npix, tavg);
+  return hipGetLastError();
+}
+
 // Enqueue the whole scan for n_epochs epochs.  `d_ext` = device copy of pl.ext (nullptr when
 // it is empty).  Returns hipSuccess or the first error.
 hipError_t ff_scan_run(const rjp_fields* fl, const rjp_bursts* hb, const ScanPlan& pl,
@@ -982,6 +1190,16 @@ hipError_t ff_scan_run(const rjp_fields* fl, const rjp_bursts* hb, const ScanPla
   // em = sum (n x)^2 * csize*au/pc * pf  (classes.py:1116-1118)
   const double em_scale = fl->csize_au * 149597870700.0 / 3.085677581491367e+16;
   const unsigned rblocks = (unsigned)((npix + kBlock - 1) / kBlock);
+  if (scan_layout(fl, mode, em != nullptr) == LAY_TAU) {
+    // the tau layout's scans keep no temperature sums: a caller that asks for T_avg with the
+    // scan (instead of once per model through rjp_tavg) gets the separate pass here
+    if (tavg) {
+      if (!fl->d_temp) return hipErrorInvalidValue;
+      hipError_t err = tavg_launch(fl, tavg, ws, st);
+      if (err != hipSuccess) return err;
+      tavg = nullptr;
+    }
+  }
 
   for (size_t k = 0; k < pl.tiles.size(); ++k) {
     const int e0 = pl.tiles[k].e0, et = pl.tiles[k].et;

@@ -93,6 +93,31 @@ hipError_t compact_fields_launch(const rjp_fields* fl, void* d_em0, int64_t* d_n
   return hipGetLastError();
 }
 
+// ---- tau scan layout ------------------------------------------------------------------------
+// a0 = em0 * T^-1.5 (scalar Gaunt factor) or em0 * T^-1.35 (power law): every factor of a
+// cell's free-free optical depth that depends on neither frequency nor epoch
+// (classes.py:1395-1397), formed exactly as K1 forms it on the compact layout (fabs(em0) *
+// tpow), red-jet flag in the sign bit.  f64 storage.
+__global__ __launch_bounds__(kFB) void tau_field_kernel(const double* __restrict__ em0,
+                                                        const double* __restrict__ temp,
+                                                        int gff_mode, double* __restrict__ a0,
+                                                        int64_t n) {
+  int64_t i = (int64_t)blockIdx.x * kFB + threadIdx.x;
+  const int64_t step = (int64_t)gridDim.x * kFB;
+  for (; i < n; i += step) {
+    const double g = em0[i];
+    a0[i] = with_sign(fabs(g) * tau_weight(temp[i], gff_mode), signbit_d(g));
+  }
+}
+
+hipError_t tau_field_launch(const rjp_fields* fl, int gff_mode, void* d_a0, hipStream_t st) {
+  const int64_t n = (int64_t)fl->nx * fl->ny * fl->nz;
+  const unsigned blocks = (unsigned)std::min<int64_t>((n + kFB - 1) / kFB, 256 * 32);
+  hipLaunchKernelGGL(tau_field_kernel, dim3(blocks), dim3(kFB), 0, st, (const double*)fl->d_em0,
+                     (const double*)fl->d_temp, gff_mode, (double*)d_a0, n);
+  return hipGetLastError();
+}
+
 // ---- synthetic dense fields --------------------------------------------
 // No FMA contraction from here to the end of K4: the generator must be bit-identical to its
 // host restatement, and K4's inside test must follow NumPy's operation order.
@@ -100,7 +125,8 @@ hipError_t compact_fields_launch(const rjp_fields* fl, void* d_em0, int64_t* d_n
 template <typename T>
 __global__ __launch_bounds__(kFB) void synth_kernel(uint64_t seed, int temp_mode, int nz,
                                                     int64_t cell0, int64_t n, T* nd, T* xi,
-                                                    T* temp, T* pf, T* ts, T* vy, T* em0) {
+                                                    T* temp, T* pf, T* ts, T* vy, T* em0,
+                                                    T* a0, int a0_mode) {
   int64_t i = (int64_t)blockIdx.x * kFB + threadIdx.x;
   const int64_t step = (int64_t)gridDim.x * kFB;
   for (; i < n; i += step) {
@@ -113,11 +139,15 @@ __global__ __launch_bounds__(kFB) void synth_kernel(uint64_t seed, int temp_mode
     const double n0 = exp10(5.0 + 2.5 * un);
     if (nd) nd[i] = (T)with_sign(n0, red);
     if (xi) xi[i] = (T)(0.05 + 0.45 * ux);
-    if (temp) temp[i] = (T)(temp_mode == 0 ? 1e4 : 5e3 + 1.5e4 * ut);
+    const double tk = temp_mode == 0 ? 1e4 : 5e3 + 1.5e4 * ut;
+    if (temp) temp[i] = (T)tk;
     if (pf) pf[i] = (T)(up < 0.25 ? 0.5 : 1.0);
-    if (em0) {     // the compact scan field straight from the generator (f64): as compact_fields_kernel
+    if (em0 || a0) {   // the derived scan fields straight from the generator (f64): as
+                       // compact_fields_kernel / tau_field_kernel
       const double e0 = n0 * (0.05 + 0.45 * ux);
-      em0[i] = (T)with_sign(e0 * e0 * (up < 0.25 ? 0.5 : 1.0), red);
+      const double g = e0 * e0 * (up < 0.25 ? 0.5 : 1.0);
+      if (em0) em0[i] = (T)with_sign(g, red);
+      if (a0) a0[i] = (T)with_sign(g * tau_weight(tk, a0_mode), red);
     }
     if (ts) ts[i] = (T)(5.0 * us * 31536000.0);
     if (vy) vy[i] = (T)(6.2 + 60.0 * (uv - 0.5));
@@ -126,16 +156,16 @@ __global__ __launch_bounds__(kFB) void synth_kernel(uint64_t seed, int temp_mode
 
 hipError_t synth_launch(uint64_t seed, int temp_mode, int nz, int64_t cell0, int64_t n,
                         int dtype, void* nd, void* xi, void* temp, void* pf, void* ts, void* vy,
-                        void* em0, hipStream_t st) {
+                        void* em0, void* a0, int a0_mode, hipStream_t st) {
   const unsigned blocks = (unsigned)std::min<int64_t>((n + kFB - 1) / kFB, 256 * 32);
   if (dtype == RJP_F64)
     hipLaunchKernelGGL(synth_kernel<double>, dim3(blocks), dim3(kFB), 0, st, seed, temp_mode, nz,
                        cell0, n, (double*)nd, (double*)xi, (double*)temp, (double*)pf,
-                       (double*)ts, (double*)vy, (double*)em0);
+                       (double*)ts, (double*)vy, (double*)em0, (double*)a0, a0_mode);
   else
     hipLaunchKernelGGL(synth_kernel<float>, dim3(blocks), dim3(kFB), 0, st, seed, temp_mode, nz,
                        cell0, n, (float*)nd, (float*)xi, (float*)temp, (float*)pf, (float*)ts,
-                       (float*)vy, (float*)em0);
+                       (float*)vy, (float*)em0, (float*)nullptr, a0_mode);
   return hipGetLastError();
 }
 
@@ -256,7 +286,7 @@ __global__ __launch_bounds__(kFB) void build_fields_kernel(GeomDev g, T* nd, T* 
                                                            T* pf, T* ts, T* vy,
                                                            double* ff_raw, double* areas_raw,
                                                            double* vx_raw, double* vz_raw,
-                                                           T* em0) {
+                                                           T* em0, T* a0, int a0_mode) {
   const int64_t n = (int64_t)g.nx * g.ny * g.nz;
   const int64_t i = (int64_t)blockIdx.x * kFB + threadIdx.x;
   if (i >= n) return;
@@ -315,22 +345,27 @@ __global__ __launch_bounds__(kFB) void build_fields_kernel(GeomDev g, T* nd, T* 
   const double reff = g.R_1 + ((g.R_2 - g.R_1) * ww) / (g.w_0 * pow(rho_mod(g, ar_), g.eps));
   const double rho_c = rho_mod(g, rc);
 
-  if (nd || em0) {
-    double v = jet ? powerlaw(g.n_0, rho_c, reff, g.R_1, g.q_n, g.qd_n) : nan;
-    if (rr < 0) v = v * g.rb_frac;                                 // classes.py:895
-    if (nd) nd[i] = (T)with_sign(v, rr < 0);
-    if (em0) {     // the compact scan field straight from the builder (f64): as compact_fields_kernel
-      const double n0 = fabs(v) * (jet ? powerlaw(g.x_0, rho_c, reff, g.R_1, g.q_x, g.qd_x) : nan);
-      em0[i] = (T)with_sign(n0 * n0 * (ff / ar), rr < 0);
-    }
-  }
-  if (xi) xi[i] = (T)(jet ? powerlaw(g.x_0, rho_c, reff, g.R_1, g.q_x, g.qd_x) : nan);
-  if (temp) {
+  double tk = nan;
+  if (temp || a0) {
     // classes.py:957-962: r converted to cm BEFORE the r_0 [au] comparison and rho()
     const double rcm = ar_ * 149597870700.0 * 1e2;
     const double rt = (rcm < g.r_0 && (rcm + h) >= g.r_0) ? (g.r_0 + rcm + h) / 2.0 : rcm;
-    temp[i] = (T)(jet ? powerlaw(g.T_0, rho_mod(g, rt), reff, g.R_1, g.q_T, g.qd_T) : nan);
+    tk = jet ? powerlaw(g.T_0, rho_mod(g, rt), reff, g.R_1, g.q_T, g.qd_T) : nan;
+    if (temp) temp[i] = (T)tk;
   }
+  if (nd || em0 || a0) {
+    double v = jet ? powerlaw(g.n_0, rho_c, reff, g.R_1, g.q_n, g.qd_n) : nan;
+    if (rr < 0) v = v * g.rb_frac;                                 // classes.py:895
+    if (nd) nd[i] = (T)with_sign(v, rr < 0);
+    if (em0 || a0) {   // the derived scan fields straight from the builder (f64): as
+                       // compact_fields_kernel / tau_field_kernel
+      const double n0 = fabs(v) * (jet ? powerlaw(g.x_0, rho_c, reff, g.R_1, g.q_x, g.qd_x) : nan);
+      const double gg = n0 * n0 * (ff / ar);
+      if (em0) em0[i] = (T)with_sign(gg, rr < 0);
+      if (a0) a0[i] = (T)with_sign(fabs(gg) * tau_weight(tk, a0_mode), rr < 0);
+    }
+  }
+  if (xi) xi[i] = (T)(jet ? powerlaw(g.x_0, rho_c, reff, g.R_1, g.q_x, g.qd_x) : nan);
   if (pf) pf[i] = (T)(ff / ar);
   if (ts && g.ts_mode == 2) {
     const double au = 149597870700.0;

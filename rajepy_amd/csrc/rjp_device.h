@@ -549,6 +549,18 @@ __device__ __forceinline__ bool signbit_d(double v) {
   return (__double_as_longlong(v) < 0);
 }
 
+// The temperature factor of a cell's free-free optical depth exactly as K1 evaluates it on the
+// wide and compact layouts (element-wise identical to the batched forms): T^-1.5 for the scalar
+// Gaunt factor, T^-1.35 for the power-law one.  Producers of the tau field rjp_fields.d_a0 use
+// it so that a0 == g0 * tpow bit for bit.
+__device__ __forceinline__ double tau_weight(double T, int gff_mode) {
+  const double in[1] = {T};
+  double out[1];
+  if (gff_mode == RJP_GFF_POWERLAW) pow_m1p35_batch<1>(in, out);
+  else pow_m1p5_batch<1>(in, out);
+  return out[0];
+}
+
 // ---- splitmix64 counter hash for the synthetic generator -------------------------------
 __host__ __device__ __forceinline__ uint64_t splitmix64(uint64_t x) {
   x += 0x9E3779B97F4A7C15ull;

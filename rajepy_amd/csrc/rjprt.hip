@@ -112,14 +112,31 @@ static int release_tables(rjp_ctx* ctx, hipStream_t st) {
   return RJP_OK;
 }
 
-// `compact_ok`: the entry point can run from the compact layout alone (d_em0 + d_temp)
-static int check_fields(rjp_ctx* ctx, const rjp_fields* f, bool need_vy, bool compact_ok = false) {
+// End of a call that staged tables: the slot's release event is recorded on EVERY path -- after
+// a failed launch too, since the slot's upload (and anything enqueued before the failure) may
+// still be in flight when the ring comes round to it again.
+static int finish_staged(rjp_ctx* ctx, hipStream_t st, hipError_t e, const char* what) {
+  const int r = release_tables(ctx, st);
+  if (e != hipSuccess) return fail(ctx, RJP_ERR_HIP, what, e);
+  return r;
+}
+
+static bool mode_ok(int m) { return m == RJP_GFF_SCALAR || m == RJP_GFF_POWERLAW; }
+
+// `compact_ok`: the entry point can run from the compact layout alone (d_em0 + d_temp);
+// `tau_mode` >= 0: ... or from the tau layout alone (d_a0 built for that mode)
+static int check_fields(rjp_ctx* ctx, const rjp_fields* f, bool need_vy, bool compact_ok = false,
+                        int tau_mode = -1) {
   if (!f) return fail(ctx, RJP_ERR_ARG, "fields is NULL");
   if (f->dtype != RJP_F32 && f->dtype != RJP_F64)
     return fail(ctx, RJP_ERR_ARG, "fields.dtype must be RJP_F32 (4) or RJP_F64 (8)");
   if (f->nx <= 0 || f->ny <= 0 || f->nz <= 0)
     return fail(ctx, RJP_ERR_ARG, "grid dimensions must be positive");
-  if (compact_ok && f->d_em0) {
+  if (f->d_a0 && (f->dtype != RJP_F64 || !mode_ok(f->a0_mode)))
+    return fail(ctx, RJP_ERR_ARG, "fields.d_a0 needs RJP_F64 storage and a valid a0_mode");
+  if (tau_mode >= 0 && f->d_a0 && f->a0_mode == tau_mode) {
+    // nothing else is needed for the scan itself (d_em0 / d_temp are checked where asked for)
+  } else if (compact_ok && f->d_em0) {
     if (!f->d_temp) return fail(ctx, RJP_ERR_ARG, "fields.d_temp must be a device pointer");
   } else if (!f->d_nd || !f->d_xi || !f->d_temp || !f->d_pf) {
     return fail(ctx, RJP_ERR_ARG, "fields nd/xi/temp/pf must be device pointers");
@@ -228,6 +245,36 @@ int rjp_compact_fields(rjp_ctx* ctx, const rjp_fields* fields, void* d_em0, int6
   return RJP_OK;
 }
 
+int rjp_tau_field(rjp_ctx* ctx, const rjp_fields* fields, int32_t gff_mode, void* d_a0,
+                  void* stream) {
+  if (int r = bind(ctx)) return r;
+  if (int r = check_fields(ctx, fields, false, true)) return r;
+  if (!mode_ok(gff_mode)) return fail(ctx, RJP_ERR_ARG, "bad gff_mode");
+  if (fields->dtype != RJP_F64 || !fields->d_em0)
+    return fail(ctx, RJP_ERR_ARG, "rjp_tau_field: needs RJP_F64 storage with the compact field "
+                                  "d_em0 attached");
+  if (!d_a0) return fail(ctx, RJP_ERR_ARG, "rjp_tau_field: NULL output");
+  RJP_HIP(ctx, rjp::tau_field_launch(fields, gff_mode, d_a0, (hipStream_t)stream));
+  return RJP_OK;
+}
+
+int rjp_tavg(rjp_ctx* ctx, const rjp_fields* fields, double* d_tavg, void* d_work,
+             size_t work_bytes, void* stream) {
+  if (int r = bind(ctx)) return r;
+  if (!fields || !fields->d_temp) return fail(ctx, RJP_ERR_ARG, "rjp_tavg: fields.d_temp is NULL");
+  if (fields->dtype != RJP_F32 && fields->dtype != RJP_F64)
+    return fail(ctx, RJP_ERR_ARG, "fields.dtype must be RJP_F32 (4) or RJP_F64 (8)");
+  if (fields->nx <= 0 || fields->ny <= 0 || fields->nz <= 0)
+    return fail(ctx, RJP_ERR_ARG, "grid dimensions must be positive");
+  if ((fields->d_ylo == nullptr) != (fields->d_yhi == nullptr))
+    return fail(ctx, RJP_ERR_ARG, "fields.d_ylo and d_yhi must both be set or both be NULL");
+  if (!d_tavg || !d_work) return fail(ctx, RJP_ERR_ARG, "rjp_tavg: d_tavg / d_work is NULL");
+  if (work_bytes < rjp::ff_scan_workspace_bytes(fields->nx, fields->ny, fields->nz, 1))
+    return fail(ctx, RJP_ERR_WORKSPACE, "rjp_tavg: workspace smaller than rjp_ff_scan_workspace(.., 1)");
+  RJP_HIP(ctx, rjp::tavg_launch(fields, d_tavg, (double*)d_work, (hipStream_t)stream));
+  return RJP_OK;
+}
+
 int rjp_y_bounds(rjp_ctx* ctx, const rjp_fields* fields, int32_t* d_ylo, int32_t* d_yhi,
                  void* stream) {
   if (int r = bind(ctx)) return r;
@@ -246,12 +293,17 @@ int rjp_ff_scan(rjp_ctx* ctx, const rjp_fields* fields, const rjp_bursts* bursts
                 const double* h_epochs_s, int32_t n_epochs, int32_t gff_mode, double* d_sumA,
                 double* d_em, double* d_tavg, void* d_work, size_t work_bytes, void* stream) {
   if (int r = bind(ctx)) return r;
-  if (int r = check_fields(ctx, fields, false, true)) return r;
+  if (!mode_ok(gff_mode)) return fail(ctx, RJP_ERR_ARG, "bad gff_mode");
+  if (int r = check_fields(ctx, fields, false, true, gff_mode)) return r;
   if (int r = check_bursts(ctx, bursts, fields)) return r;
   if (!h_epochs_s || n_epochs < 1) return fail(ctx, RJP_ERR_ARG, "need >= 1 epoch");
-  if (gff_mode != RJP_GFF_SCALAR && gff_mode != RJP_GFF_POWERLAW)
-    return fail(ctx, RJP_ERR_ARG, "bad gff_mode");
   if (!d_sumA || !d_work) return fail(ctx, RJP_ERR_ARG, "d_sumA / d_work is NULL");
+  if (fields->d_a0 && fields->a0_mode == gff_mode && !fields->d_em0 && !fields->d_temp &&
+      (d_em || d_tavg))
+    return fail(ctx, RJP_ERR_ARG, "rjp_ff_scan: fields hold the tau layout only; d_em needs "
+                                  "d_em0 and d_tavg needs d_temp");
+  if (fields->d_a0 && fields->a0_mode == gff_mode && d_tavg && !fields->d_temp)
+    return fail(ctx, RJP_ERR_ARG, "rjp_ff_scan: d_tavg on the tau layout needs fields.d_temp");
   if (work_bytes < rjp::ff_scan_workspace_bytes(fields->nx, fields->ny, fields->nz, n_epochs))
     return fail(ctx, RJP_ERR_WORKSPACE, "rjp_ff_scan: workspace smaller than rjp_ff_scan_workspace()");
   hipStream_t st = (hipStream_t)stream;
@@ -265,9 +317,12 @@ int rjp_ff_scan(rjp_ctx* ctx, const rjp_fields* fields, const rjp_bursts* bursts
     if (int r = stage_tables(ctx, st, src, len, 1, dev)) return r;
     d_ext = dev[0];
   }
-  RJP_HIP(ctx, rjp::ff_scan_run(fields, bursts, plan, d_ext, h_epochs_s, n_epochs, gff_mode,
-                                d_sumA, d_em, d_tavg, (double*)d_work, st));
-  if (d_ext) return release_tables(ctx, st);
+  const hipError_t e = rjp::ff_scan_run(fields, bursts, plan, d_ext, h_epochs_s, n_epochs,
+                                        gff_mode, d_sumA, d_em, d_tavg, (double*)d_work, st);
+  // the staged slot is marked busy up to here on EVERY path (its upload, and whatever was
+  // enqueued before a failure, may still be in flight)
+  if (d_ext) return finish_staged(ctx, st, e, "ff_scan_run");
+  if (e != hipSuccess) return fail(ctx, RJP_ERR_HIP, "ff_scan_run", e);
   return RJP_OK;
 }
 
@@ -313,9 +368,8 @@ int rjp_ff_maps(rjp_ctx* ctx, const double* d_sumA, const double* d_tavg, int64_
   const size_t len[2] = {(size_t)n_chan, (size_t)n_chan};
   double* dev[2];
   if (int r = stage_tables(ctx, st, src, len, 2, dev)) return r;
-  RJP_HIP(ctx, rjp::ff_maps_launch(d_sumA, d_tavg, n_pix, n_epochs, dev[0], dev[1], n_chan, d_tau,
-                                   d_flux, d_ftot, (double*)d_work, st));
-  return release_tables(ctx, st);
+  return finish_staged(ctx, st, rjp::ff_maps_launch(d_sumA, d_tavg, n_pix, n_epochs, dev[0], dev[1], n_chan, d_tau,
+                                   d_flux, d_ftot, (double*)d_work, st), "ff_maps_launch");
 }
 
 int rjp_rrl_scan(rjp_ctx* ctx, const rjp_fields* fields, const rjp_bursts* bursts,
@@ -332,9 +386,8 @@ int rjp_rrl_scan(rjp_ctx* ctx, const rjp_fields* fields, const rjp_bursts* burst
   const size_t len[2] = {(size_t)n_chan, ext.size()};
   double* dev[2];
   if (int r = stage_tables(ctx, st, src, len, 2, dev)) return r;
-  RJP_HIP(ctx, rjp::rrl_scan_launch(fields, bursts, ext.empty() ? nullptr : dev[1], time_s, line,
-                                    h_nu, dev[0], n_chan, d_tau_rrl, st));
-  return release_tables(ctx, st);
+  return finish_staged(ctx, st, rjp::rrl_scan_launch(fields, bursts, ext.empty() ? nullptr : dev[1], time_s, line,
+                                    h_nu, dev[0], n_chan, d_tau_rrl, st), "rrl_scan_launch");
 }
 
 int rjp_ff_cells(rjp_ctx* ctx, const rjp_fields* fields, const rjp_bursts* bursts, double time_s,
@@ -353,9 +406,8 @@ int rjp_ff_cells(rjp_ctx* ctx, const rjp_fields* fields, const rjp_bursts* burst
   const size_t len[2] = {(size_t)n_chan, ext.size()};
   double* dev[2];
   if (int r = stage_tables(ctx, st, src, len, 2, dev)) return r;
-  RJP_HIP(ctx, rjp::ff_cells_launch(fields, bursts, ext.empty() ? nullptr : dev[1], time_s,
-                                    gff_mode, dev[0], n_chan, d_tau_cells, st));
-  return release_tables(ctx, st);
+  return finish_staged(ctx, st, rjp::ff_cells_launch(fields, bursts, ext.empty() ? nullptr : dev[1], time_s,
+                                    gff_mode, dev[0], n_chan, d_tau_cells, st), "ff_cells_launch");
 }
 
 int rjp_rrl_cells(rjp_ctx* ctx, const rjp_fields* fields, const rjp_bursts* bursts,
@@ -372,9 +424,8 @@ int rjp_rrl_cells(rjp_ctx* ctx, const rjp_fields* fields, const rjp_bursts* burs
   const size_t len[2] = {(size_t)n_chan, ext.size()};
   double* dev[2];
   if (int r = stage_tables(ctx, st, src, len, 2, dev)) return r;
-  RJP_HIP(ctx, rjp::rrl_cells_launch(fields, bursts, ext.empty() ? nullptr : dev[1], time_s,
-                                     line, h_nu, dev[0], n_chan, d_tau_cells, st));
-  return release_tables(ctx, st);
+  return finish_staged(ctx, st, rjp::rrl_cells_launch(fields, bursts, ext.empty() ? nullptr : dev[1], time_s,
+                                     line, h_nu, dev[0], n_chan, d_tau_cells, st), "rrl_cells_launch");
 }
 
 int rjp_rrl_maps(rjp_ctx* ctx, const double* d_tau_rrl, const double* d_tau_ff,
@@ -392,23 +443,23 @@ int rjp_rrl_maps(rjp_ctx* ctx, const double* d_tau_rrl, const double* d_tau_ff,
   const size_t len[2] = {(size_t)n_chan, (size_t)n_chan};
   double* dev[2];
   if (int r = stage_tables(ctx, st, src, len, 2, dev)) return r;
-  RJP_HIP(ctx, rjp::rrl_maps_launch(d_tau_rrl, d_tau_ff, d_tavg, d_flux_ff, n_pix, dev[0], dev[1],
-                                    n_chan, d_flux, d_ftot, (double*)d_work, st));
-  return release_tables(ctx, st);
+  return finish_staged(ctx, st, rjp::rrl_maps_launch(d_tau_rrl, d_tau_ff, d_tavg, d_flux_ff, n_pix, dev[0], dev[1],
+                                    n_chan, d_flux, d_ftot, (double*)d_work, st), "rrl_maps_launch");
 }
 
 int rjp_build_fields(rjp_ctx* ctx, const rjp_geometry* gm, int dtype, void* d_nd, void* d_xi,
                      void* d_temp, void* d_pf, void* d_ts, void* d_vy, double* d_ff_raw,
                      double* d_areas_raw, double* d_vx_raw, double* d_vz_raw, void* d_em0,
-                     void* stream) {
+                     void* d_a0, int32_t a0_mode, void* stream) {
   if (int r = bind(ctx)) return r;
   if (!gm) return fail(ctx, RJP_ERR_ARG, "geometry is NULL");
   if (dtype != RJP_F32 && dtype != RJP_F64) return fail(ctx, RJP_ERR_ARG, "bad dtype tag");
   if (gm->nx <= 0 || gm->ny <= 0 || gm->nz <= 0 || !(gm->csize > 0))
     return fail(ctx, RJP_ERR_ARG, "bad grid in geometry");
-  if (d_em0 && dtype != RJP_F64)
-    return fail(ctx, RJP_ERR_ARG, "rjp_build_fields: d_em0 is written for RJP_F64 storage only "
-                                  "(float storage goes through rjp_compact_fields' range check)");
+  if ((d_em0 || d_a0) && dtype != RJP_F64)
+    return fail(ctx, RJP_ERR_ARG, "rjp_build_fields: d_em0 / d_a0 are written for RJP_F64 storage "
+                                  "only (float storage goes through rjp_compact_fields' range check)");
+  if (d_a0 && !mode_ok(a0_mode)) return fail(ctx, RJP_ERR_ARG, "rjp_build_fields: bad a0_mode");
   const double au = 149597870700.0, d2r = M_PI / 180.0;
   rjp::GeomDev g;
   g.nx = gm->nx; g.ny = gm->ny; g.nz = gm->nz; g.ccw = gm->rotation_ccw;
@@ -464,25 +515,28 @@ int rjp_build_fields(rjp_ctx* ctx, const rjp_geometry* gm, int dtype, void* d_nd
     hipLaunchKernelGGL(rjp::build_fields_kernel<double>, dim3(blocks), dim3(rjp::kFB), 0, st, g,
                        (double*)d_nd, (double*)d_xi, (double*)d_temp, (double*)d_pf,
                        (double*)d_ts, (double*)d_vy, d_ff_raw, d_areas_raw, d_vx_raw, d_vz_raw,
-                       (double*)d_em0);
+                       (double*)d_em0, (double*)d_a0, (int)a0_mode);
   else
     hipLaunchKernelGGL(rjp::build_fields_kernel<float>, dim3(blocks), dim3(rjp::kFB), 0, st, g,
                        (float*)d_nd, (float*)d_xi, (float*)d_temp, (float*)d_pf, (float*)d_ts,
-                       (float*)d_vy, d_ff_raw, d_areas_raw, d_vx_raw, d_vz_raw, (float*)nullptr);
+                       (float*)d_vy, d_ff_raw, d_areas_raw, d_vx_raw, d_vz_raw, (float*)nullptr,
+                       (float*)nullptr, 0);
   RJP_HIP(ctx, hipGetLastError());
   return RJP_OK;
 }
 
 int rjp_synth_fields(rjp_ctx* ctx, uint64_t seed, int32_t temp_mode, int32_t nz, int64_t cell0,
                      int64_t n, int dtype, void* d_nd, void* d_xi, void* d_temp, void* d_pf,
-                     void* d_ts, void* d_vy, void* d_em0, void* stream) {
+                     void* d_ts, void* d_vy, void* d_em0, void* d_a0, int32_t a0_mode,
+                     void* stream) {
   if (int r = bind(ctx)) return r;
   if (n <= 0 || nz <= 0 || cell0 < 0) return fail(ctx, RJP_ERR_ARG, "rjp_synth_fields: bad range");
   if (dtype != RJP_F32 && dtype != RJP_F64) return fail(ctx, RJP_ERR_ARG, "bad dtype tag");
-  if (d_em0 && dtype != RJP_F64)
-    return fail(ctx, RJP_ERR_ARG, "rjp_synth_fields: d_em0 is written for RJP_F64 storage only");
+  if ((d_em0 || d_a0) && dtype != RJP_F64)
+    return fail(ctx, RJP_ERR_ARG, "rjp_synth_fields: d_em0 / d_a0 are written for RJP_F64 storage only");
+  if (d_a0 && !mode_ok(a0_mode)) return fail(ctx, RJP_ERR_ARG, "rjp_synth_fields: bad a0_mode");
   RJP_HIP(ctx, rjp::synth_launch(seed, temp_mode, nz, cell0, n, dtype, d_nd, d_xi, d_temp, d_pf,
-                                 d_ts, d_vy, d_em0, (hipStream_t)stream));
+                                 d_ts, d_vy, d_em0, d_a0, (int)a0_mode, (hipStream_t)stream));
   return RJP_OK;
 }
 

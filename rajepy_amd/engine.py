@@ -31,6 +31,8 @@ class DeviceFields:
         self.ff_raw, self.areas_raw = ff_raw, areas_raw
         self.ylo = self.yhi = None          # optional occupied y-range per sightline (int32)
         self.em0 = None                     # optional compact scan field (rjp_fields.d_em0)
+        self.a0 = None                      # optional tau scan field (rjp_fields.d_a0) ...
+        self.a0_mode = 0                    # ... and the Gaunt mode it was built for
 
     @property
     def ncells(self):
@@ -45,6 +47,8 @@ class DeviceFields:
         f.d_nd, f.d_xi, f.d_temp, f.d_pf = (t.data_ptr() if t is not None else None for t in
                                             (self.nd, self.xi, self.temp, self.pf))
         f.d_em0 = self.em0.data_ptr() if self.em0 is not None else None
+        f.d_a0 = self.a0.data_ptr() if self.a0 is not None else None
+        f.a0_mode = int(self.a0_mode)
         f.d_ts = self.ts.data_ptr() if self.ts is not None else None
         f.d_vy = self.vy.data_ptr() if self.vy is not None else None
         f.nx, f.ny, f.nz = self.shape
@@ -54,10 +58,24 @@ class DeviceFields:
         f.d_yhi = self.yhi.data_ptr() if self.yhi is not None else None
         return f
 
-    def nbytes(self, rrl=False):
+    def scan_fields(self, gff_mode, want_em=True):
+        """Fields per cell one continuum grid pass streams: 2 on the tau layout (a0, ts; em0 as
+        a third only with emission-measure maps), 3 on the compact one (em0, temp, ts), else the
+        5 wide ones."""
+        if (self.a0 is not None and self.a0_mode == gff_mode and self.dtype == RJP_F64 and
+                (not want_em or self.em0 is not None)):
+            return 3 if want_em else 2
+        return 3 if self.em0 is not None else 5
+
+    def nbytes(self, rrl=False, gff_mode=None, want_em=True):
         """Bytes one grid pass streams: the RRL scan reads the six wide fields; the continuum
-        scan the three of the compact layout when it is attached, else the five wide ones."""
-        n = 6 if rrl else (3 if self.em0 is not None else 5)
+        scan what `scan_fields` says (without `gff_mode`: the compact / wide figure)."""
+        if rrl:
+            n = 6
+        elif gff_mode is None:
+            n = 3 if self.em0 is not None else 5
+        else:
+            n = self.scan_fields(gff_mode, want_em)
         return n * self.ncells * self.dtype
 
     def drop_wide(self):
@@ -66,6 +84,10 @@ class DeviceFields:
         if self.em0 is None:
             raise ValueError("no compact layout attached")
         self.nd = self.xi = self.pf = None
+
+    def drop_tau(self):
+        """Detach the tau layout (scans fall back to the compact / wide one)."""
+        self.a0 = None
 
 
 def make_bursts(red, blue):
@@ -104,6 +126,7 @@ class RTEngine:
         self.ctx = ctx
         self._work = None
         self.use_compact = not (_lib.DEBUG and os.environ.get("RJP_NO_COMPACT"))
+        self.use_tau = not (_lib.DEBUG and os.environ.get("RJP_NO_TAU"))
 
     def close(self):
         if getattr(self, "ctx", None):
@@ -193,6 +216,34 @@ class RTEngine:
             fields.em0 = em0
         return fields
 
+    def tau_layout(self, fields, gff_mode):
+        """Attach the tau scan layout for `gff_mode` (rjp_tau_field): a0 = em0 T^-1.5|-1.35,
+        everything of a cell's optical depth that depends on neither frequency nor epoch.  K1
+        then streams a0 and ts (16 B/cell; em0 as well only when EM maps are asked for) and
+        returns bit-identical maps.  f64 storage with the compact field attached; anything else
+        keeps its layout."""
+        fields.a0 = None
+        if not self.use_tau or fields.dtype != RJP_F64 or fields.em0 is None:
+            return fields
+        a0 = self._f64(fields.ncells)
+        fs = fields.struct()
+        _lib.check(self.lib.rjp_tau_field(self.ctx, C.byref(fs), int(gff_mode), a0.data_ptr(),
+                                          self._stream()), self.ctx, "rjp_tau_field")
+        fields.a0, fields.a0_mode = a0, int(gff_mode)
+        return fields
+
+    def tavg(self, fields):
+        """T_avg map of the model, nanmean_y(T where T > 0) -> device tensor [P] (rjp_tavg):
+        depends on neither frequency nor epoch, so a model asks once."""
+        nx, ny, nz = fields.shape
+        out = self._f64(fields.npix)
+        wb = self.lib.rjp_ff_scan_workspace(nx, ny, nz, 1)
+        work = self._workspace(wb)
+        fs = fields.struct()
+        _lib.check(self.lib.rjp_tavg(self.ctx, C.byref(fs), out.data_ptr(), work.data_ptr(),
+                                     work.numel(), self._stream()), self.ctx, "rjp_tavg")
+        return out
+
     def compute_y_bounds(self, fields):
         """Attach the per-sightline occupied y-range to `fields` (rjp_y_bounds): later scans
         skip the rows no cell of which can contribute.  Recompute after changing a field."""
@@ -221,8 +272,11 @@ class RTEngine:
                                            self._stream()), self.ctx, "rjp_pack_field")
         self.synchronize()
         setattr(fields, name, dst)
+        had_tau = fields.a0 is not None
         if name == "xi" and fields.em0 is not None:
             self.compact(fields)                # em0 holds (nd xi)^2 pf
+        if had_tau and name in ("xi", "temp"):
+            self.tau_layout(fields, fields.a0_mode)     # a0 holds em0 T^-1.5|-1.35
         if fields.ylo is not None and name in ("xi", "temp"):
             self.compute_y_bounds(fields)       # the occupied range depends on these fields
 
@@ -233,12 +287,20 @@ class RTEngine:
             return None
         return self._f64(n)
 
+    def _direct_a0(self, n, dtype, tau_mode):
+        """... and the tau scan field when a Gaunt mode is named."""
+        if tau_mode is None or dtype != RJP_F64 or not (self.use_compact and self.use_tau):
+            return None
+        return self._f64(n)
+
     def build_fields(self, geom, dtype=RJP_F64, want_ts=True, want_vy=True, want_raw=True,
-                     want_vxz=False, want_wide=True):
+                     want_vxz=False, want_wide=True, tau_mode=None):
         """K4: geometry -> packed fields on the device (`geom` is a _lib.Geometry).
-        `want_wide=False` (f64, continuum only) skips nd / xi / pf: 24 B/cell resident."""
+        `want_wide=False` (f64, continuum only) skips nd / xi / pf: 24 B/cell resident.
+        `tau_mode` = the model's Gaunt mode: K4 writes the tau scan field a0 in the same pass."""
         n = geom.nx * geom.ny * geom.nz
         em0 = self._direct_em0(n, dtype)
+        a0 = self._direct_a0(n, dtype, tau_mode)
         if not want_wide and em0 is None:
             raise ValueError("want_wide=False needs the compact layout (f64 storage)")
         nd, xi, pf = ((self._empty(n, dtype) for _ in range(3)) if want_wide
@@ -253,27 +315,37 @@ class RTEngine:
         ptr = lambda t: t.data_ptr() if t is not None else None
         _lib.check(self.lib.rjp_build_fields(
             self.ctx, C.byref(geom), dtype, ptr(nd), ptr(xi), temp.data_ptr(), ptr(pf), ptr(ts),
-            ptr(vy), ptr(ffr), ptr(arr), ptr(vxr), ptr(vzr), ptr(em0), self._stream()),
-            self.ctx, "rjp_build_fields")
+            ptr(vy), ptr(ffr), ptr(arr), ptr(vxr), ptr(vzr), ptr(em0), ptr(a0),
+            int(tau_mode or 0), self._stream()), self.ctx, "rjp_build_fields")
         out = DeviceFields((geom.nx, geom.ny, geom.nz), dtype, geom.csize, nd, xi, temp, pf,
                            ts, vy, ffr, arr)
         out.vx_raw, out.vz_raw = vxr, vzr
         if em0 is not None:
             out.em0 = em0
+            if a0 is not None:
+                out.a0, out.a0_mode = a0, int(tau_mode)
             return out
-        return self.compact(out)
+        out = self.compact(out)
+        return self.tau_layout(out, tau_mode) if tau_mode is not None else out
 
     def synth_fields(self, shape, seed, temp_mode=0, dtype=RJP_F64, csize_au=0.5,
-                     with_vy=False, cell0=0, wide=True):
+                     with_vy=False, cell0=0, wide=True, tau_mode=None, with_em0=True):
         """Measurement harness: dense synthetic fields generated on the device
         (SURVEY.md 8(d)); `shape` may be a sub-block starting at flat cell `cell0` of a
         grid whose z-extent is shape[2].  `wide=False` (f64) generates only the compact scan
-        layout (em0, temp, ts): 24 B/cell."""
+        layout (em0, temp, ts): 24 B/cell.  `tau_mode`: also the tau scan field a0 for that
+        Gaunt mode, in the same pass; with `with_em0=False` as well the generator leaves a0,
+        temp, ts (scans without emission-measure maps: 16 B/cell streamed)."""
         nx, ny, nz = shape
         n = nx * ny * nz
         em0 = self._direct_em0(n, dtype)
+        a0 = self._direct_a0(n, dtype, tau_mode)
         if not wide and em0 is None:
             raise ValueError("wide=False needs the compact layout (f64 storage)")
+        if not with_em0:
+            if wide or a0 is None:
+                raise ValueError("with_em0=False is for wide=False with a tau_mode (f64 storage)")
+            em0 = None
         nd, xi, pf = ((self._empty(n, dtype) for _ in range(3)) if wide else (None, None, None))
         temp, ts = self._empty(n, dtype), self._empty(n, dtype)
         vy = self._empty(n, dtype) if with_vy else None
@@ -281,23 +353,30 @@ class RTEngine:
         _lib.check(self.lib.rjp_synth_fields(
             self.ctx, int(seed), int(temp_mode), int(nz), int(cell0), int(n), dtype,
             ptr(nd), ptr(xi), temp.data_ptr(), ptr(pf), ts.data_ptr(), ptr(vy), ptr(em0),
-            self._stream()), self.ctx, "rjp_synth_fields")
+            ptr(a0), int(tau_mode or 0), self._stream()), self.ctx, "rjp_synth_fields")
         out = DeviceFields(shape, dtype, csize_au, nd, xi, temp, pf, ts, vy)
+        if a0 is not None:
+            out.a0, out.a0_mode = a0, int(tau_mode)
         if em0 is not None:
             out.em0 = em0
+        if em0 is not None or not with_em0:
             return out
-        return self.compact(out)
+        out = self.compact(out)
+        return self.tau_layout(out, tau_mode) if tau_mode is not None else out
 
     # -- K1 / K2 -----------------------------------------------------------------------------
-    def ff_scan(self, fields, bursts, epochs_s, gff_mode, want_em=True, out=None):
-        """-> (sumA[E,P], em[E,P] or None, tavg[P]) device tensors (float64)."""
+    def ff_scan(self, fields, bursts, epochs_s, gff_mode, want_em=True, out=None,
+                want_tavg=True):
+        """-> (sumA[E,P], em[E,P] or None, tavg[P] or None) device tensors (float64).
+        `want_tavg=False`: no T_avg map (a caller that keeps the model's map from `tavg()`; on
+        the tau layout the scan then never reads the temperature field)."""
         E = len(epochs_s)
         P = fields.npix
         nx, ny, nz = fields.shape
         if out is None:
             sumA = self._f64(E, P)
             em = self._f64(E, P) if want_em else None
-            tavg = self._f64(P)
+            tavg = self._f64(P) if want_tavg else None
         else:
             sumA, em, tavg = out
         wb = self.lib.rjp_ff_scan_workspace(nx, ny, nz, E)
@@ -307,16 +386,18 @@ class RTEngine:
         _lib.check(self.lib.rjp_ff_scan(
             self.ctx, C.byref(fs), C.byref(bursts) if bursts is not None else None, ep, E,
             int(gff_mode), sumA.data_ptr(), em.data_ptr() if em is not None else None,
-            tavg.data_ptr(), work.data_ptr(), work.numel(), self._stream()), self.ctx,
-            "rjp_ff_scan")
+            tavg.data_ptr() if tavg is not None else None, work.data_ptr(), work.numel(),
+            self._stream()), self.ctx, "rjp_ff_scan")
         return sumA, em, tavg
 
-    def time_ff_scan(self, fields, bursts, epochs_s, gff_mode, reps=5, want_em=True):
+    def time_ff_scan(self, fields, bursts, epochs_s, gff_mode, reps=5, want_em=True,
+                     want_tavg=True):
         """Average device time [ms] of one rjp_ff_scan (HIP events on the launch stream)."""
         E = len(epochs_s)
         P = fields.npix
         nx, ny, nz = fields.shape
-        sumA, em, tavg = self._f64(E, P), (self._f64(E, P) if want_em else None), self._f64(P)
+        sumA, em = self._f64(E, P), (self._f64(E, P) if want_em else None)
+        tavg = self._f64(P) if want_tavg else None
         wb = self.lib.rjp_ff_scan_workspace(nx, ny, nz, E)
         work = self._workspace(wb)
         fs = fields.struct()
@@ -324,9 +405,9 @@ class RTEngine:
         ms = C.c_double()
         _lib.check(self.lib.rjp_time_ff_scan(
             self.ctx, C.byref(fs), C.byref(bursts) if bursts is not None else None, ep, E,
-            int(gff_mode), sumA.data_ptr(), em.data_ptr() if want_em else None, tavg.data_ptr(),
-            work.data_ptr(), work.numel(), self._stream(), int(reps), C.byref(ms)), self.ctx,
-            "rjp_time_ff_scan")
+            int(gff_mode), sumA.data_ptr(), em.data_ptr() if want_em else None,
+            tavg.data_ptr() if want_tavg else None, work.data_ptr(), work.numel(),
+            self._stream(), int(reps), C.byref(ms)), self.ctx, "rjp_time_ff_scan")
         return ms.value
 
     def ff_maps(self, sumA, tavg, ctau, cflux, want_tau=True, want_flux=True,

@@ -75,6 +75,11 @@ def _dist():
     return dist
 
 
+def _in_group():
+    dist = _dist()
+    return dist.is_available() and dist.is_initialized()
+
+
 def all_gather_blocks(local, shards, rank, axis=0, group=None):
     """Gather per-rank blocks of unequal leading size along `axis` to every rank.
 
@@ -86,8 +91,10 @@ def all_gather_blocks(local, shards, rank, axis=0, group=None):
     if local.shape[axis] != counts[rank]:
         raise ValueError("local block has %d items on axis %d, plan says %d"
                          % (local.shape[axis], axis, counts[rank]))
-    if shards.world == 1:
-        return local
+    if shards.world == 1 and not _in_group():
+        return local                         # no process group: nothing to talk to
+    # (inside an initialised group the collective is issued even for one rank, so that a
+    # one-rank RCCL group on a single GPU exercises the path an eight-rank one takes)
     loc = local.movedim(axis, 0).contiguous()
     cmax = max(counts)
     if loc.shape[0] < cmax:
@@ -115,7 +122,7 @@ def gather_to_root(local, shards, rank, axis=0, root=0, group=None):
     import torch
     dist = _dist()
     counts = shards.counts()
-    if shards.world == 1:
+    if shards.world == 1 and not _in_group():
         return local
     loc = local.movedim(axis, 0).contiguous()
     cmax = max(counts)
@@ -151,8 +158,9 @@ def sweep_flux_vs_time(model, epochs_s, freqs, rank=0, world=1, group=None):
     ctau, cflux = E.ff_channel_coeffs(freqs, model.csize, model.params["target"]["dist"],
                                       model.gff_mode, gv)
     if mine:
-        sumA, _, tavg = eng.ff_scan(dev, model._rjp_bursts(), mine, model.gff_mode,
-                                    want_em=False)
+        tavg = model._model_tavg()
+        sumA, _, _ = eng.ff_scan(dev, model._rjp_bursts(), mine, model.gff_mode,
+                                 want_em=False, want_tavg=False)
         _, _, ftot = eng.ff_maps(sumA, tavg, ctau, cflux, want_tau=False, want_flux=False,
                                  want_ftot=True)
     else:
@@ -221,7 +229,7 @@ def sweep_xslab(model, epochs_s, freqs, rank=0, world=1, gather_maps=False, grou
     Returns (ftot[E,F] host array, tau or None, flux or None)."""
     dist = _dist()
     _, tau, flux, ftot = xslab_local(model, epochs_s, freqs, rank, world, want_maps=gather_maps)
-    if world > 1:
+    if world > 1 or _in_group():
         if ftot.is_cuda and dist.get_backend(group) == "gloo":
             t = ftot.cpu()
             dist.all_reduce(t, group=group)

@@ -11,7 +11,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 REQUIRED = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step",
             "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config",
-            "roofline", "cpu_baseline", "sustained", "ranks_seen"}
+            "roofline", "cpu_baseline", "sustained", "ranks_seen", "backend", "devices",
+            "distinct_devices"}
 
 
 @pytest.mark.parametrize("config", ["tiny", "tiny_rrl"])
@@ -36,10 +37,17 @@ def test_bench_prints_one_contract_line(config):
     assert {"bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_source",
             "algorithmic_bytes", "algorithmic_bytes_8d"} <= set(rf)
     if config == "tiny":
+        # the tau layout: a0 and ts per cell; the step asks for optical depths and fluxes only,
+        # the same launch with the EM map (a third field) is timed beside it
+        assert rf["fields_streamed_per_cell"] == 2 and rf["timed_step_asks_for_em"] is False
+        assert rf["with_em"]["fields_streamed_per_cell"] == 3 and rf["with_em"]["ms_per_launch"] > 0
+        assert rf["tavg"]["ms"] > 0 and "layout" in r["config"] and "tau" in r["config"]["layout"]
         # 8(d)'s five-field byte model is priced on the kernel that moves those bytes
-        assert rf["fields_streamed_per_cell"] == 3 and rf["algorithmic_bytes_8d"] > rf["algorithmic_bytes"]
+        assert rf["algorithmic_bytes_8d"] > rf["algorithmic_bytes"]
         assert rf["wide_ms_per_launch"] > 0 and rf["layout_build_ms"] > 0 and rf["frac_8d"] > 0
         assert r["api_level"]["ms_per_step"] >= r["ms_per_step"] * 0.5
+    assert "rehearsal" not in r and r["backend"] is None
+    assert r["distinct_devices"] == 1 and len(r["devices"]) == 1 and r["devices"][0]["id"]
     assert r["sustained"]["steps"] >= 3 and r["sustained"]["ms_per_step"] > 0
     assert r["ranks_seen"] == 1 and r["storage_dtype"] == "f64"
     assert rf["bound"] == "hbm" and rf["peak"] == 8000.0 and rf["unit"] == "GB/s"
@@ -47,10 +55,16 @@ def test_bench_prints_one_contract_line(config):
     cb = r["cpu_baseline"]
     assert {"value", "unit", "cores", "kind", "sample"} <= set(cb)
     assert cb["kind"] == "port" and cb["cores"] == 1 and cb["value"] > 0
+    # the host the CPU figures ran on, and the reference-proper provenance
+    assert cb["host"]["os_cpu_count"] >= 1 and "lscpu_model" in cb["host"]
+    assert cb["host"]["affinity"] is None or cb["host"]["affinity"] >= 1
+    assert cb["reference_proper"]["unit"] == "Mvoxel-freq/s"
     if config == "tiny":          # the one-process-per-core leg
         ac = cb["all_cores"]
         assert "error" not in ac, ac
         assert ac["cores"] >= 1 and ac["value"] > 0 and ac["late_start"] is False
+        assert ac["cores_available"] >= ac["cores"] and (ac["cap"] is None) == (
+            ac["cores"] == ac["cores_available"])
     else:
         assert "all_cores" not in cb
 
@@ -80,7 +94,12 @@ def test_bench_launches_its_own_ranks(config, sharding, scaling):
     assert len(lines) == 1, lines
     r = json.loads(lines[0])
     assert r["n_gpus"] == 2 and r["ranks_seen"] == 2 and r["scaling"] == scaling
-    assert r["config"]["sharding"] == sharding and r["value"] > 0
+    # two ranks on ONE device over gloo: plumbing only -- the line says so and has no `value`
+    assert r["rehearsal"] is True and r["value"] is None and r["rehearsal_value"] > 0
+    assert r["backend"] == "gloo" and r["distinct_devices"] == 1 and len(r["devices"]) == 2
+    assert r["devices"][0]["id"] == r["devices"][1]["id"] and "strong_value" not in r
+    assert r["rehearsal_strong_value"] > 0
+    assert r["config"]["sharding"] == sharding
     assert r["n1"]["value"] > 0
     if config == "tiny":
         # weak (timed region) + the labelled strong and channel-sharded legs, one line

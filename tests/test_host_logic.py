@@ -54,7 +54,9 @@ def test_abi_exports_every_declared_symbol():
 
 
 def test_abi_struct_layouts_match_header():
-    assert ctypes.sizeof(_lib.Fields) == 6 * 8 + 4 * 4 + 8 + 3 * 8
+    assert ctypes.sizeof(_lib.Fields) == 6 * 8 + 4 * 4 + 8 + 3 * 8 + 8 + 2 * 4
+    assert _lib.Fields.d_a0.offset == 6 * 8 + 4 * 4 + 8 + 3 * 8      # appended: ABI 103 prefix kept
+    assert _lib.Fields.a0_mode.offset == _lib.Fields.d_a0.offset + 8
     assert ctypes.sizeof(_lib.Bursts) == 8 + 3 * 2 * 8            # counts + 6 host pointers
     assert ctypes.sizeof(_lib.Line) == 6 * 8
     assert ctypes.sizeof(_lib.Geometry) == 4 * 4 + 24 * 8 + 2 * 4
@@ -104,6 +106,45 @@ def test_product_never_imports_the_oracle():
             if fn.endswith((".py", ".hip", ".h", ".sh")):
                 txt = open(os.path.join(dirpath, fn)).read()
                 assert "oracle" not in txt.replace("# oracle", ""), fn
+
+
+# ---- Pipeline epoch batching -----------------------------------------------------------
+@pytest.mark.parametrize("n_times, n_freqs", [(100, 1), (33, 2), (5, 3)])
+def test_pipeline_prefetches_each_epoch_once_in_chunks_of_32(tmp_path, n_times, n_freqs):
+    """Pipeline.execute hands the epochs still to come to JetModel.prefetch_epochs 32 at a
+    time -- one pass over HBM per chunk: ceil(N / 32) scans for N epochs, every epoch in
+    exactly one chunk, in run order (the reference scans the grid once per run and channel,
+    classes.py:2358-2453).  No GPU: the device calls are replaced by recorders."""
+    jm = make_model(tmp_path)
+    times = [round(0.05 * i, 4) for i in range(n_times)]
+    freqs = [1e9 * (k + 1) for k in range(n_freqs)]
+    pp = {"min_el": 20., "dcys": {"model_dcy": str(tmp_path / "run")},
+          "continuum": {"times": np.array(times), "freqs": np.array(freqs),
+                        "t_obs": np.array([1200] * n_freqs),
+                        "tscps": np.array([("VLA", "A")] * n_freqs),
+                        "t_ints": np.array([5] * n_freqs), "bws": np.array([1e8] * n_freqs),
+                        "chanws": np.array([1e8] * n_freqs)},
+          "rrls": {"times": None, "lines": np.array([]), "t_obs": np.array([]),
+                   "tscps": np.array([]), "t_ints": np.array([]), "bws": np.array([]),
+                   "chanws": np.array([])}}
+    pl = classes.Pipeline(jm, pp, log=jm.log)
+    chunks, served = [], []
+    jm.prefetch_epochs = lambda ts: chunks.append([float(t) for t in ts])
+    pl._radiative_transfer = lambda idx, run, clobber: served.append(float(jm.time))
+    jm.save = lambda f: None
+    pl.execute(simobserve=False, verbose=False, resume=False)
+    assert len(served) == n_times * n_freqs
+    assert len(chunks) == -(-n_times // 32)
+    assert all(len(c) <= 32 for c in chunks)
+    flat = [t for c in chunks for t in c]
+    assert flat == [t * con.year for t in times]            # each epoch once, in run order
+    # every run found its epoch in a chunk prefetched before it was served
+    seen = set()
+    it = iter(chunks)
+    for t in served:
+        if t not in seen:
+            seen.update(next(it))
+        assert t in seen
 
 
 # ---- JetModel host behaviour ---------------------------------------------------------
