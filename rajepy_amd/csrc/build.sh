@@ -1,6 +1,6 @@
 #!/bin/bash
-# Builds librjprt.so for gfx950 in-tree (rajepy_amd/librjprt.so).  hipcc cross-compiles
-# without a GPU.  Usage: build.sh [--report | --debug-switches]
+# Builds librjprt.so for gfx950 in-tree (rajepy_amd/librjprt.so) through csrc/Makefile (nine
+# translation units, compiled in parallel).  hipcc cross-compiles without a GPU.  Usage: build.sh [--report | --debug-switches]
 #   --report          prints per-kernel register use
 #   --debug-switches  builds rajepy_amd/librjprt_dbg.so with -DRJP_DEBUG_SWITCHES: the only build
 #                     that reads the RJP_YSPLIT / RJP_FORCE_VEC1 / RJP_NO_UNIFORM / RJP_NO_TILE32
@@ -14,9 +14,12 @@ out="$here/../librjprt.so"
 # constants are rematerialised where used: K3 -17 % (0 spills in the loop), the 32-epoch K1
 # tile 169 -> 164 VGPRs = 3 waves/SIMD instead of 2 (-3 %), the single-epoch K1 unchanged
 # (A/B in profiles/r02_build_flags_ab.md).
-flags=(--offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -Wall -Wno-unused-function -mllvm -disable-machine-licm)
+jobs="$(nproc 2>/dev/null || echo 4)"
 if [[ "${1:-}" == "--report" ]]; then
-  hipcc "${flags[@]}" -Rpass-analysis=kernel-resource-usage -o "$out" "$here/rjprt.hip" 2> "$here/../../gpurun_out/resource_usage.txt" || { cat "$here/../../gpurun_out/resource_usage.txt"; exit 1; }
+  obj="$here/../../build/rjprt_report"
+  make -s -C "$here" -j"$jobs" OUT="$out" OBJDIR="$obj" REPORT=1 EXTRA="-Rpass-analysis=kernel-resource-usage"
+  mkdir -p "$here/../../gpurun_out"
+  cat "$obj"/*.remarks > "$here/../../gpurun_out/resource_usage.txt"
   python3 - "$here/../../gpurun_out/resource_usage.txt" <<'PY'
 import re, sys, subprocess
 txt = open(sys.argv[1]).read()
@@ -38,8 +41,8 @@ for r, n in zip(rows, names):
 PY
 elif [[ "${1:-}" == "--debug-switches" ]]; then
   out="$here/../librjprt_dbg.so"
-  hipcc "${flags[@]}" -DRJP_DEBUG_SWITCHES -o "$out" "$here/rjprt.hip"
+  make -s -C "$here" -j"$jobs" OUT="$out" OBJDIR="$here/../../build/rjprt_dbg" EXTRA="-DRJP_DEBUG_SWITCHES ${RJP_EXTRA:-}"
 else
-  hipcc "${flags[@]}" -o "$out" "$here/rjprt.hip"
+  make -s -C "$here" -j"$jobs" OUT="$out" EXTRA="${RJP_EXTRA:-}"
 fi
 echo "built $out"

@@ -2,7 +2,7 @@
 // synthetic dense-field generator of the measurement harness.
 #include <algorithm>
 
-#include "rjp_device.h"
+#include "rjp_host.h"
 
 namespace rjp {
 
@@ -174,25 +174,6 @@ hipError_t synth_launch(uint64_t seed, int temp_mode, int nz, int64_t cell0, int
 // for everything that feeds a comparison (the 8-vertex inside test, classes.py:657-669), so
 // that the jet mask comes out identical; the rotation sines/cosines are computed on the host
 // (NumPy) and passed in, as the reference does (maths/geometry.py:249-253).
-struct GeomDev {
-  int nx, ny, nz, ccw;
-  int ix0, nx_total;              // x-slab: rows [ix0, ix0+nx) of an nx_total-wide grid
-  double cs;
-  double ca, sa, cb, sb;          // derotation: alpha = inc - 90 (about x), beta = pa (about y)
-  double ca2, sa2, cb2, sb2;      // velocity rotation: alpha = 90 - inc, beta = -pa
-  double w_0, r_0, mr0, eps, R_1, R_2;
-  double gm;                      // G * M_star * MSOL [SI]
-  double v_lsr;
-  double n_0, x_0, T_0, v_0;
-  double q_n, q_x, q_T, q_v, qd_n, qd_x, qd_T, qd_v;
-  double rb_frac;
-  double ts_const, ts_pow, ts_base;   // ts = ts_const * (rad^ts_pow - ts_base)  [q^d_v == 0]
-  int ts_mode;                        // 0 = skip, 1 = closed form (q^d_v = 0), 2 = with 2F1
-  // q^d_v != 0 (maths/geometry.py:150-178): a = q^d_v, b = (1 - q_v + eps q^d_v)/eps,
-  // hypergeometric connection coefficients K1 = b/(b-a), K2 = Gamma(b+1)Gamma(a-b)/Gamma(a)
-  double hy_a, hy_b, hy_k1, hy_k2, hy_axis;
-  double r1_m, r2_m, w0_m, mr0_m, r0_m;
-};
 
 // x^p for a finite normal x > 0 and |p log2 x| < 1000, relative error < 1e-14 (|p log2 x| up
 // to ~100): log2 x = e + 2 atanh((m-1)/(m+1)) log2(e) with m in [sqrt(1/2), sqrt 2) (degree-9
@@ -407,5 +388,22 @@ __global__ __launch_bounds__(kFB) void build_fields_kernel(GeomDev g, T* nd, T* 
   }
 }
 #pragma clang fp contract(fast)
+
+hipError_t build_fields_launch(const GeomDev& g, int dtype, void* nd, void* xi, void* temp,
+                               void* pf, void* ts, void* vy, double* ff_raw, double* areas_raw,
+                               double* vx_raw, double* vz_raw, void* em0, void* a0, int a0_mode,
+                               hipStream_t st) {
+  const int64_t n = (int64_t)g.nx * g.ny * g.nz;
+  const unsigned blocks = (unsigned)((n + kFB - 1) / kFB);
+  if (dtype == RJP_F64)
+    hipLaunchKernelGGL(build_fields_kernel<double>, dim3(blocks), dim3(kFB), 0, st, g, (double*)nd,
+                       (double*)xi, (double*)temp, (double*)pf, (double*)ts, (double*)vy, ff_raw,
+                       areas_raw, vx_raw, vz_raw, (double*)em0, (double*)a0, a0_mode);
+  else
+    hipLaunchKernelGGL(build_fields_kernel<float>, dim3(blocks), dim3(kFB), 0, st, g, (float*)nd,
+                       (float*)xi, (float*)temp, (float*)pf, (float*)ts, (float*)vy, ff_raw,
+                       areas_raw, vx_raw, vz_raw, (float*)nullptr, (float*)nullptr, 0);
+  return hipGetLastError();
+}
 
 }  // namespace rjp

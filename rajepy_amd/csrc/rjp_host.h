@@ -1,0 +1,115 @@
+// Host-side interface between the translation units of librjprt (rjprt.hip = the C-ABI,
+// ff_scan.hip, ff_scan_inst.hip x 5, fields.hip, rrl_scan.hip): launch wrappers and the small
+// structs they exchange.  Nothing here is exported; the library's surface is include/rjprt.h.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#include <vector>
+
+#include "rjp_device.h"
+
+namespace rjp {
+
+// ---- ff_scan.hip --------------------------------------------------------------------------
+// The epoch tiling of one scan, decided on the host before anything is enqueued, so that the
+// constants of bursts beyond RJP_SGPR_BURSTS (parameters + one q per tile) and the step tables
+// of the uniform-epoch tiles can travel to the device in ONE small table:
+// ext = [params: 6 * next][tile 0: q (2 * next), step table (2 * nbt * 16 or 0)][tile 1 ...] ...
+struct ScanTile {
+  int e0, et;
+  UnifDev un;          // un.qext / un.atab are patched to the device table by ff_scan_run
+  size_t q_off, a_off; // offsets of the tile's q and step table in ScanPlan::ext
+  int nsplit, ylen;    // y-ranges of this tile's launch
+};
+struct ScanPlan {
+  bool bursts = false;
+  int vec = 1, next = 0;
+  std::vector<ScanTile> tiles;
+  std::vector<double> ext;       // host image of the overflow table (empty without overflow)
+};
+
+int ff_scan_vec(const rjp_fields* fl);
+int scan_layout(const rjp_fields* fl, int mode, bool want_em);
+bool tile_dma_ok(const rjp_fields* fl);
+size_t ff_scan_workspace_bytes(int nx, int ny, int nz, int n_epochs);
+void ff_scan_plan(const rjp_fields* fl, const rjp_bursts* hb, const double* epochs, int n_epochs,
+                  bool want_em, ScanPlan& pl);
+hipError_t ff_scan_run(const rjp_fields* fl, const rjp_bursts* hb, const ScanPlan& pl,
+                       const double* d_ext, const double* epochs, int n_epochs, int mode,
+                       double* sumA, double* em, double* tavg, double* ws, hipStream_t st);
+hipError_t tavg_launch(const rjp_fields* fl, double* tavg, double* ws, hipStream_t st);
+hipError_t y_bounds_launch(const rjp_fields* fl, int32_t* ylo, int32_t* yhi, hipStream_t st);
+hipError_t ff_cells_launch(const rjp_fields* fl, const rjp_bursts* hb, const double* d_ext,
+                           double time_s, int mode, const double* d_ctau, int nchan, double* out,
+                           hipStream_t st);
+size_t ff_maps_workspace_bytes(int64_t npix, int n_epochs, int n_chan);
+hipError_t ff_maps_launch(const double* sumA, const double* tavg, int64_t npix, int n_epochs,
+                          const double* d_ctau, const double* d_cflux, int n_chan, double* tau,
+                          double* flux, double* ftot, double* part, hipStream_t st);
+// out[row] = sum of part[row * nblk .. + nblk) in a fixed order
+hipError_t sum_partials_launch(const double* part, int rows, int nblk, double* out,
+                               hipStream_t st);
+
+// ---- ff_scan_inst.hip: one slice of the K1 kernel family per translation unit -------------
+#define RJP_SCAN_SLICE_ARGS                                                                  \
+  const rjp_fields *fl, const BurstsDev &b, bool bursts, const double *t, const UnifDev &un, \
+      int et, int nsplit, int ylen, double *ws, bool want_em, hipStream_t st
+hipError_t scan_f64_tau(int vec, RJP_SCAN_SLICE_ARGS);
+hipError_t scan_f64_cmp_scalar(int vec, RJP_SCAN_SLICE_ARGS);
+hipError_t scan_f64_cmp_plaw(int vec, RJP_SCAN_SLICE_ARGS);
+hipError_t scan_f64_wide(int vec, const rjp_fields* fl, const BurstsDev& b, bool bursts, int mode,
+                         const double* t, const UnifDev& un, int et, int nsplit, int ylen,
+                         double* ws, bool want_em, hipStream_t st);
+hipError_t scan_f32(int vec, int lay, const rjp_fields* fl, const BurstsDev& b, bool bursts,
+                    int mode, const double* t, const UnifDev& un, int et, int nsplit, int ylen,
+                    double* ws, bool want_em, hipStream_t st);
+
+// ---- fields.hip ---------------------------------------------------------------------------
+struct GeomDev {
+  int nx, ny, nz, ccw;
+  int ix0, nx_total;              // x-slab: rows [ix0, ix0+nx) of an nx_total-wide grid
+  double cs;
+  double ca, sa, cb, sb;          // derotation: alpha = inc - 90 (about x), beta = pa (about y)
+  double ca2, sa2, cb2, sb2;      // velocity rotation: alpha = 90 - inc, beta = -pa
+  double w_0, r_0, mr0, eps, R_1, R_2;
+  double gm;                      // G * M_star * MSOL [SI]
+  double v_lsr;
+  double n_0, x_0, T_0, v_0;
+  double q_n, q_x, q_T, q_v, qd_n, qd_x, qd_T, qd_v;
+  double rb_frac;
+  double ts_const, ts_pow, ts_base;   // ts = ts_const * (rad^ts_pow - ts_base)  [q^d_v == 0]
+  int ts_mode;                        // 0 = skip, 1 = closed form (q^d_v = 0), 2 = with 2F1
+  // q^d_v != 0 (maths/geometry.py:150-178): a = q^d_v, b = (1 - q_v + eps q^d_v)/eps,
+  // hypergeometric connection coefficients K1 = b/(b-a), K2 = Gamma(b+1)Gamma(a-b)/Gamma(a)
+  double hy_a, hy_b, hy_k1, hy_k2, hy_axis;
+  double r1_m, r2_m, w0_m, mr0_m, r0_m;
+};
+
+hipError_t pack_field_launch(const double* src, const double* den, const uint8_t* red, void* dst,
+                             int64_t n, int dtype, hipStream_t st);
+hipError_t compact_fields_launch(const rjp_fields* fl, void* d_em0, int64_t* d_n_bad,
+                                 hipStream_t st);
+hipError_t tau_field_launch(const rjp_fields* fl, int gff_mode, void* d_a0, hipStream_t st);
+hipError_t synth_launch(uint64_t seed, int temp_mode, int nz, int64_t cell0, int64_t n, int dtype,
+                        void* nd, void* xi, void* temp, void* pf, void* ts, void* vy, void* em0,
+                        void* a0, int a0_mode, hipStream_t st);
+hipError_t build_fields_launch(const GeomDev& g, int dtype, void* nd, void* xi, void* temp,
+                               void* pf, void* ts, void* vy, double* ff_raw, double* areas_raw,
+                               double* vx_raw, double* vz_raw, void* em0, void* a0, int a0_mode,
+                               hipStream_t st);
+
+// ---- rrl_scan.hip -------------------------------------------------------------------------
+hipError_t rrl_scan_launch(const rjp_fields* fl, const rjp_bursts* hb, const double* d_ext,
+                           double time_s, const rjp_line* line, const double* h_nu,
+                           const double* d_nu, int nchan, double* tau, hipStream_t st);
+hipError_t rrl_cells_launch(const rjp_fields* fl, const rjp_bursts* hb, const double* d_ext,
+                            double time_s, const rjp_line* line, const double* h_nu,
+                            const double* d_nu, int nchan, double* out, hipStream_t st);
+hipError_t rrl_maps_launch(const double* tau_rrl, const double* tau_ff, const double* tavg,
+                           const double* flux_ff, int64_t npix, const double* d_cflux,
+                           const double* d_hnu_k, int nchan, double* flux, double* ftot,
+                           double* part, hipStream_t st);
+
+}  // namespace rjp

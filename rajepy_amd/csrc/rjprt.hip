@@ -1,5 +1,6 @@
 // librjprt.so -- C-ABI entry points (include/rjprt.h) over the gfx950 kernels.
-// Single translation unit: the kernel sources are included below.
+// The kernels live in their own translation units (ff_scan*.hip, fields.hip, rrl_scan.hip;
+// csrc/Makefile builds them in parallel); rjp_host.h declares their launch wrappers.
 #include <hip/hip_runtime.h>
 
 #include <cmath>
@@ -9,9 +10,7 @@
 #include <string>
 #include <vector>
 
-#include "ff_scan.hip"
-#include "fields.hip"
-#include "rrl_scan.hip"
+#include "rjp_host.h"
 
 struct rjp_ctx {
   int device = -1;
@@ -508,20 +507,9 @@ int rjp_build_fields(rjp_ctx* ctx, const rjp_geometry* gm, int dtype, void* d_nd
       g.ts_mode = 2;
     }
   }
-  const int64_t n = (int64_t)g.nx * g.ny * g.nz;
-  const unsigned blocks = (unsigned)((n + rjp::kFB - 1) / rjp::kFB);
-  hipStream_t st = (hipStream_t)stream;
-  if (dtype == RJP_F64)
-    hipLaunchKernelGGL(rjp::build_fields_kernel<double>, dim3(blocks), dim3(rjp::kFB), 0, st, g,
-                       (double*)d_nd, (double*)d_xi, (double*)d_temp, (double*)d_pf,
-                       (double*)d_ts, (double*)d_vy, d_ff_raw, d_areas_raw, d_vx_raw, d_vz_raw,
-                       (double*)d_em0, (double*)d_a0, (int)a0_mode);
-  else
-    hipLaunchKernelGGL(rjp::build_fields_kernel<float>, dim3(blocks), dim3(rjp::kFB), 0, st, g,
-                       (float*)d_nd, (float*)d_xi, (float*)d_temp, (float*)d_pf, (float*)d_ts,
-                       (float*)d_vy, d_ff_raw, d_areas_raw, d_vx_raw, d_vz_raw, (float*)nullptr,
-                       (float*)nullptr, 0);
-  RJP_HIP(ctx, hipGetLastError());
+  RJP_HIP(ctx, rjp::build_fields_launch(g, dtype, d_nd, d_xi, d_temp, d_pf, d_ts, d_vy, d_ff_raw,
+                                        d_areas_raw, d_vx_raw, d_vz_raw, d_em0, d_a0, (int)a0_mode,
+                                        (hipStream_t)stream));
   return RJP_OK;
 }
 

@@ -13,7 +13,7 @@
 //            (NaN prefactor) are skipped with a wave-uniform branch.
 // Compute-bound (vector FP64): ~200 FP64 instructions per (cell, channel); HBM traffic is
 // 6 fields per cell, read once per block of 256 channels.
-#include "rjp_device.h"
+#include "rjp_host.h"
 
 namespace rjp {
 
@@ -1026,11 +1026,7 @@ hipError_t rrl_maps_launch(const double* tau_rrl, const double* tau_ff, const do
                      ftot ? part : nullptr);
   hipError_t err = hipGetLastError();
   if (err != hipSuccess) return err;
-  if (ftot) {
-    hipLaunchKernelGGL(sum_partials_kernel, dim3((unsigned)nchan), dim3(kRB), 0, st, part,
-                       (int)nblk, ftot);
-    err = hipGetLastError();
-  }
+  if (ftot) err = sum_partials_launch(part, nchan, (int)nblk, ftot, st);
   return err;
 }
 
