@@ -3,16 +3,34 @@
 // The reference evaluates scipy.special.wofz over the WHOLE 3-D grid once per channel and
 // recomputes every channel-independent per-cell quantity each time
 // (classes.py:1159-1214; maths/rrls.py:350-354, 383-389).  Here a 256-thread workgroup owns a
-// tile of 16 z-adjacent sightlines of one x-row and up to 256 channels:
-//   phase 1  the 256 threads turn a slab of 16 y x 16 z cells into per-cell line constants
-//            (Doppler-shifted nu0, 1/(sigma sqrt2), Voigt y, LTE prefactor, h/kT ...) staged
-//            in LDS -- each cell's constants are computed once, not once per channel;
-//   phase 2  lanes run over CHANNELS: every lane reads the same cell's constants from LDS
-//            (broadcast), evaluates Re w(x+iy) for its channel and accumulates tau in FP64
-//            registers, one accumulator per sightline of the tile.  Cells outside the jet
-//            (NaN prefactor) are skipped with a wave-uniform branch.
-// Compute-bound (vector FP64): ~200 FP64 instructions per (cell, channel); HBM traffic is
-// 6 fields per cell, read once per block of 256 channels.
+// tile of z-adjacent sightlines of one x-row -- 8 sightlines for the 256-channel-lane layout,
+// 16 for the 64- and 16-lane ones -- and a block of up to 256 channels:
+//   phase 1  the 256 threads turn a slab of 256 cells (32 y x 8 z, or 16 y x 16 z) into
+//            per-cell line constants (Doppler-shifted nu0, 1/(sigma sqrt2), Voigt y, LTE
+//            prefactor, h/kT, pole-term constants) staged in LDS -- once per cell, not once
+//            per channel -- and, for the layouts whose waves work on one cell at a time, into
+//            one path code per (cell, wave): which of the Faddeeva paths below the whole wave
+//            takes for that cell;
+//   phase 2  lanes run over CHANNELS (folded about the block centre, so that a wave holds a
+//            narrow |x| range): every lane reads the same cell's constants from LDS
+//            (broadcast), branches on the wave's path code (a scalar), evaluates Re w(x+iy)
+//            for its channel and accumulates tau in FP64; the per-(sightline, channel)
+//            accumulators live in LDS, so the sightline loop is not unrolled (< 128 VGPRs,
+//            4 waves per SIMD).  Cells outside the jet are skipped with a scalar branch.
+// Compute-bound (vector FP64) by construction -- ~105 VALU instructions per (cell, channel) on
+// cfg3's fields, census in profiles/r03_k3_census.md; HBM traffic is 6 fields per cell, read
+// once per block of 256 channels.
+//
+// Accuracy budget.  The wave-uniform paths (far-field series, plain lattice with or without the
+// pole term, centred lattice) are designed for <= 1e-8 relative on Re w against
+// scipy.special.wofz over their whole domain -- one order inside SURVEY.md section 7's 1e-7,
+// three inside BASELINE.json's 1e-5 on the maps: lattice step h = 0.675 with 8 node pairs
+// (3.4e-9), 6- and 4-term far-field series (4.1e-9 / 1.2e-9), pole term skipped where a
+// rigorous bound puts it below 3e-8 Re w (measured <= 1.5e-9), centred lattice with 7 nodes a
+// side (7e-10); tools/voigt_design.py restates each path in NumPy and prints this table.
+// Rounds 1-2 held them to 1e-11 (h = 0.6, 10 pairs, 8/5 terms): 131 instead of ~105
+// instructions.  The generic per-lane path (16-lane layout, collapse=False, irregular cells)
+// keeps h = 0.6 / 10 pairs / 1e-11.
 #include "rjp_host.h"
 
 namespace rjp {
@@ -26,12 +44,16 @@ constexpr int kRB = 256;     // threads per workgroup
 //  * y < 0.03, where sum and pole term of the plain lattice would cancel near a node:
 //    - kernels whose waves work on one cell: lattice centred on x (voigt_centred below);
 //    - otherwise: lattice shifted by h/2 whenever x is within h/4 of a node.
-// With h = 0.6 the relative error of Re w is < 1e-11 for 1e-10 <= y <= 1e3, 0 <= x <= 1e4
-// (measured against scipy.special.wofz, which the reference calls).
-// Far field (|z|^2 > 64 and (x^2 > 64 or y > 1)): 6-term Laplace continued fraction,
+// Generic per-lane code (voigt_rew): h = 0.6, 10 node pairs: relative error of Re w < 1e-11
+// for 1e-10 <= y <= 1e3, 0 <= x <= 1e4 (measured against scipy.special.wofz, which the reference
+// calls); far field (|z|^2 > 64 and (x^2 > 64 or y > 1)): 6-level Laplace continued fraction,
 // relative error < 3e-10 there.
 constexpr double kH = 0.6;
 constexpr int kNPair = 10;
+// Wave-uniform paths (voigt_plain_wave, voigt_centred, voigt_far_series): h = 0.675, 8 node
+// pairs: <= 1e-8 (tools/voigt_design.py)
+constexpr double kHW = 0.675;
+constexpr int kNPairW = 8;
 // node tables for the two lattices (delta = 0 and delta = 1/2): tau = t^2, w = 2 exp(-tau)
 // (the self-paired node t = 0 carries half weight), wt = w tau
 __device__ __constant__ double c_tau0[kNPair] = {0.0, 0.36, 1.44, 3.2399999999999993, 5.76, 9.0, 12.959999999999997, 17.64, 23.04, 29.159999999999993};
@@ -106,8 +128,8 @@ __device__ __forceinline__ double kmul(double K, double b);
 struct PoleTop { double cos_top, exp_top; };
 __device__ __forceinline__ PoleTop pole_top() {
   PoleTop t;
-  asm volatile("v_mov_b64 %0, %1" : "=v"(t.cos_top) : "s"(-1.10650535275172774e-11));
-  asm volatile("v_mov_b64 %0, %1" : "=v"(t.exp_top) : "s"(2.48136182542816624e-06));
+  asm volatile("v_mov_b64 %0, %1" : "=v"(t.cos_top) : "s"(2.00440237723759486e-09));
+  asm volatile("v_mov_b64 %0, %1" : "=v"(t.exp_top) : "s"(2.50213726461024045e-05));
   return t;
 }
 
@@ -122,15 +144,15 @@ __device__ __forceinline__ void cos_2pi_x3(double u0, double u1, double u2, doub
     w2[i] = w * w;
   }
   // near-minimax on |w| <= pi/2 with the two leading coefficients kept at 1, -1/2 (inline
-  // constants): degree 14, max abs error 1e-14 (tools/minimax_fit.py) -- three FMAs per
-  // cosine fewer than the degree-20 Taylor polynomial this replaced
-  constexpr double cf[5] = {2.08632488319929278e-09, -2.75571005464740897e-07,
-                            2.48015855574161217e-05, -1.38888888828295133e-03,
-                            4.16666666666052621e-02};
+  // constants): degree 12, max abs error 3.9e-12 (tools/minimax_fit.py; the pole term enters
+  // Re w amplified by at most ~10 where sum and pole term cancel, y >= 0.03) -- degree 14
+  // (1e-14) in round 2, degree-20 Taylor in round 1
+  constexpr double cf[4] = {-2.75347756843411723e-07, 2.48013152427276996e-05,
+                            -1.38888875194187922e-03, 4.16666666468048091e-02};
 #pragma unroll
   for (int i = 0; i < 3; ++i) p[i] = fma_k(top, w2[i], cf[0]);
 #pragma unroll
-  for (int j = 1; j < 5; ++j)
+  for (int j = 1; j < 4; ++j)
 #pragma unroll
     for (int i = 0; i < 3; ++i) p[i] = fma_k(p[i], w2[i], cf[j]);
 #pragma unroll
@@ -154,14 +176,13 @@ __device__ __forceinline__ double exp_k(double x, double top) {
   const double kd = __builtin_rint(kmul(1.4426950408889634074, x));
   double r = kfma(-6.93147180369123816490e-01, kd, x);
   r = kfma(-1.90821492927058770002e-10, kd, r);
-  // degree 9, near-minimax on |r| <= ln2/2 with 1, 1, 1/2 kept: relative error 1.2e-13
+  // degree 8, near-minimax on |r| <= ln2/2 with 1, 1, 1/2 kept: relative error 1.6e-12
   // (tools/minimax_fit.py); only the pole term uses this exp
-  double p = fma_k(top, r, 2.48694657480789912e-05);
-  p = fma_k(p, r, 1.98481138785137922e-04);
-  p = fma_k(p, r, 1.38888369809909941e-03);
-  p = fma_k(p, r, 8.33332808680723944e-03);
-  p = fma_k(p, r, 4.16666667860245560e-02);
-  p = fma_k(p, r, 1.66666666787199630e-01);
+  double p = fma_k(top, r, 1.99141676370814211e-04);
+  p = fma_k(p, r, 1.38885875111343206e-03);
+  p = fma_k(p, r, 8.33327326606923997e-03);
+  p = fma_k(p, r, 4.16666677111410463e-02);
+  p = fma_k(p, r, 1.66666668158620745e-01);
   p = __builtin_fma(p, r, 0.5);
   p = __builtin_fma(p, r, 1.0);
   p = __builtin_fma(p, r, 1.0);
@@ -254,7 +275,9 @@ __device__ __attribute__((noinline)) double pole_term_plain(double ax, double y,
 // 1/((k+1/2)^2 h^2 + y^2) in a 64-entry LDS table, one entry per lane.  The Gaussian weights
 // of a lane follow a recurrence outward from the node nearest t = 0 (|t_m| <= h/2):
 // E_{j+1} = E_j R_j, R_{j+1} = R_j exp(-2 h^2) -- two short polynomials instead of 21 exp.
-// Relative error < 3e-12 for 1e-10 <= y < 0.03, 0 <= x <= 16 (against scipy.special.wofz).
+// h = 0.675, 7 nodes on each side of the middle one, exp polynomials of degree 6 / 10: relative
+// error < 1e-9 for 1e-10 <= y < 0.03, 0 <= x <= 16 (against scipy.special.wofz;
+// tools/voigt_design.py -- rounds 1-2: h = 0.6, 10 nodes a side, 3e-12).
 // The centred lattice is valid for every y < pi/h (the parity tests pass with any bound); it is
 // USED below y = 0.03, where the plain lattice would cancel: above, the paired plain lattice is
 // cheaper (cfg3: 775 ms with the bound at 0.03, 815 at 0.1, 880 at 0.3, 970 at 1.0;
@@ -264,8 +287,8 @@ __device__ __attribute__((noinline)) double pole_term_plain(double ax, double y,
 #endif
 constexpr double kCenYMax = RJP_CEN_YMAX;
 static_assert(kCenYMax >= 0.03 && kCenYMax <= 5.0, "plain lattice needs y >= 0.03; q > 0 needs y < pi/h");
-constexpr int kCenJ = 10;            // nodes on each side of the middle one
-constexpr int kCenOff = 38;          // table index of k = 0; window [km-10, km+10], km >= -27
+constexpr int kCenJ = 7;             // nodes on each side of the middle one
+constexpr int kCenOff = 38;          // table index of k = 0; window [km-7, km+7], km >= -25
 constexpr double kCenXMax = 16.0;    // beyond: continued fraction (the table ends)
 
 __device__ __forceinline__ void wave_lds_fence() {
@@ -292,26 +315,24 @@ __device__ __forceinline__ double voigt_centred(double ax, double y, double q, d
   // wave-uniform and so is the branch that leads here)
   {
     const int lane = threadIdx.x & (RJP_WAVE - 1);
-    const double a = ((double)(lane - kCenOff) + 0.5) * kH;
+    const double a = ((double)(lane - kCenOff) + 0.5) * kHW;
     wave_lds_fence();                       // earlier readers of the previous cell's table
     tab[lane] = rcp_fast(__builtin_fma(a, a, y * y));
     wave_lds_fence();
   }
   const double axc = fmin(ax, kCenXMax);
-  const double km = __builtin_rint(__builtin_fma(axc, -1.0 / kH, -0.5));
-  const double tm = __builtin_fma(km + 0.5, kH, axc);          // |tm| <= h/2
-  const double w = tm * tm;                                     // <= 0.09
-  double em = -1.0 / 5040.0;                                    // exp(-w), degree 7
-  em = __builtin_fma(em, w, 1.0 / 720.0);
+  const double km = __builtin_rint(__builtin_fma(axc, -1.0 / kHW, -0.5));
+  const double tm = __builtin_fma(km + 0.5, kHW, axc);         // |tm| <= h/2
+  const double w = tm * tm;                                     // <= 0.114
+  double em = 1.0 / 720.0;                                      // exp(-w), degree 6 (5e-11)
   em = __builtin_fma(em, w, -1.0 / 120.0);
   em = __builtin_fma(em, w, 1.0 / 24.0);
   em = __builtin_fma(em, w, -1.0 / 6.0);
   em = __builtin_fma(em, w, 0.5);
   em = __builtin_fma(em, w, -1.0);
   em = __builtin_fma(em, w, 1.0);
-  const double v = (-2.0 * kH) * tm;                            // |v| <= 0.36
-  double u = 2.505210838544172e-08;                             // exp(v), degree 11
-  u = __builtin_fma(u, v, 2.755731922398589e-07);
+  const double v = (-2.0 * kHW) * tm;                           // |v| <= 0.456
+  double u = 2.755731922398589e-07;                             // exp(v), degree 10 (4e-12)
   u = __builtin_fma(u, v, 2.7557319223985893e-06);
   u = __builtin_fma(u, v, 2.48015873015873e-05);
   u = __builtin_fma(u, v, 1.984126984126984e-04);
@@ -322,8 +343,8 @@ __device__ __forceinline__ double voigt_centred(double ax, double y, double q, d
   u = __builtin_fma(u, v, 0.5);
   u = __builtin_fma(u, v, 1.0);
   u = __builtin_fma(u, v, 1.0);
-  constexpr double kC1 = 0.69767632607103103;                   // exp(-h^2)
-  constexpr double kQ = 0.48675225595997168;                    // exp(-2 h^2)
+  constexpr double kC1 = 0.6340515618580675;                    // exp(-h^2), h = 0.675
+  constexpr double kQ = 0.40202138309465485;                    // exp(-2 h^2)
   const double* t = tab + ((int)km + kCenOff);
   double s = em * t[0];
   double e = em, r = kC1 * u;                                   // towards +t
@@ -338,16 +359,15 @@ __device__ __forceinline__ double voigt_centred(double ax, double y, double q, d
     e *= r; r *= kQ;
     s = __builtin_fma(e, t[-j], s);
   }
-  s *= y * (kH / 3.14159265358979323846);
-  // pole term: below 1e-13 Re w once x^2 exceeds the per-cell bound cq; skipped when no lane
-  // of the wave needs it
+  s *= y * (kHW / 3.14159265358979323846);
+  // pole term: below 3e-8 Re w by a rigorous bound (measured: 1e-9) once x^2 exceeds the
+  // per-cell bound cq; skipped when no lane of the wave needs it
   if (__builtin_amdgcn_ballot_w64(ax * ax < cq) != 0) {
     double c;
     if (kCenYMax <= 0.03 || y < 0.03) {
-      const double th = 2.0 * ax * y, t2 = th * th;             // < 1 wherever the term matters
-      c = 1.0 / 479001600.0;                                    // cos(th), degree 12
-      c = __builtin_fma(c, t2, -1.0 / 3628800.0);
-      c = __builtin_fma(c, t2, 1.0 / 40320.0);
+      // th = 2 x y < 0.4 wherever the term matters (x^2 < cq < 40, y < 0.03): degree 8, 5e-13
+      const double th = 2.0 * ax * y, t2 = th * th;
+      c = 1.0 / 40320.0;                                        // cos(th), degree 8
       c = __builtin_fma(c, t2, -1.0 / 720.0);
       c = __builtin_fma(c, t2, 1.0 / 24.0);
       c = __builtin_fma(c, t2, -0.5);
@@ -469,9 +489,9 @@ __device__ __forceinline__ double kmul(double K, double b) {                 // 
 // Far field, every lane of the wave: asymptotic series of w(z) in u = 1/z^2,
 //   w(z) ~ (i / (sqrt(pi) z)) sum_k (2k-1)!!/2^k u^k,   Re w = (y Re S - x Im S) / (|z|^2 sqrt pi),
 // ONE reciprocal per evaluation (the Laplace continued fraction above needs one per level).
-// Truncation after K terms, measured against scipy.special.wofz over 1e-10 <= y <= 1e3:
-// |z|^2 > 64 (the Gaussian core exp(-x^2) <= 1.6e-28 is invisible there): K = 8 -> 8e-11;
-// |z|^2 > 144: K = 5 -> 2.5e-10.
+// Truncation after K terms, measured against scipy.special.wofz over 1e-10 <= y <= 1e3
+// (tools/voigt_design.py): |z|^2 > 64 (the Gaussian core exp(-x^2) <= 1.6e-28 is invisible
+// there): K = 6 -> 4.1e-9 (K = 8 -> 8e-11: rounds 1-2); |z|^2 > 196: K = 4 -> 1.2e-9.
 template <int K>
 __device__ __forceinline__ double voigt_far_series(double ax, double y) {
   constexpr double c[9] = {1.0, 0.5, 0.75, 1.875, 6.5625, 29.53125, 162.421875, 1055.7421875,
@@ -497,36 +517,37 @@ __device__ __forceinline__ double voigt_far_series(double ax, double y) {
   return __builtin_fma(y, pr, -ax * pi) * (r2 * inv) * 0.56418958354775628695;
 }
 
-// Plain lattice (y >= 0.03), every lane of the wave: the ten node pairs over ONE common
-// denominator -- a single reciprocal per evaluation.  With m_n = |z|^2 + t_n^2 the pair
+// Plain lattice (y >= 0.03), every lane of the wave: the eight node pairs (h = 0.675) over ONE
+// common denominator -- a single reciprocal per evaluation.  With m_n = |z|^2 + t_n^2 the pair
 // (+t_n, -t_n) is
 //   w_n [1/((x-t_n)^2+y^2) + 1/((x+t_n)^2+y^2)] = 2 w_n m_n / d_n,   d_n = m_n^2 - 4 t_n^2 x^2,
 // so numerator and denominator share m_n, and the node weights enter as RATIOS while the
 // fractions are merged (one constant multiply per merge instead of one per node).  The
 // d_n are >= y^4 >= 8e-7 with at most one pair near its minimum and <= ~|z|^4 each: their
-// product stays inside the FP64 range for |z| < 1e7 (path_code sends waves with larger |x|
+// product stays inside the FP64 range for |z| < 1e9 (path_code sends waves with |x| > 1e6
 // to the generic path).  Near a node d_n loses digits ~ t_n^2 / y^2, as the factored form
-// of the generic path does: relative error < 1e-11 against wofz for 0.03 <= y <= 1e3,
-// 0 <= x <= 1e4, pole term included.
+// of the generic path does.  Relative error <= 3.4e-9 against wofz for 0.03 <= y, x^2 <= 64,
+// pole term included (worst at x = 0 just above y = pi/h, where the pole term ends;
+// tools/voigt_design.py).  Rounds 1-2: h = 0.6, ten pairs, 1e-11.
 template <bool POLE>
 __device__ __forceinline__ double voigt_plain_wave(double ax, double y, double q,
                                                    const PoleTop& top) {
-  constexpr double tau[kNPair] = {0.0, 0.36, 1.44, 3.2399999999999993, 5.76, 9.0,
-                                  12.959999999999997, 17.64, 23.04, 29.159999999999993};
+  constexpr double tau[kNPairW] = {0.0, 0.45562500000000006, 1.8225000000000002,
+                                   4.100625000000002, 7.290000000000001, 11.390625,
+                                   16.402500000000007, 22.325625000000006};
   // w2[n] = 2 exp(-tau[n]) (w2[0] = 1): ratios w2[b]/w2[a] of the pairs (0,1) (2,3) ... and
   // of the merges
-  constexpr double w2[kNPair] = {1.0, 1.395352652142062, 0.47385551736424353,
-                                 0.0783277901979742, 0.006302223196888882,
-                                 0.0002468196081733591, 4.705150400019559e-06,
-                                 4.3659155902509556e-08, 1.9719011151983032e-10,
-                                 4.3351377652379543e-13};
-  static_assert(kNPair == 10, "five pairs of fractions below");
+  constexpr double w2[kNPairW] = {1.0, 1.268103123716135, 0.3232423849306784,
+                                  0.03312464143162309, 0.0013646561055127519,
+                                  2.2601872086292614e-05, 1.5049246515289555e-07,
+                                  4.028415451797932e-10};
+  static_assert(kNPairW == 8, "four pairs of fractions below");
   const double x2 = ax * ax;
   const double r2 = __builtin_fma(y, y, x2);
   const double X4 = -4.0 * x2;
-  double N[5], D[5];
+  double N[4], D[4];
 #pragma unroll
-  for (int a = 0; a < kNPair; a += 2) {
+  for (int a = 0; a < kNPairW; a += 2) {
     const double ma = a == 0 ? r2 : kadd(tau[a], r2);
     const double mb = kadd(tau[a + 1], r2);
     const double da = a == 0 ? ma * ma : kfma(tau[a], X4, ma * ma);
@@ -538,24 +559,23 @@ __device__ __forceinline__ double voigt_plain_wave(double ax, double y, double q
   // merges: N01 = N0 D1 + sigma N1 D0 with sigma the ratio of the fractions' scales
   const double N01 = __builtin_fma(N[0], D[1], kmul(w2[2] / w2[0], N[1] * D[0])), D01 = D[0] * D[1];
   const double N23 = __builtin_fma(N[2], D[3], kmul(w2[6] / w2[4], N[3] * D[2])), D23 = D[2] * D[3];
-  const double N03 = __builtin_fma(N01, D23, kmul(w2[4] / w2[0], N23 * D01)), D03 = D01 * D23;
-  const double Nall = __builtin_fma(N03, D[4], kmul(w2[8] / w2[0], N[4] * D03)), Dall = D03 * D[4];
+  const double Nall = __builtin_fma(N01, D23, kmul(w2[4] / w2[0], N23 * D01)), Dall = D01 * D23;
   // sum = w2[0] * Nall / Dall; Re w = (h y / pi) * sum
-  const double ky = kmul(w2[0] * kH / 3.14159265358979323846, y);
+  const double ky = kmul(w2[0] * kHW / 3.14159265358979323846, y);
   if (!POLE) return Nall * rcp_fast(Dall) * ky;
   // P = Re[ 2 exp(-z^2) q / (q - exp(-i theta)) ], theta = 2 pi x / h, for every lane (it
-  // is below 1e-11 Re w where x^2 exceeds the per-cell bound cq, and harmless there):
+  // is negligible where x^2 exceeds the per-cell bound cq, and harmless there):
   // Re[e^{-i phi} conj(q - e^{-i theta})] = q cos(phi) - cos(theta - phi), phi = 2 x y;
-  // |q - e^{-i theta}|^2 = 1 - 2 q cos(theta) + q^2 >= (1 - q)^2 >= 0.07 for y >= 0.03
-  const double e = __builtin_fma(y, y, -x2);      // in (-|x|^2, (pi/h)^2 = 27.4): no clamp
-  const double u = kmul(1.0 / kH, ax);                          // theta / 2 pi (+ whole turns)
+  // |q - e^{-i theta}|^2 = 1 - 2 q cos(theta) + q^2 >= (1 - q)^2 >= 0.06 for y >= 0.03
+  const double e = __builtin_fma(y, y, -x2);      // in (-|x|^2, (pi/h)^2 = 21.7): no clamp
+  const double u = kmul(1.0 / kHW, ax);                         // theta / 2 pi (+ whole turns)
   const double ph = kmul(0.31830988618379067154, ax * y);       // phi / 2 pi
   double cth, cph, cps;
   cos_2pi_x3(u, ph, u - ph, top.cos_top, cth, cph, cps);
   const double den = __builtin_fma(q, q - 2.0 * cth, 1.0);
   const double num = __builtin_fma(q, cph, -cps);
   // one reciprocal for both fractions: (Nall ky den + 2 E q num Dall) / (Dall den), with
-  // Dall <= (|z|^2 + 30)^20 < 1e40 for the |x| < 16 a wave of this path can hold
+  // Dall <= (|z|^2 + 23)^16 < 1e32 for the |x| <= 8 a wave of this path can hold
   const double pq = 2.0 * exp_k(e, top.exp_top) * q * num;
   return __builtin_fma(Nall * ky, den, pq * Dall) * rcp_fast(Dall * den);
 }
@@ -565,8 +585,8 @@ __device__ __forceinline__ double voigt_plain_wave(double ax, double y, double q
 // per lane.  One byte per wave of the channel block.
 enum : int {
   kPathSkip = 0,      // C == 0: the cell contributes nothing (outside the jet, NaN, ...)
-  kPathFar8 = 1,      // every lane far field, |z|^2 > 64
-  kPathFar5 = 2,      // every lane |z|^2 > 144
+  kPathFarA = 1,      // every lane far field, |z|^2 > 64: 6-term series
+  kPathFarB = 2,      // every lane |z|^2 > 196: 4-term series
   kPathPlain = 3,     // plain lattice, pole term negligible in every lane
   kPathPlainPole = 4, // plain lattice + pole term
   kPathCentred = 5,   // y < 0.03: centred lattice
@@ -610,7 +630,8 @@ __device__ __forceinline__ CellLine cell_line(const RrlFields<T>& f, int64_t o,
                                               const BurstsDev& b, double time_s,
                                               const LineDev& ln) {
   CellLine c;
-  const double kPiOverH = 3.14159265358979323846 / kH;
+  // (the layouts whose waves work on one cell take the wave-uniform paths: their lattice step)
+  const double kPiOverH = 3.14159265358979323846 / (CEN ? kHW : kH);
   const double nd = (double)f.nd[o], xi = (double)f.xi[o], Tk = (double)f.temp[o],
                pf = (double)f.pf[o], vy = (double)f.vy[o];
   double chi = 1.0;
@@ -630,13 +651,14 @@ __device__ __forceinline__ CellLine cell_line(const RrlFields<T>& f, int64_t o,
   const double lnq = -2.0 * kPiOverH * c.y;
   c.q = (c.y < kPiOverH) ? exp(lnq) : -1.0;
   const double omq = -expm1(lnq);                                  // 1 - q
-  // pole term needed iff y^2 - x^2 + ln(6 q / (1-q)^2) > ln(1e-11 y / (4 * 67)), i.e. iff
-  // x^2 < cq   (the wave-uniform kernels; the generic per-lane path keeps 1e-13)
+  // pole term needed iff y^2 - x^2 + ln(6 q / (1-q)^2) > ln(tol y / (4 * 67)), i.e. iff
+  // x^2 < cq; tol = 3e-8 for the wave-uniform kernels (a crude bound: the term left out is
+  // <= 1.5e-9 Re w when measured, tools/voigt_design.py), 1e-13 for the generic per-lane path
   c.cq = c.y * c.y + lnq + 1.7917594692280550 - 2.0 * log(omq) - log(0.25 * c.y) +
-         (CEN ? 25.3284360229345 : 29.9336062089226) + 4.2046926193909657;
+         (CEN ? 17.3221740089 : 29.9336062089226) + 4.2046926193909657;
   // centred lattice (y < 0.03): |P| <= exp(y^2 - x^2) and Re w >= y / (4 (|z|^2 + 1)) with
-  // |z|^2 <= 16^2 + 1: negligible iff x^2 > y^2 - ln y + ln(1e13) + ln(4 * 258)
-  if (CEN && c.y < kCenYMax) c.cq = c.y * c.y - log(c.y) + 29.9336062089226 + 6.9392539460415;
+  // |z|^2 <= 16^2 + 1: negligible iff x^2 > y^2 - ln y + ln(1 / 3e-8) + ln(4 * 258)
+  if (CEN && c.y < kCenYMax) c.cq = c.y * c.y - log(c.y) + 17.3221740089 + 6.9392539460415;
   if (!(c.C == c.C) || c.C == 0.0 || !(c.y > 0.0)) c.C = 0.0;     // nansum drops NaN terms
   return c;
 }
@@ -664,11 +686,13 @@ __device__ __forceinline__ int path_code(const CellLine& c, const double (&rg)[4
   const double x2min = xmin * xmin;
   const double r2min = __builtin_fma(c.y, c.y, x2min);
   if (!regular || !(xmax - xmax == 0.0)) code = kPathGeneric;
-  else if (r2min > 64.0 && (x2min > 64.0 || c.y > 1.0)) code = r2min > 144.0 ? kPathFar5 : kPathFar8;
+  else if (r2min > 64.0 && (x2min > 64.0 || c.y > 1.0)) code = r2min > 196.0 ? kPathFarB : kPathFarA;
   else if (xmax > 1e6) code = kPathGeneric;
   else if (c.y < kCenYMax) code = kPathCentred;
   else code = (c.q >= 0.0 && x2min < c.cq) ? kPathPlainPole : kPathPlain;
-  if (!(c.a * dnu_max < 1e-3)) code |= kPathExpFlag;
+  // 1 - E0 exp(-a dnu) to first order in a dnu: the dropped term (a dnu)^2 / 2 stays below
+  // 2e-9 of the factor itself (which is ~ a nu_ref for h nu << k T)
+  if (!(0.5 * (c.a * dnu_max) * (c.a * dnu_max) < 2e-9 * (1.0 - c.E0))) code |= kPathExpFlag;
   return code;
 }
 
@@ -695,7 +719,15 @@ __device__ __attribute__((noinline)) double line_term_generic(double C, double n
                                                               double q, double cq, double nu_f,
                                                               double dnu, double dnu_max) {
   CellLine c;
-  c.C = C; c.nu0 = nu0; c.is2 = is2; c.y = y; c.a = a; c.E0 = E0; c.q = q; c.cq = cq;
+  c.C = C; c.nu0 = nu0; c.is2 = is2; c.y = y; c.a = a; c.E0 = E0;
+  // q and cq as staged belong to the wave-uniform lattice (h = 0.675); the generic code runs
+  // its own (h = 0.6, pole term kept down to 1e-13 Re w): as cell_line<.., CEN = false>
+  (void)q; (void)cq;
+  const double kPiOverH = 3.14159265358979323846 / kH;
+  const double lnq = -2.0 * kPiOverH * y;
+  c.q = (y < kPiOverH) ? exp(lnq) : -1.0;
+  c.cq = y * y + lnq + 1.7917594692280550 - 2.0 * log(-expm1(lnq)) - log(0.25 * y) +
+         29.9336062089226 + 4.2046926193909657;
   return line_term<false>(c, nu_f, dnu, dnu_max, nullptr);
 }
 
@@ -867,16 +899,17 @@ __global__ __launch_bounds__(kRB, RJP_K3_WAVES) void rrl_scan_kernel(
           const double yv = s_y[ci];
           const double ax = fabs((nu_f - s_nu0[ci]) * s_is2[ci]);
           double V;
-          if (path == kPathFar8) V = voigt_far_series<8>(ax, yv);
-          else if (path == kPathFar5) V = voigt_far_series<5>(ax, yv);
+          if (path == kPathFarA) V = voigt_far_series<6>(ax, yv);
+          else if (path == kPathFarB) V = voigt_far_series<4>(ax, yv);
           else if (path == kPathPlain) V = voigt_plain_wave<false>(ax, yv, 0.0, ptop);
           else if (path == kPathPlainPole) V = voigt_plain_wave<true>(ax, yv, s_q[ci], ptop);
           else V = voigt_centred(ax, yv, s_q[ci], s_cq[ci], s_tab[tid / RJP_WAVE]);
           // 1 - exp(-h nu / kT) = 1 - E0 * exp(-a (nu - nu_ref))
+          // (to first order in a dnu over the band unless the path code says otherwise)
           const double eps = s_a[ci] * dnu;
           double ex;
           if (pc & kPathExpFlag) ex = exp(-eps);
-          else ex = __builtin_fma(eps, __builtin_fma(eps, __builtin_fma(eps, -1.0 / 6.0, 0.5), -1.0), 1.0);
+          else ex = 1.0 - eps;
           acc = __builtin_fma(s_C[ci] * V, __builtin_fma(-s_E0[ci], ex, 1.0), acc);
         }
       } else {

@@ -96,6 +96,69 @@ def test_cfg4_continuum_full_size(eng, dtype, tol):
         np.testing.assert_allclose(em_s[e], jet.emission_measure()[:, 0], rtol=tol)
     # every sightline of the dense set is optically relevant: no zeros, no NaNs
     assert bool(torch_all_finite(sumA8)) and float(sumA8.min().item()) > 0.0
+    del tau, flux
+
+    # (a') K2 exactly as the bench launches it: ONE epoch x the 256 channels of cfg4 (the
+    # channel axis is cut into 4 chunks of 64 over gridDim.z): the first and the last channel
+    # of the first, a middle and the last chunk against the oracle on the sampled sightlines
+    # (classes.py:1395-1397, 1473-1475, 1519-1521)
+    f256 = np.geomspace(1e9, 5e10, 256)
+    ct, cf = E.ff_channel_coeffs(f256, 0.5, 120., E.RJP_GFF_SCALAR, [ph.gff(nu, 1e4) for nu in f256])
+    tau, flux, ftot = eng.ff_maps(sumA8[1:2].contiguous(), tavg, ct, cf)
+    eng.synchronize()
+    chk = [0, 63, 64, 100, 191, 192, 255]
+    jet.time = ep[1]
+    np.testing.assert_allclose(tau[0][chk][:, idx].cpu().numpy(),
+                               jet.optical_depth_ff(f256[chk])[:, :, 0], rtol=tol)
+    np.testing.assert_allclose(flux[0][chk][:, idx].cpu().numpy(),
+                               jet.flux_ff(f256[chk])[:, :, 0], rtol=tol)
+    np.testing.assert_allclose(ftot.cpu().numpy(), flux.nansum(dim=2).cpu().numpy(), rtol=1e-12)
+
+
+@pytest.mark.parametrize("temp_mode", [0, 1])
+def test_cfg4_tau_layout_is_bit_identical_at_full_size(eng, temp_mode):
+    """512x4096x512: the tau layout (a0, ts: 16 B/cell; + em0 with EM maps) against the compact
+    (3-field) and wide (5-field) scans of the same 1.07e9 cells, bit for bit over every
+    sightline -- single epoch as the bench launches it (no EM, no T_avg), single epoch with EM,
+    an 8-epoch direct tile and the 32-epoch uniform tile; T_avg from rjp_tavg == the scans'.
+    Both Gaunt branches (classes.py:1388-1397, 1421-1429)."""
+    import torch
+    from rajepy_amd import engine as E
+    shape = (512, 4096, 512)
+    mode = E.RJP_GFF_SCALAR if temp_mode == 0 else E.RJP_GFF_POWERLAW
+    fields = eng.synth_fields(shape, SEED, temp_mode, 8, csize_au=0.5, tau_mode=mode)
+    assert fields.a0 is not None and fields.scan_fields(mode, False) == 2
+    jet = _sample_jet(shape, [(0, 0)], temp_mode, 0. if temp_mode == 0 else -0.5)
+    bursts = U.bursts_from_oracle(jet)
+    e1 = [1.0 * orc.YEAR]
+    e8 = [y * orc.YEAR for y in (0.3, 0.9, 1.0, 1.7, 2.2, 2.9, 3.6, 4.4)]
+    e32 = [float(t) for t in np.linspace(0., 5., 32) * orc.YEAR]
+    cases = [(e1, False), (e1, True), (e8, False), (e32, False)]
+    if temp_mode == 0:
+        cases.append((e32, True))
+
+    def run():
+        out = []
+        for ep, em in cases:
+            a, g, _ = eng.ff_scan(fields, bursts, ep, mode, want_em=em, want_tavg=False)
+            out.append((a.clone(), None if g is None else g.clone()))
+        return out
+    got = run()
+    tav = eng.tavg(fields).clone()
+    a0, fields.a0 = fields.a0, None                      # compact layout
+    cmp_ = run()
+    t_cmp = eng.ff_scan(fields, bursts, e1, mode)[2].clone()
+    em0, fields.em0 = fields.em0, None                   # wide layout
+    wide = [eng.ff_scan(fields, bursts, ep, mode, want_em=em) for ep, em in cases[:2]]
+    eng.synchronize()
+    for (a, g), (ac, gc) in zip(got, cmp_):
+        assert torch.equal(a, ac)
+        assert (g is None) == (gc is None) and (g is None or torch.equal(g, gc))
+    for (a, g), (aw, gw, tw) in zip(got[:2], wide):
+        assert torch.equal(a, aw) and (g is None or torch.equal(g, gw))
+        assert torch.equal(tav, tw)
+    assert torch.equal(tav, t_cmp)
+    fields.em0, fields.a0 = em0, a0
 
 
 def torch_all_finite(t):
@@ -122,7 +185,7 @@ def test_cfg3_rrl_full_size(eng):
     idx = [x * nz + z for (x, z) in pix]
     got = tau.cpu().numpy()[:, idx]
     ref = jet.optical_depth_rrl("H66a", np.asarray(rf))[:, :, 0]
-    np.testing.assert_allclose(got, ref, rtol=1e-9)
+    np.testing.assert_allclose(got, ref, rtol=U.K3_RTOL_WAVE)
     assert bool(torch_all_finite(tau))
 
 
@@ -248,5 +311,27 @@ def test_cfg3_rrl_256_channels_full_size(eng):
     idx = [x * nz + z for (x, z) in pix]
     got = tau.cpu().numpy()[:, idx]
     ref = jet.optical_depth_rrl("H66a", np.asarray(rf))[:, :, 0]
-    np.testing.assert_allclose(got, ref, rtol=1e-9)
+    np.testing.assert_allclose(got, ref, rtol=U.K3_RTOL_WAVE)
     assert bool(torch_all_finite(tau))
+
+    # the map stage of the same cube at the same size: continuum scan + K2 for the 256 channels
+    # + rrl_maps, flux_rrl with and without the continuum (classes.py:1319-1343;
+    # rrls.py:444-449) on the sampled sightlines, and the per-channel totals against the cube
+    from rajepy_amd import engine as E
+    from rajepy_amd.maths import physics as ph
+    rfa = np.asarray(rf)
+    gv = [ph.gff(nu, 1e4) for nu in rfa]
+    ctau, cflux = E.ff_channel_coeffs(rfa, 0.5, 120., E.RJP_GFF_SCALAR, gv)
+    cfl, hnu = E.rrl_channel_coeffs(rfa, 0.5, 120.)
+    sumA, _, tavg = eng.ff_scan(fields, U.bursts_from_oracle(jet), [jet.time], E.RJP_GFF_SCALAR)
+    tau_ff, flux_ff, _ = eng.ff_maps(sumA, tavg, ctau, cflux, want_ftot=False)
+    P = nx * nz
+    for contsub in (True, False):
+        flux, ftot = eng.rrl_maps(tau, tau_ff.reshape(nchan, P), tavg,
+                                  None if contsub else flux_ff.reshape(nchan, P), cfl, hnu)
+        eng.synchronize()
+        ref = jet.flux_rrl("H66a", rfa, contsub=contsub)[:, :, 0]
+        np.testing.assert_allclose(flux.cpu().numpy()[:, idx], ref, rtol=U.K3_RTOL_WAVE)
+        np.testing.assert_allclose(ftot.cpu().numpy(), flux.nansum(dim=1).cpu().numpy(),
+                                   rtol=1e-12)
+        del flux

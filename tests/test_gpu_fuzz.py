@@ -121,4 +121,4 @@ def test_k3_random_models(eng, seed):
         ref = jet.optical_depth_rrl(rrl, np.asarray(rf))
     got = tau.cpu().numpy().reshape(ref.shape)
     assert np.array_equal(got == 0, ref == 0)
-    np.testing.assert_allclose(got, ref, rtol=2e-9)
+    np.testing.assert_allclose(got, ref, rtol=U.k3_rtol(len(rf)))

@@ -208,7 +208,7 @@ def test_rrl_dense_synthetic_vs_oracle(eng, nchan):
     tau = eng.rrl_scan(fields, U.bursts_from_oracle(jet), jet.time, line, rf)
     eng.synchronize()
     ref = jet.optical_depth_rrl("H66a", np.asarray(rf))
-    np.testing.assert_allclose(tau.cpu().numpy().reshape(ref.shape), ref, rtol=1e-9)
+    np.testing.assert_allclose(tau.cpu().numpy().reshape(ref.shape), ref, rtol=U.k3_rtol(nchan))
 
 
 @pytest.mark.parametrize("tag", ["cfg1_example", "tilted"])
@@ -349,7 +349,7 @@ def test_no_bursts_paths(eng, dtype):
     eng.synchronize()
     ref = jet.optical_depth_rrl("H66a", np.asarray(rf))
     np.testing.assert_allclose(t.cpu().numpy().reshape(ref.shape), ref,
-                               rtol=1e-9 if dtype == 8 else RTOL)
+                               rtol=U.k3_rtol(len(rf)) if dtype == 8 else RTOL)
 
 
 @pytest.mark.parametrize("dtype", [8, 4])
@@ -432,7 +432,7 @@ def test_shape_edge_cases_with_and_without_bounds(eng, shape):
             # device's exp by 1/tau; these thin columns reach tau ~ 1e-6
             np.testing.assert_allclose(got, ref_flux, rtol=max(tol, 1e-9))
             np.testing.assert_allclose(trrl.cpu().numpy().reshape(ref_rrl.shape), ref_rrl,
-                                       rtol=max(tol, 1e-9))
+                                       rtol=max(tol, U.k3_rtol(len(rf))))
 
 
 @pytest.mark.parametrize("dtype", [8, 4])
@@ -705,7 +705,7 @@ def test_rrl_small_voigt_y_every_lane_layout(eng, nchan, cw, thin):
     eng.synchronize()
     ref = jet.optical_depth_rrl("H66a", np.asarray(rf))
     assert np.isfinite(ref).all() and (ref > 0).all()
-    np.testing.assert_allclose(tau.cpu().numpy().reshape(ref.shape), ref, rtol=1e-9)
+    np.testing.assert_allclose(tau.cpu().numpy().reshape(ref.shape), ref, rtol=U.k3_rtol(nchan))
 
 
 @pytest.mark.parametrize("store", ["f64", "f32"])

@@ -1,0 +1,213 @@
+#!/usr/bin/env python3
+"""Design and error budget of K3's wave-uniform Faddeeva paths (rajepy_amd/csrc/rrl_scan.hip).
+
+The reference evaluates the Voigt profile through scipy.special.wofz (maths/rrls.py:350-354);
+BASELINE.json's bar on the maps is 1e-5 relative, SURVEY.md section 7 asks for <= 1e-7 on
+Re w.  Round 3 spends that budget: the wave-uniform paths are designed for <= 1e-8 relative on
+Re w(x + i y) over their whole domain (one order inside SURVEY's bound, three inside the
+bar), instead of the 1e-11 of rounds 1-2 -- a wider lattice step, fewer nodes, shorter series
+and polynomials.  This script restates every path in NumPy float64 with the kernel's operation
+structure and constants, measures it against scipy.special.wofz over the path's domain, and
+prints the constants the kernel uses.  (scipy is test / design infrastructure here; the product
+never imports it for this.)
+
+    python tools/voigt_design.py            # error table + constants
+"""
+import numpy as np
+from scipy.special import wofz
+
+np.seterr(all="ignore")
+
+H = 0.675                  # lattice step of the wave-uniform paths (generic per-lane path: 0.6)
+NPAIR = 8                  # node pairs t_n = n h, n = 0 .. 7 (n = 0 self-paired)
+CEN_J = 7                  # centred lattice: nodes on each side of the middle one
+CEN_YMAX = 0.03            # below: centred lattice (sum and pole term of the plain one cancel)
+FAR = ((6, 64.0), (4, 196.0))     # (series terms K, |z|^2 above which every lane must lie)
+TOL_POLE = 3e-8            # pole term skipped where a rigorous bound puts it below this * Re w
+C_FAR = [1.0, 0.5, 0.75, 1.875, 6.5625, 29.53125, 162.421875, 1055.7421875, 7918.06640625]
+
+# near-minimax polynomials (tools/minimax_fit.py): cos on |w| <= pi/2 in s = w^2 (degree 12 in
+# w, abs err 3.9e-12), exp on |r| <= ln2/2 (degree 8, rel err 1.6e-12)
+COS12 = [2.00440237723759486e-09, -2.75347756843411723e-07, 2.48013152427276996e-05,
+         -1.38888875194187922e-03, 4.16666666468048091e-02, -0.5, 1.0]
+EXP8 = [2.50213726461024045e-05, 1.99141676370814211e-04, 1.38885875111343206e-03,
+        8.33327326606923997e-03, 4.16666677111410463e-02, 1.66666668158620745e-01, 0.5, 1.0, 1.0]
+
+
+def horner(c, x):
+    p = np.full_like(x, c[0])
+    for k in c[1:]:
+        p = p * x + k
+    return p
+
+
+def cos_2pi(u):
+    k = np.rint(2.0 * u)
+    w = 6.28318530717958647692 * (u - 0.5 * k)
+    p = horner(COS12, w * w)
+    return np.where(k.astype(np.int64) & 1, -p, p)
+
+
+def exp_k(x):
+    kd = np.rint(1.4426950408889634074 * x)
+    r = x - kd * 6.93147180369123816490e-01
+    r = r - kd * 1.90821492927058770002e-10
+    return np.ldexp(horner(EXP8, r), kd.astype(np.int64))
+
+
+def far_series(x, y, K):
+    x2, y2 = x * x, y * y
+    r2 = x2 + y2
+    inv = 1.0 / (r2 * r2)
+    ur, nui = (x2 - y2) * inv, 2.0 * (x * y) * inv
+    pr = C_FAR[K - 1] + C_FAR[K] * ur
+    pi = -C_FAR[K] * nui
+    for k in range(K - 2, -1, -1):
+        t = pr * ur + (pi * nui + C_FAR[k])
+        pi = -pr * nui + pi * ur
+        pr = t
+    return (y * pr - x * pi) * (r2 * inv) * 0.56418958354775628695
+
+
+def plain_wave(x, y, pole):
+    """Eight node pairs over one common denominator (voigt_plain_wave)."""
+    tau = [(n * H) ** 2 for n in range(NPAIR)]
+    w2 = [1.0] + [2.0 * np.exp(-t) for t in tau[1:]]
+    x2 = x * x
+    r2 = y * y + x2
+    X4 = -4.0 * x2
+    N, D = [], []
+    for a in range(0, NPAIR, 2):
+        ma = r2 if a == 0 else tau[a] + r2
+        mb = tau[a + 1] + r2
+        da = ma * ma if a == 0 else tau[a] * X4 + ma * ma
+        db = tau[a + 1] * X4 + mb * mb
+        N.append(ma * db + (w2[a + 1] / w2[a]) * (mb * da))
+        D.append(da * db)
+    N01, D01 = N[0] * D[1] + (w2[2] / w2[0]) * (N[1] * D[0]), D[0] * D[1]
+    N23, D23 = N[2] * D[3] + (w2[6] / w2[4]) * (N[3] * D[2]), D[2] * D[3]
+    Nall, Dall = N01 * D23 + (w2[4] / w2[0]) * (N23 * D01), D01 * D23
+    ky = (w2[0] * H / np.pi) * y
+    if not pole:
+        return Nall / Dall * ky
+    q = np.exp(-2.0 * np.pi * y / H)
+    e = y * y - x2
+    u = x / H
+    ph = 0.31830988618379067154 * (x * y)
+    cth, cph, cps = cos_2pi(u), cos_2pi(ph), cos_2pi(u - ph)
+    den = q * (q - 2.0 * cth) + 1.0
+    num = q * cph - cps
+    pq = 2.0 * exp_k(e) * q * num
+    return (Nall * ky * den + pq * Dall) / (Dall * den)
+
+
+def pole_bound_cq(y, rmax2=67.0):
+    """x^2 above which |P| <= 6 e^{y^2-x^2} q / (1-q)^2 is below TOL_POLE * Re w, with
+    Re w >= y / (4 (|z|^2 + 1)) and |z|^2 < rmax2 - 1 on this path (cell_line)."""
+    lnq = -2.0 * np.pi * y / H
+    omq = -np.expm1(lnq)
+    return (y * y + lnq + np.log(6.0) - 2.0 * np.log(omq) - np.log(0.25 * y) +
+            np.log(1.0 / TOL_POLE) + np.log(rmax2))
+
+
+def centred(x, y):
+    """Lattice centred on x (voigt_centred), y < CEN_YMAX, x <= 16."""
+    km = np.rint(-x / H - 0.5)
+    tm = (km + 0.5) * H + x
+    w = tm * tm
+    em = horner([1.0 / 720.0, -1.0 / 120.0, 1.0 / 24.0, -1.0 / 6.0, 0.5, -1.0, 1.0], w)
+    v = (-2.0 * H) * tm
+    fact = [1.0]
+    for k in range(1, 11):
+        fact.append(fact[-1] * k)
+    uu = horner([1.0 / f for f in fact[::-1]], v)
+    kC1, kQ = np.exp(-H * H), np.exp(-2.0 * H * H)
+    tab = lambda k: 1.0 / (((k + 0.5) * H) ** 2 + y * y)
+    s = em * tab(km)
+    e, r = em.copy(), kC1 * uu
+    for j in range(1, CEN_J + 1):
+        e = e * r
+        r = r * kQ
+        s = s + e * tab(km + j)
+    e, r = em.copy(), kC1 / uu
+    for j in range(1, CEN_J + 1):
+        e = e * r
+        r = r * kQ
+        s = s + e * tab(km - j)
+    s = s * (y * (H / np.pi))
+    q = np.exp(-2.0 * np.pi * y / H)
+    th = 2.0 * x * y
+    t2 = th * th
+    c = horner([1.0 / 40320.0, -1.0 / 720.0, 1.0 / 24.0, -0.5, 1.0], t2)     # cos, degree 8
+    g = np.exp(y * y - x * x)
+    return s + 2.0 * g * c * q / (1.0 + q)
+
+
+def rel(a, ref):
+    return np.abs(a - ref) / np.abs(ref)
+
+
+def main():
+    print("H = %.4f  pi/H = %.4f  NPAIR = %d  CEN_J = %d" % (H, np.pi / H, NPAIR, CEN_J))
+    # ---- plain lattice (+ pole term) over its domain: 0.03 <= y, |z|^2 <= 64 or (x^2 <= 64, y <= 1)
+    worst = (0, None)
+    worst_skip = (0, None)
+    for y in np.concatenate([np.geomspace(CEN_YMAX, 1, 80), np.linspace(1, 8.1, 143)]):
+        x = np.linspace(0, 8.0, 6401)
+        x = x[(x * x + y * y <= 64.0) | ((x * x <= 64.0) & (y <= 1.0))]
+        if x.size == 0:
+            continue
+        ref = wofz(x + 1j * y).real
+        has_pole = y < np.pi / H
+        full = plain_wave(x, y, has_pole)
+        e = rel(full, ref)
+        i = int(np.argmax(e))
+        if e[i] > worst[0]:
+            worst = (e[i], (x[i], y))
+        if has_pole:
+            # lanes of a wave whose smallest x^2 exceeds cq run WITHOUT the pole term
+            cq = pole_bound_cq(y)
+            m = x * x >= cq
+            if m.any():
+                e2 = rel(plain_wave(x[m], y, False), ref[m])
+                j = int(np.argmax(e2))
+                if e2[j] > worst_skip[0]:
+                    worst_skip = (e2[j], (x[m][j], y))
+    print("plain lattice (pole term where y < pi/H): max rel err %.2e at x=%.3f y=%.4f"
+          % (worst[0], worst[1][0], worst[1][1]))
+    print("plain lattice, pole term skipped beyond cq:  max rel err %.2e at x=%.3f y=%.4f"
+          % (worst_skip[0], worst_skip[1][0], worst_skip[1][1]))
+    # ---- far field
+    for K, r2 in FAR:
+        worst = 0.0
+        for y in np.geomspace(1e-10, 1e3, 260):
+            x0 = np.sqrt(max(r2 - y * y, 64.0 if y <= 1.0 else 0.0))
+            x = x0 * (1.0 + 1e-9) + np.concatenate([np.linspace(0, 4, 81), np.geomspace(4, 1e4, 40)])
+            ok = x * x + y * y > r2
+            ref = wofz(x + 1j * y).real
+            worst = max(worst, float(rel(far_series(x, y, K), ref)[ok].max()))
+        print("far series K = %d, every lane |z|^2 > %g and (x^2 > 64 or y > 1): max rel err %.2e"
+              % (K, r2, worst))
+    # ---- centred lattice
+    worst = (0, None)
+    for y in np.geomspace(1e-10, CEN_YMAX, 60):
+        x = np.linspace(0, 16.0, 6401)
+        ref = wofz(x + 1j * y).real
+        e = rel(centred(x, y), ref)
+        i = int(np.argmax(e))
+        if e[i] > worst[0]:
+            worst = (e[i], (x[i], y))
+    print("centred lattice (y < %.2f, x <= 16): max rel err %.2e at x=%.3f y=%.3e"
+          % (CEN_YMAX, worst[0], worst[1][0], worst[1][1]))
+    # ---- constants for the kernel
+    tau = [(n * H) ** 2 for n in range(NPAIR)]
+    w2 = [1.0] + [2.0 * float(np.exp(-t)) for t in tau[1:]]
+    print("tau  = {" + ", ".join(repr(t) for t in tau) + "}")
+    print("w2   = {" + ", ".join(repr(t) for t in w2) + "}")
+    print("kC1 = exp(-h^2) = %r   kQ = exp(-2 h^2) = %r" % (float(np.exp(-H * H)),
+                                                           float(np.exp(-2 * H * H))))
+    print("ln(1/TOL_POLE) = %r" % float(np.log(1.0 / TOL_POLE)))
+
+
+if __name__ == "__main__":
+    main()
