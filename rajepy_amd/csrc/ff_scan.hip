@@ -486,7 +486,12 @@ static bool use_tile32() {
 }
 
 void ff_scan_plan(const rjp_fields* fl, const rjp_bursts* hb, const double* epochs,
-                  int n_epochs, bool want_em, ScanPlan& pl) {
+                  int n_epochs, int mode, bool want_em, ScanPlan& pl) {
+  // tiles of >= 16 epochs (the uniform-epoch recurrences) exist for f64 storage on the tau and
+  // compact layouts -- what every BASELINE configuration runs on; f32 storage and the wide
+  // layout take tiles of <= 8 epochs (their long-tile kernels were a third of the library's
+  // build time and size for no configuration that uses them)
+  const bool long_tiles = fl->dtype == RJP_F64 && scan_layout(fl, mode, want_em) != LAY_WIDE;
   BurstsDev probe_b;
   pl.bursts = bursts_to_dev(hb, probe_b);
   pl.next = bursts_overflow(hb);
@@ -506,11 +511,11 @@ void ff_scan_plan(const rjp_fields* fl, const rjp_bursts* hb, const double* epoc
       const int left = n_epochs - e0;
       tl.et = (left >= 8 && pl.vec != 4) ? 8 : left >= 4 ? 4 : left >= 2 ? 2 : 1;
       UnifDev probe;
-      if (left >= 16) {
+      if (left >= 16 && long_tiles) {
         uniform_tile(epochs + e0, 16, hb, probe, q.data());
         if (probe.on) tl.et = 16;
       }
-      if (left >= 32 && (!want_em || tile32_em()) && use_tile32()) {
+      if (left >= 32 && long_tiles && (!want_em || tile32_em()) && use_tile32()) {
         uniform_tile(epochs + e0, 32, hb, probe, q.data());
         if (probe.on) tl.et = 32;
       }

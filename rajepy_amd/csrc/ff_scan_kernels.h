@@ -519,6 +519,11 @@ template <typename T, int VEC, int ET, int MODE, bool BURSTS, int LAY>
 inline hipError_t launch_tile(const rjp_fields* fl, const BurstsDev& b, const double* t,
                               const UnifDev& un, int nsplit, int ylen, double* ws, bool want_em,
                               hipStream_t st) {
+  // (long tiles: f64 storage on the tau / compact layouts only -- ff_scan_plan never asks for
+  // another, and nothing is instantiated for them)
+  if constexpr (ET >= 16 && (sizeof(T) == 4 || LAY == LAY_WIDE)) {
+    return hipErrorInvalidValue;
+  } else {
   FieldPtrs<T> f{(const T*)fl->d_nd, (const T*)fl->d_xi, (const T*)fl->d_temp,
                  (const T*)fl->d_pf, (const T*)fl->d_ts, fl->d_ylo, fl->d_yhi,
                  (const T*)fl->d_em0, (const T*)fl->d_a0};
@@ -580,6 +585,7 @@ inline hipError_t launch_tile(const rjp_fields* fl, const BurstsDev& b, const do
     return hipGetLastError();
   }
   return hipErrorInvalidValue;       // a 16-epoch tile that is not uniform: launcher bug
+  }
 }
 
 template <typename T, int VEC, int MODE, int LAY>

@@ -35,7 +35,7 @@ int scan_layout(const rjp_fields* fl, int mode, bool want_em);
 bool tile_dma_ok(const rjp_fields* fl);
 size_t ff_scan_workspace_bytes(int nx, int ny, int nz, int n_epochs);
 void ff_scan_plan(const rjp_fields* fl, const rjp_bursts* hb, const double* epochs, int n_epochs,
-                  bool want_em, ScanPlan& pl);
+                  int mode, bool want_em, ScanPlan& pl);
 hipError_t ff_scan_run(const rjp_fields* fl, const rjp_bursts* hb, const ScanPlan& pl,
                        const double* d_ext, const double* epochs, int n_epochs, int mode,
                        double* sumA, double* em, double* tavg, double* ws, hipStream_t st);

@@ -307,7 +307,7 @@ int rjp_ff_scan(rjp_ctx* ctx, const rjp_fields* fields, const rjp_bursts* bursts
     return fail(ctx, RJP_ERR_WORKSPACE, "rjp_ff_scan: workspace smaller than rjp_ff_scan_workspace()");
   hipStream_t st = (hipStream_t)stream;
   rjp::ScanPlan plan;
-  rjp::ff_scan_plan(fields, bursts, h_epochs_s, n_epochs, d_em != nullptr, plan);
+  rjp::ff_scan_plan(fields, bursts, h_epochs_s, n_epochs, gff_mode, d_em != nullptr, plan);
   double* d_ext = nullptr;
   if (!plan.ext.empty()) {
     const double* src[1] = {plan.ext.data()};

@@ -37,6 +37,15 @@ def _eq(a, b):
     return np.array_equal(a.cpu().numpy(), b.cpu().numpy(), equal_nan=True)
 
 
+def _close(a, b, rtol=1e-11):
+    """Same NaN / zero pattern, values to `rtol`: the wide layout has no tiles of >= 16 epochs
+    (it evaluates every epoch directly, in tiles of 8), the tau and compact layouts run the
+    uniform-epoch recurrence there -- the same numbers to rounding, not bit for bit."""
+    x, y = a.cpu().numpy(), b.cpu().numpy()
+    return (np.array_equal(np.isnan(x), np.isnan(y)) and np.array_equal(x == 0, y == 0) and
+            np.allclose(x, y, rtol=rtol, atol=0, equal_nan=True))
+
+
 @pytest.mark.parametrize("temp_mode", [0, 1])
 @pytest.mark.parametrize("n_ep", [1, 2, 3, 8, 11, 16, 32, 37])
 @pytest.mark.parametrize("want_em", [True, False])
@@ -62,9 +71,10 @@ def test_tau_layout_is_bit_identical_to_compact_and_wide(eng, temp_mode, n_ep, w
     aw, ew, tw = eng.ff_scan(f, bursts, ep, mode, want_em=want_em)
     t_single = eng.ff_scan(f, bursts, ep[:1], mode)[2]
     eng.synchronize()
-    assert _eq(a2, a1) and _eq(a2, aw)
+    same = _eq if n_ep < 16 else _close          # (wide: direct tiles only)
+    assert _eq(a2, a1) and same(a2, aw)
     if want_em:
-        assert _eq(e2, e1) and _eq(e2, ew)
+        assert _eq(e2, e1) and same(e2, ew)
     else:
         assert e2 is None
     # T_avg: the one-off pass == what a single-epoch scan of either other layout derives ==
@@ -168,8 +178,9 @@ def test_tau_layout_keeps_numpys_nan_semantics(eng, n_ep, bursts_on):
             aw, ew, tw = eng.ff_scan(f, bursts, ep, mode)
             eng.synchronize()
             f.em0, f.a0 = em0, a0
-            assert _eq(a2, a1) and _eq(a2, aw) and _eq(a2n, a2)
-            assert _eq(e2, e1) and _eq(e2, ew)
+            same = _eq if (n_ep < 16 or not bursts_on) else _close
+            assert _eq(a2, a1) and same(a2, aw) and _eq(a2n, a2)
+            assert _eq(e2, e1) and same(e2, ew)
             assert _eq(t2, t1) and _eq(t2, tw)
         tav = eng.tavg(f).cpu().numpy().reshape(shape[0], shape[2])
         with np.errstate(all="ignore"):
