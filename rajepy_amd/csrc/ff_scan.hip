@@ -167,8 +167,8 @@ __global__ __launch_bounds__(kBlock) void ff_maps_kernel(
     }
     const int64_t o = ((int64_t)e * nchan + f) * npix + p;
     if (live) {
-      if (tau) store_plain(tau + o, t);
-      if (flux) store_plain(flux + o, s);
+      if (tau) store_cube(tau + o, t);
+      if (flux) store_cube(flux + o, s);
     }
     if (part) {
       double acc = 0.0;

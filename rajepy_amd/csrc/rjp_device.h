@@ -51,6 +51,25 @@ __device__ __forceinline__ void store_plain(double* __restrict__ p, const double
 __device__ __forceinline__ void store_plain(double* __restrict__ p, const double (&v)[1]) {
   p[0] = v[0];
 }
+// stores of the product cubes (written once, never read back by a kernel of the step)
+#ifndef RJP_K2_NT
+#define RJP_K2_NT 0
+#endif
+__device__ __forceinline__ void store_cube(double* __restrict__ p, const double (&v)[2]) {
+  rjp_d2 t; t.x = v[0]; t.y = v[1];
+#if RJP_K2_NT
+  __builtin_nontemporal_store(t, reinterpret_cast<rjp_d2*>(p));
+#else
+  *reinterpret_cast<rjp_d2*>(p) = t;
+#endif
+}
+__device__ __forceinline__ void store_cube(double* __restrict__ p, const double (&v)[1]) {
+#if RJP_K2_NT
+  __builtin_nontemporal_store(v[0], p);
+#else
+  p[0] = v[0];
+#endif
+}
 
 // ---- burst factor chi(t) (classes.py:442-448, 866-868) ---------------------------------
 // Kernel-argument copy of rjp_bursts.  The first RJP_SGPR_BURSTS bursts of each jet travel by

@@ -8,10 +8,13 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 RUNS = [("cfg2", "f64", {}, []), ("cfg5", "f64", {}, []), ("cfg3", "f64", {}, []),
-        ("cfg4", "f32", {}, []), ("cfg5", "f32", {}, []),
+        ("cfg4", "f64", {}, ["--em"]),
         ("cfg4", "f64", {}, ["--gaunt", "powerlaw"]),
-        ("cfg4", "f64", {}, ["--layout", "wide"]),
-        ("cfg4", "f32", {}, ["--layout", "wide"])]
+        ("cfg4", "f64", {}, ["--layout", "compact", "--em"]),
+        ("cfg4", "f64", {}, ["--layout", "wide", "--em"]),
+        ("cfg4x8", "f64", {}, []),
+        ("cfg4", "f32", {}, ["--em"]), ("cfg5", "f32", {}, []),
+        ("cfg4", "f32", {}, ["--layout", "wide", "--em"])]
 
 
 def main():
@@ -31,7 +34,7 @@ def main():
         lines.append(line[-1])
         rf, cb = r["roofline"], r.get("cpu_baseline", {})
         rows.append("| %s_%s%s | %s | %s | %.3f | %.3e | %s | %.3f | %.0f | %.3f | %s |" % (
-            cfg, storage, ("_wide" if "wide" in more else "") + ("_powerlaw" if "powerlaw" in more else ""),
+            cfg, storage, "".join("_" + m.lstrip("-") for m in more if m not in ("--layout", "--gaunt")),
             r["config"]["workload"], r["config"]["layout"],
             r["ms_per_step"], r["value"], rf["kernel"], rf["ms_per_launch"], rf["achieved"],
             rf["frac"], ("%.2f" % cb["value"]) if cb else "-"))
