@@ -154,6 +154,18 @@ int rjp_compact_fields(rjp_ctx* ctx, const rjp_fields* fields, void* d_em0,
 int rjp_tau_field(rjp_ctx* ctx, const rjp_fields* fields, int32_t gff_mode, void* d_a0,
                   void* stream);
 
+/* Launch times for the free-free scan of a model that has bursts in ONE jet only.  The
+ * reference's burst Gaussians carry a NaN launch time into the cell's density, which nansum
+ * then drops -- but a jet without any registered burst has the constant steady-state mass-loss
+ * rate whatever the launch time (classes.py:232-233, 442-448, 866-875): its cells keep chi = 1.
+ * rjp_ff_scan masks EVERY cell with a NaN launch time once bursts are present (a per-cell jet
+ * test there cost the single-epoch scan 2.7 %), so such a model scans the copy written here:
+ * d_ts_out[i] = 0 where d_ts[i] is NaN and the cell belongs to `jet` (0 = red, 1 = blue: the one
+ * WITHOUT bursts; the flag is read from the sign bit of d_a0, d_em0 or d_nd), d_ts[i] elsewhere.
+ * (rjp_rrl_scan and the collapse=False entry points apply the rule themselves.) */
+int rjp_unmask_launch_times(rjp_ctx* ctx, const rjp_fields* fields, int32_t jet, void* d_ts_out,
+                            void* stream);
+
 /* T_avg map of the model: d_tavg[p] = nanmean_y(T where T > 0) [K], NaN on empty sightlines
  * (classes.py:1471-1472, 1484-1485, 1254-1256).  One pass over fields->d_temp (the only field
  * read; d_ylo / d_yhi are honoured), bit-identical to the map a single-epoch rjp_ff_scan

@@ -264,7 +264,11 @@ __device__ __forceinline__ void compute_rows(const RowBatch<VEC, U>& rb, const B
       if (BURSTS) {
         // nansum semantics hoisted out of the epoch loop: g chi^2 is NaN iff g is NaN or
         // chi is (chi is NaN iff the launch time is -- such cells were given chi = 1 above);
-        // a masked cell contributes an exact zero at every epoch
+        // a masked cell contributes an exact zero at every epoch.  (The one exception of the
+        // reference -- a jet WITHOUT bursts has a constant mass-loss rate, classes.py:232-233,
+        // so a NaN launch time does not reach its cells -- is served by the caller: it scans
+        // launch times patched by rjp_unmask_launch_times; a per-cell test here cost the
+        // single-epoch scan 2.7 %.)
         const double g = poison_unless(g0[u][v], ts[u][v] == ts[u][v]);
         const double gm = nan_to_zero<CMP>(g);
         const double am = nan_to_zero<CMP>(g * tpow);

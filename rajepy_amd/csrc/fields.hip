@@ -118,6 +118,41 @@ hipError_t tau_field_launch(const rjp_fields* fl, int gff_mode, void* d_a0, hipS
   return hipGetLastError();
 }
 
+// ---- launch times of a jet without bursts -----------------------------------------------------
+// The reference's burst Gaussians carry a NaN launch time into the cell's density (dropped by
+// nansum) -- but a jet WITHOUT any registered burst has the constant steady-state mass-loss
+// rate whatever the launch time (classes.py:232-233, 442-448): its cells keep chi = 1.  The
+// free-free scan masks every cell with a NaN launch time as soon as the model has a burst, so
+// a model with bursts in ONE jet only scans a copy of `ts` in which the NaNs of the other
+// jet's cells are replaced by 0 (any finite value gives chi = 1 there).  `flag`: a field that
+// carries the red-jet flag in its sign bit (a0, em0 or nd).
+template <typename T>
+__global__ __launch_bounds__(kFB) void unmask_ts_kernel(const T* __restrict__ ts,
+                                                        const T* __restrict__ flag, int jet,
+                                                        T* __restrict__ out, int64_t n) {
+  int64_t i = (int64_t)blockIdx.x * kFB + threadIdx.x;
+  const int64_t step = (int64_t)gridDim.x * kFB;
+  for (; i < n; i += step) {
+    const double t = (double)ts[i];
+    const bool red = signbit_d((double)flag[i]);
+    const bool mine = red == (jet == 0);
+    out[i] = (!(t == t) && mine) ? (T)0 : ts[i];
+  }
+}
+
+hipError_t unmask_ts_launch(const rjp_fields* fl, int jet, void* d_out, hipStream_t st) {
+  const int64_t n = (int64_t)fl->nx * fl->ny * fl->nz;
+  const unsigned blocks = (unsigned)std::min<int64_t>((n + kFB - 1) / kFB, 256 * 32);
+  const void* flag = fl->d_a0 ? fl->d_a0 : fl->d_em0 ? fl->d_em0 : fl->d_nd;
+  if (fl->dtype == RJP_F64)
+    hipLaunchKernelGGL(unmask_ts_kernel<double>, dim3(blocks), dim3(kFB), 0, st,
+                       (const double*)fl->d_ts, (const double*)flag, jet, (double*)d_out, n);
+  else
+    hipLaunchKernelGGL(unmask_ts_kernel<float>, dim3(blocks), dim3(kFB), 0, st,
+                       (const float*)fl->d_ts, (const float*)flag, jet, (float*)d_out, n);
+  return hipGetLastError();
+}
+
 // ---- synthetic dense fields --------------------------------------------
 // No FMA contraction from here to the end of K4: the generator must be bit-identical to its
 // host restatement, and K4's inside test must follow NumPy's operation order.

@@ -227,9 +227,13 @@ __device__ __forceinline__ double exp_any(double x) {
 
 // chi for one cell of one jet (wave-uniform loop count; parameters come from SGPRs, those of
 // bursts beyond RJP_SGPR_BURSTS from the overflow table)
+// A NaN launch time gives NaN (the reference's Gaussians propagate it, classes.py:442-448) --
+// unless the jet has no burst at all: its mass-loss rate is then the steady-state constant
+// whatever the launch time (classes.py:232-233), chi = 1.
 __device__ __forceinline__ double chi_jet(const BurstsDev& b, int jet, double tl) {
   double chi = 1.0;
   const int nb = b.n[jet];
+  if (nb > 0 && !(tl == tl)) return __builtin_nan("");
   const int n0 = nb < RJP_SGPR_BURSTS ? nb : RJP_SGPR_BURSTS;
   for (int i = 0; i < n0; ++i) {
     double d = tl - b.t0[jet][i];

@@ -92,6 +92,7 @@ hipError_t pack_field_launch(const double* src, const double* den, const uint8_t
 hipError_t compact_fields_launch(const rjp_fields* fl, void* d_em0, int64_t* d_n_bad,
                                  hipStream_t st);
 hipError_t tau_field_launch(const rjp_fields* fl, int gff_mode, void* d_a0, hipStream_t st);
+hipError_t unmask_ts_launch(const rjp_fields* fl, int jet, void* d_out, hipStream_t st);
 hipError_t synth_launch(uint64_t seed, int temp_mode, int nz, int64_t cell0, int64_t n, int dtype,
                         void* nd, void* xi, void* temp, void* pf, void* ts, void* vy, void* em0,
                         void* a0, int a0_mode, hipStream_t st);

@@ -257,6 +257,23 @@ int rjp_tau_field(rjp_ctx* ctx, const rjp_fields* fields, int32_t gff_mode, void
   return RJP_OK;
 }
 
+int rjp_unmask_launch_times(rjp_ctx* ctx, const rjp_fields* fields, int32_t jet, void* d_ts_out,
+                            void* stream) {
+  if (int r = bind(ctx)) return r;
+  if (!fields || !fields->d_ts || !d_ts_out)
+    return fail(ctx, RJP_ERR_ARG, "rjp_unmask_launch_times: fields.d_ts / d_ts_out is NULL");
+  if (fields->dtype != RJP_F32 && fields->dtype != RJP_F64)
+    return fail(ctx, RJP_ERR_ARG, "fields.dtype must be RJP_F32 (4) or RJP_F64 (8)");
+  if (fields->nx <= 0 || fields->ny <= 0 || fields->nz <= 0)
+    return fail(ctx, RJP_ERR_ARG, "grid dimensions must be positive");
+  if (jet != 0 && jet != 1) return fail(ctx, RJP_ERR_ARG, "jet must be 0 (red) or 1 (blue)");
+  if (!fields->d_a0 && !fields->d_em0 && !fields->d_nd)
+    return fail(ctx, RJP_ERR_ARG, "rjp_unmask_launch_times: needs a field that carries the jet "
+                                  "flag (d_a0, d_em0 or d_nd)");
+  RJP_HIP(ctx, rjp::unmask_ts_launch(fields, jet, d_ts_out, (hipStream_t)stream));
+  return RJP_OK;
+}
+
 int rjp_tavg(rjp_ctx* ctx, const rjp_fields* fields, double* d_tavg, void* d_work,
              size_t work_bytes, void* stream) {
   if (int r = bind(ctx)) return r;

@@ -365,6 +365,32 @@ class RTEngine:
         return self.tau_layout(out, tau_mode) if tau_mode is not None else out
 
     # -- K1 / K2 -----------------------------------------------------------------------------
+    def _scan_struct(self, fields, bursts):
+        """`rjp_fields` for a free-free scan.  A model with bursts in ONE jet only scans a copy
+        of the launch times in which the NaNs of the other jet's cells are cleared
+        (rjp_unmask_launch_times): the reference's burst-less jet has a constant mass-loss rate,
+        so a NaN launch time does not drop its cells (classes.py:232-233, 442-448).  The copy
+        is kept with the fields and rebuilt when `ts` or the flag-carrying field changes."""
+        fs = fields.struct()
+        if bursts is None or fields.ts is None:
+            return fs
+        n_r, n_b = int(bursts.n[0]), int(bursts.n[1])
+        if (n_r == 0) == (n_b == 0):
+            return fs
+        jet = 0 if n_r == 0 else 1
+        flag = fields.a0 if fields.a0 is not None else (fields.em0 if fields.em0 is not None
+                                                        else fields.nd)
+        key = (jet, fields.ts.data_ptr(), flag.data_ptr())
+        cached = getattr(fields, "_ts_unmasked", None)
+        if cached is None or cached[0] != key:
+            out = self._empty(fields.ncells, fields.dtype)
+            _lib.check(self.lib.rjp_unmask_launch_times(self.ctx, C.byref(fs), jet,
+                                                        out.data_ptr(), self._stream()),
+                       self.ctx, "rjp_unmask_launch_times")
+            cached = fields._ts_unmasked = (key, out)
+        fs.d_ts = cached[1].data_ptr()
+        return fs
+
     def ff_scan(self, fields, bursts, epochs_s, gff_mode, want_em=True, out=None,
                 want_tavg=True):
         """-> (sumA[E,P], em[E,P] or None, tavg[P] or None) device tensors (float64).
@@ -381,7 +407,7 @@ class RTEngine:
             sumA, em, tavg = out
         wb = self.lib.rjp_ff_scan_workspace(nx, ny, nz, E)
         work = self._workspace(wb)
-        fs = fields.struct()
+        fs = self._scan_struct(fields, bursts)
         ep = _lib.dbl_array(epochs_s)
         _lib.check(self.lib.rjp_ff_scan(
             self.ctx, C.byref(fs), C.byref(bursts) if bursts is not None else None, ep, E,
@@ -400,7 +426,7 @@ class RTEngine:
         tavg = self._f64(P) if want_tavg else None
         wb = self.lib.rjp_ff_scan_workspace(nx, ny, nz, E)
         work = self._workspace(wb)
-        fs = fields.struct()
+        fs = self._scan_struct(fields, bursts)
         ep = _lib.dbl_array(epochs_s)
         ms = C.c_double()
         _lib.check(self.lib.rjp_time_ff_scan(

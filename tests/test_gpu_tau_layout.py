@@ -236,3 +236,72 @@ def test_tau_layout_with_occupied_y_ranges_and_many_bursts(eng):
     for k in (3, 20):
         jet.time = ep[k]
         np.testing.assert_allclose(tau[k], jet.optical_depth_ff(5e9), rtol=1e-11, atol=0)
+
+
+@pytest.mark.parametrize("which", ["B", "R"])
+def test_nan_launch_times_only_mask_cells_of_a_jet_that_has_bursts(eng, which):
+    """The reference's Gaussians propagate a NaN launch time into the cell's density (dropped
+    by nansum, classes.py:442-448, 866-875) -- but the mass-loss rate of a jet WITHOUT any
+    registered burst is the steady-state constant, whatever the launch time
+    (classes.py:232-233): its cells keep contributing with chi = 1.  Bursts in one jet only,
+    NaN launch times sprinkled over both (densities finite): K1 on every layout and tile kind,
+    the collapse=False cells and K3, all against the oracle."""
+    from rajepy_amd import _lib, engine as E
+    from rajepy_amd.maths import physics as ph, rrls
+    shape = (4, 45, 16)
+    g = U.synth_host(shape, 777, 0)
+    rng = np.random.default_rng(3)
+    g["ts"] = np.where(rng.random(shape) < 0.15, np.nan, g["ts"])
+    p = copy.deepcopy(U.load_golden("cfg1_example")[2])
+    p["ejection"] = {"t_0": np.array([0.6, 1.4]), "hl": np.array([0.3, 0.5]),
+                     "chi": np.array([4., 7.]), "which": np.array([which, which])}
+    p["grid"].update(n_x=shape[0], n_y=shape[1], n_z=shape[2])
+    jet = orc.OracleJet.from_fields(p, g["nd"], g["xi"], g["temp"], g["ff"], g["areas"],
+                                    g["ts"], g["rr"], g["vy"])
+    bursts = U.bursts_from_oracle(jet)
+    f = eng.upload_fields(g["nd"], g["xi"], g["temp"], g["ff"], g["areas"], g["ts"],
+                          g["rr"] < 0, vy=g["vy"], csize_au=jet.csize, dtype=8)
+    eng.tau_layout(f, E.RJP_GFF_SCALAR)
+    freqs = np.array([5e9])
+    gv = [ph.gff(5e9, p["properties"]["T_0"])]
+    ctau, cflux = E.ff_channel_coeffs(freqs, jet.csize, p["target"]["dist"], E.RJP_GFF_SCALAR, gv)
+    layouts = {"tau": (f.a0, f.em0), "compact": (None, f.em0), "wide": (None, None)}
+    for years in ([0.9], [0.2, 0.7, 1.5], list(np.linspace(0., 3., 16)),
+                  list(np.linspace(0., 3.1, 32))):
+        ep = [y * orc.YEAR for y in years]
+        ref_tau, ref_em = [], []
+        for t in (ep[0], ep[-1]):
+            jet.time = t
+            ref_tau.append(jet.optical_depth_ff(5e9))
+            ref_em.append(jet.emission_measure())
+        for name, (a0, em0) in layouts.items():
+            f.a0, f.em0 = a0, em0
+            sumA, em, _ = eng.ff_scan(f, bursts, ep, E.RJP_GFF_SCALAR, want_tavg=False)
+            eng.synchronize()
+            tau = (ctau[0] * sumA.cpu().numpy()).reshape(len(ep), shape[0], shape[2])
+            emh = em.cpu().numpy().reshape(len(ep), shape[0], shape[2])
+            for k, e in enumerate((0, len(ep) - 1)):
+                np.testing.assert_allclose(tau[e], ref_tau[k], rtol=1e-11, err_msg=name)
+                np.testing.assert_allclose(emh[e], ref_em[k], rtol=1e-11, err_msg=name)
+    f.a0, f.em0 = layouts["tau"]
+    # the masked cells really were in play: dropping the NaNs changes the maps
+    jet.time = 0.9 * orc.YEAR
+    with_nan = jet.optical_depth_ff(5e9)
+    jet2 = orc.OracleJet.from_fields(p, g["nd"], g["xi"], g["temp"], g["ff"], g["areas"],
+                                     np.nan_to_num(g["ts"], nan=0.0), g["rr"], g["vy"])
+    jet2.time = jet.time
+    assert not np.allclose(with_nan, jet2.optical_depth_ff(5e9), rtol=1e-6)
+    # collapse=False cells and K3
+    cells = eng.ff_cells(f, bursts, jet.time, E.RJP_GFF_SCALAR, ctau)
+    line = _lib.Line(**rrls.line_constants("H66a"))
+    nu0 = rrls.rrl_nu_0("H", 66, 1)
+    eng.synchronize()
+    np.testing.assert_allclose(cells.cpu().numpy().reshape(shape),
+                               jet.optical_depth_ff(5e9, collapse=False), rtol=1e-11)
+    for nchan in (8, 40):
+        rf = orc.chan_freqs(nu0, nchan * 2e5, 2e5)
+        trrl = eng.rrl_scan(f, bursts, jet.time, line, rf)
+        eng.synchronize()
+        ref = jet.optical_depth_rrl("H66a", np.asarray(rf))
+        np.testing.assert_allclose(trrl.cpu().numpy().reshape(ref.shape), ref,
+                                   rtol=U.k3_rtol(nchan))
