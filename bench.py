@@ -737,12 +737,29 @@ def main(argv=None):
         # tiles of >= 16 epochs on f64 fields run the LDS-DMA variant of the scan
         dma = E_loc >= 16 and long_tiles and fields.shape[2] % 2 == 0
         kname = "ff_scan_tile_kernel" if dma else "ff_scan_kernel"
+        scan_path, mom_err = eng.last_scan_path()
+        if scan_path == "moments":
+            # the sweep went through the launch-time moments (ff_moments.hip): ONE pass over the
+            # grid for all epochs of the launch + a contraction over the moment maps
+            kname, npass = "moments_kernel", 1
+        if scan_path == "moments":
+            alg_bytes = npass * nfld * ncell_loc * dsz + base_maps
+            alg_8d = npass * 5 * ncell_loc * dsz + E_loc * P * 2 * 8
         roof_extra = {"grid_passes_per_launch": npass, "fields_streamed_per_cell": nfld,
                       "epochs_per_launch": E_loc, "timed_step_asks_for_em": want_em,
+                      "scan_path": scan_path,
                       "tavg": {"ms": wl.tavg_ms, "bytes": ncell_loc * dsz,
                                "what": "T_avg = nanmean_y(T > 0) is independent of frequency "
                                        "and epoch: one rjp_tavg pass per MODEL, not part of "
                                        "a step"}}
+        if scan_path == "moments":
+            roof_extra["moments"] = {
+                "what": "sum_y a0 chi(t_e - ts)^2 as a convolution over launch time: one pass "
+                        "accumulates 2 x 32 x 16 Chebyshev moments of a0 per sightline (LDS "
+                        "atomics: they, not HBM, bound it), every epoch is a contraction with "
+                        "host-built coefficient tables",
+                "worst_rel_err_of_the_expansion": mom_err,
+                "moment_maps_bytes": 2 * 32 * 16 * P * 8}
         if n_ep_cfg:
             # 8(d) prices one grid pass PER EPOCH; the fused tiles make `npass` passes serve
             # E_loc epochs -- both figures, as 8(d) asks

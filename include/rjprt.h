@@ -28,7 +28,8 @@
 extern "C" {
 #endif
 
-#define RJP_VERSION 104          /* 0.1.4 */
+#define RJP_VERSION 105          /* 0.1.5 */
+#define RJP_RANGE_BLOCKS 2048    /* partial (min, max) pairs rjp_field_range writes */
 #define RJP_MAX_EPOCH_TILE 32    /* most epochs evaluated per grid pass: 32 uniformly spaced ones (with or without d_em), 16 when only 16-31 are left, else tiles of 8, 4, 2, 1 */
 
 enum rjp_status {
@@ -100,6 +101,17 @@ typedef struct rjp_fields {
   const void* d_a0;
   int32_t a0_mode;          /* enum rjp_gff_mode d_a0 was built for */
   int32_t reserved_;        /* 0 */
+  /* Optional: the range of the finite launch times, [ts_lo, ts_hi] in seconds (rjp_field_range;
+   * both 0 = not provided).  With it, a tau-layout scan of >= 12 epochs without EM maps may take
+   * the MOMENT path: sum_y a0 chi(t_e - ts)^2 is a convolution of the sightline's launch-time
+   * distribution with chi^2, so ONE pass over the grid accumulates per-sightline Chebyshev
+   * moments of a0 over 32 launch-time bins and any number of epochs -- uniformly spaced or not --
+   * becomes a small contraction.  The host checks the expansion against chi^2 for the call's
+   * bursts and epochs and uses the path only when every coefficient table is good to 1e-11
+   * relative (else the epoch tiles run, as before); sums are reproducible to rounding, not bit
+   * for bit (LDS atomics).  A range that does not contain every finite launch time gives wrong
+   * maps: pass what rjp_field_range returned for d_ts, or zeros. */
+  double ts_lo, ts_hi;
 } rjp_fields;
 
 /* Ejection bursts (classes.py:399-463): mdot(t)/mdot_ss = 1 + sum_b amp_rel_b *
@@ -166,6 +178,13 @@ int rjp_tau_field(rjp_ctx* ctx, const rjp_fields* fields, int32_t gff_mode, void
 int rjp_unmask_launch_times(rjp_ctx* ctx, const rjp_fields* fields, int32_t jet, void* d_ts_out,
                             void* stream);
 
+/* Per-block (min, max) of the finite entries of a field of n elements (NaN ignored):
+ * d_partials[2 b], d_partials[2 b + 1], b < RJP_RANGE_BLOCKS (+inf / -inf for a block without a
+ * finite entry); the caller finishes the reduction on the host.  Used once per model for
+ * rjp_fields.ts_lo / ts_hi. */
+int rjp_field_range(rjp_ctx* ctx, const void* d_field, int64_t n, int dtype, double* d_partials,
+                    void* stream);
+
 /* T_avg map of the model: d_tavg[p] = nanmean_y(T where T > 0) [K], NaN on empty sightlines
  * (classes.py:1471-1472, 1484-1485, 1254-1256).  One pass over fields->d_temp (the only field
  * read; d_ylo / d_yhi are honoured), bit-identical to the map a single-epoch rjp_ff_scan
@@ -198,6 +217,11 @@ int rjp_ff_scan(rjp_ctx* ctx, const rjp_fields* fields, const rjp_bursts* bursts
                 const double* h_epochs_s, int32_t n_epochs, int32_t gff_mode,
                 double* d_sumA, double* d_em, double* d_tavg,
                 void* d_work, size_t work_bytes, void* stream);
+
+/* Which path the last rjp_ff_scan of this context took: 0 = epoch tiles, 1 = launch-time moments
+ * (and, in *worst_rel_err if non-NULL, the worst relative error of the moment expansion the
+ * host measured for that call; 0 for the tiles).  For tests and the bench line. */
+int rjp_last_scan_path(const rjp_ctx* ctx, double* worst_rel_err);
 
 /* ---- K2: per-channel map stage --------------------------------------------------------
  * Replaces the map-level arithmetic of optical_depth_ff / intensity_ff / flux_ff

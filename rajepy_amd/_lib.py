@@ -17,7 +17,8 @@ LIB_PATH = (DEBUG and os.environ.get("RJP_LIB")) or os.path.join(_HERE, "librjpr
 RJP_F32, RJP_F64 = 4, 8
 RJP_GFF_SCALAR, RJP_GFF_POWERLAW = 0, 1
 RJP_MAX_EPOCH_TILE = 32
-RJP_VERSION = 104             # include/rjprt.h; the binding below matches exactly this ABI
+RJP_RANGE_BLOCKS = 2048
+RJP_VERSION = 105             # include/rjprt.h; the binding below matches exactly this ABI
 RJP_OK = 0
 RJP_ERR_ARG, RJP_ERR_HIP, RJP_ERR_NODEVICE, RJP_ERR_WORKSPACE, RJP_ERR_DEGENERATE = \
     -1, -2, -3, -4, -5
@@ -37,7 +38,8 @@ class Fields(C.Structure):
                 ("nx", C.c_int32), ("ny", C.c_int32), ("nz", C.c_int32),
                 ("dtype", C.c_int32), ("csize_au", C.c_double),
                 ("d_ylo", C.c_void_p), ("d_yhi", C.c_void_p), ("d_em0", C.c_void_p),
-                ("d_a0", C.c_void_p), ("a0_mode", C.c_int32), ("reserved_", C.c_int32)]
+                ("d_a0", C.c_void_p), ("a0_mode", C.c_int32), ("reserved_", C.c_int32),
+                ("ts_lo", C.c_double), ("ts_hi", C.c_double)]
 
 
 class Bursts(C.Structure):
@@ -84,11 +86,13 @@ SIGNATURES = {
     "rjp_compact_fields": (C.c_int, [_P, C.POINTER(Fields), _P, _P, _P]),
     "rjp_tau_field": (C.c_int, [_P, C.POINTER(Fields), C.c_int32, _P, _P]),
     "rjp_tavg": (C.c_int, [_P, C.POINTER(Fields), _P, _P, C.c_size_t, _P]),
+    "rjp_field_range": (C.c_int, [_P, _P, C.c_int64, C.c_int, _P, _P]),
     "rjp_unmask_launch_times": (C.c_int, [_P, C.POINTER(Fields), C.c_int32, _P, _P]),
     "rjp_y_bounds": (C.c_int, [_P, C.POINTER(Fields), _P, _P, _P]),
     "rjp_ff_scan_workspace": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
     "rjp_ff_scan": (C.c_int, [_P, C.POINTER(Fields), C.POINTER(Bursts), _DP, C.c_int32,
                               C.c_int32, _P, _P, _P, _P, C.c_size_t, _P]),
+    "rjp_last_scan_path": (C.c_int, [_P, _DP]),
     "rjp_ff_maps_workspace": (C.c_size_t, [C.c_int64, C.c_int32, C.c_int32]),
     "rjp_ff_maps": (C.c_int, [_P, _P, _P, C.c_int64, C.c_int32, _DP, _DP, C.c_int32,
                               _P, _P, _P, _P, C.c_size_t, _P]),

@@ -1,0 +1,309 @@
+// Epoch sweeps by launch-time moments (round 3).
+//
+// For a fixed sightline the free-free sum of the reference at epoch t_e is
+//     sumA_e = sum_y a0_y * chi_jet(y)(t_e - ts_y)^2        (classes.py:861-875, 1395-1432)
+// -- a convolution of the sightline's distribution of a0 over LAUNCH TIME with the fixed
+// function F_jet = chi_jet^2.  The epoch enters through F only.  So instead of evaluating
+// chi for every (cell, epoch) pair (the tiles of ff_scan_kernels.h: 11-13 instructions per
+// pair, ALU-bound from 8 epochs on), the launch-time axis [ts_lo, ts_hi] is cut into K bins and
+// the per-sightline CHEBYSHEV MOMENTS of a0 are accumulated in ONE pass over the grid,
+//     M[p][jet][k][n] = sum_{y in bin k, jet} a0_y T_n(xi_y),    xi = position inside the bin,
+// after which ANY number of epochs, uniformly spaced or not, is the small contraction
+//     sumA_e[p] = sum_{jet,k,n} M[p][jet][k][n] * W[jet][k][n][e],
+// W = Chebyshev coefficients of s -> F_jet(t_e - s) on bin k, computed on the host for the
+// call's bursts and epochs.  F is entire (a polynomial in Gaussians): the expansion converges
+// faster than geometrically, and the host CHECKS it -- the interpolant is compared with F at
+// 2N+1 points of every (jet, bin, epoch) and the path is used only when the worst relative
+// error stays below 1e-11 (the agreement the recurrence tiles have with the direct ones); a
+// launch-time range too wide for the narrowest burst simply keeps the tiles.
+//
+// Moment pass: launch times are uncorrelated along y in general (and in the synthetic set), so
+// a cell's (jet, bin) is random and the accumulators cannot live in registers: a workgroup owns
+// 16 z-adjacent sightlines over all y and keeps their 16 x 2 x 32 x 16 moments in LDS (128 KB),
+// updated with f64 LDS atomics (16 per cell -- they, not HBM, bound the pass: 6.8 ms at
+// 512x4096x512, tools/native/moments_probe.hip), then writes them transposed, M_T[idx][p].
+// Sums of one sightline come from 16 threads in atomic order: results are reproducible to
+// rounding, not bit for bit (the tiles are).  Contraction: one lane per sightline, the W row
+// of each coefficient through scalar loads, 32 epochs per pass over M_T.
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+#include "rjp_host.h"
+
+namespace rjp {
+
+constexpr int kMomSL = 16;                 // sightlines per workgroup
+constexpr int kMomU = 8;                   // rows of loads in flight per thread
+constexpr int kMomIdx = 2 * RJP_MOM_BINS * RJP_MOM_ORDER;
+
+struct MomDev {
+  double s0, inv_h;
+  int has_bursts[2];
+};
+
+__global__ __launch_bounds__(256) void moments_kernel(const double* __restrict__ a0,
+                                                      const double* __restrict__ ts,
+                                                      const int32_t* __restrict__ ylo,
+                                                      const int32_t* __restrict__ yhi, int ny,
+                                                      int nz, int64_t npix, int64_t npixp,
+                                                      MomDev md, double* __restrict__ MT) {
+  constexpr int K = RJP_MOM_BINS, N = RJP_MOM_ORDER, SL = kMomSL, U = kMomU;
+  extern __shared__ double s_mom[];        // [2][K][N][SL]
+  constexpr int TOT = kMomIdx * SL;
+  for (int i = threadIdx.x; i < TOT; i += 256) s_mom[i] = 0.0;
+  __syncthreads();
+  const int sl = threadIdx.x % SL, yr = threadIdx.x / SL;
+  constexpr int YR = 256 / SL;
+  const int64_t p = (int64_t)blockIdx.x * SL + sl;
+  if (p < npix) {
+    const int64_t x = p / nz;
+    const int z = (int)(p - x * nz);
+    const int64_t col = x * (int64_t)ny * nz + z;
+    const int ya = ylo ? ylo[p] : 0, yb = ylo ? yhi[p] : ny;
+    for (int y0 = ya + yr; y0 < yb; y0 += YR * U) {
+      double a[U], t[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int y = y0 + u * YR;
+        const bool in = y < yb;
+        a[u] = in ? __builtin_nontemporal_load(a0 + col + (int64_t)y * nz) : 0.0;
+        t[u] = in ? __builtin_nontemporal_load(ts + col + (int64_t)y * nz) : 0.0;
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const bool red = signbit_d(a[u]);
+        double am = __builtin_fmax(__builtin_fabs(a[u]), 0.0);          // nansum: NaN -> 0
+        double tv = t[u];
+        if (!(tv == tv)) {
+          // a NaN launch time drops the cell -- unless its jet has no burst: F == 1 there,
+          // whatever the bin (classes.py:232-233, 442-448)
+          if (md.has_bursts[red ? 0 : 1]) am = 0.0;
+          tv = md.s0;
+        }
+        if (am != 0.0) {
+          const double w = (tv - md.s0) * md.inv_h;
+          const double kf = __builtin_fmin(__builtin_fmax(__builtin_floor(w), 0.0), (double)(K - 1));
+          const double xi = __builtin_fma(2.0, w - kf, -1.0);
+          double* base = s_mom + (((red ? 0 : K) + (int)kf) * N) * SL + sl;
+          double tm = 1.0, tc = xi;
+          atomicAdd(base, am);
+          // (an infinite term -- T = 0 makes T^-1.5 infinite, and the reference's sum with it --
+          // goes into the zeroth moment only: its coefficient is the bin average of chi^2 > 0,
+          // so the sightline comes out +inf as in the tiles, not inf * T_n(xi) = NaN)
+          if (am <= 1.7976931348623157e308) {
+            atomicAdd(base + SL, am * tc);
+            const double x2 = 2.0 * xi;
+#pragma unroll
+            for (int n = 2; n < N; ++n) {
+              const double tn = __builtin_fma(x2, tc, -tm);
+              tm = tc;
+              tc = tn;
+              atomicAdd(base + n * SL, am * tn);
+            }
+          }
+        }
+      }
+    }
+  }
+  __syncthreads();
+  // transposed flush: M_T[idx][p] (a full 128-byte segment per 16 lanes)
+  for (int i = threadIdx.x; i < TOT; i += 256) {
+    const int idx = i / SL, s = i % SL;
+    MT[(int64_t)idx * npixp + (int64_t)blockIdx.x * SL + s] = s_mom[i];
+  }
+}
+
+// sumA[e][p] = sum_idx M_T[idx][p] * W[idx][e], e < ne <= 32
+__global__ __launch_bounds__(256) void moments_eval_kernel(const double* __restrict__ MT,
+                                                           int64_t npix, int64_t npixp,
+                                                           const double* __restrict__ W, int ne,
+                                                           double* __restrict__ sumA) {
+  constexpr int ET = RJP_MOM_TILE;
+  const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (p >= npix) return;
+  double acc[ET];
+#pragma unroll
+  for (int e = 0; e < ET; ++e) acc[e] = 0.0;
+  for (int i = 0; i < kMomIdx; ++i) {
+    const double m = MT[(int64_t)i * npixp + p];
+    const double* w = W + (size_t)i * ET;          // wave-uniform: scalar loads
+#pragma unroll
+    for (int e = 0; e < ET; ++e) acc[e] = __builtin_fma(m, w[e], acc[e]);
+  }
+#pragma unroll
+  for (int e = 0; e < ET; ++e)
+    if (e < ne) sumA[(int64_t)e * npix + p] = acc[e];
+}
+
+// ---- per-block min / max of a field, NaN ignored (rjp_field_range) -----------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void field_range_kernel(const T* __restrict__ f, int64_t n,
+                                                          double* __restrict__ part) {
+  double lo = __builtin_inf(), hi = -__builtin_inf();
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const double v = (double)f[i];
+    if (v == v) { lo = __builtin_fmin(lo, v); hi = __builtin_fmax(hi, v); }
+  }
+#pragma unroll
+  for (int d = RJP_WAVE / 2; d > 0; d >>= 1) {
+    lo = __builtin_fmin(lo, __shfl_xor(lo, d, RJP_WAVE));
+    hi = __builtin_fmax(hi, __shfl_xor(hi, d, RJP_WAVE));
+  }
+  __shared__ double s_lo[256 / RJP_WAVE], s_hi[256 / RJP_WAVE];
+  if ((threadIdx.x & (RJP_WAVE - 1)) == 0) { s_lo[threadIdx.x / RJP_WAVE] = lo; s_hi[threadIdx.x / RJP_WAVE] = hi; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < 256 / RJP_WAVE; ++w) { lo = __builtin_fmin(lo, s_lo[w]); hi = __builtin_fmax(hi, s_hi[w]); }
+    part[2 * blockIdx.x] = lo;
+    part[2 * blockIdx.x + 1] = hi;
+  }
+}
+
+hipError_t field_range_launch(const void* d_field, int64_t n, int dtype, double* d_part,
+                              hipStream_t st) {
+  if (dtype == RJP_F64)
+    hipLaunchKernelGGL(field_range_kernel<double>, dim3(RJP_RANGE_BLOCKS), dim3(256), 0, st,
+                       (const double*)d_field, n, d_part);
+  else
+    hipLaunchKernelGGL(field_range_kernel<float>, dim3(RJP_RANGE_BLOCKS), dim3(256), 0, st,
+                       (const float*)d_field, n, d_part);
+  return hipGetLastError();
+}
+
+// ---- host side --------------------------------------------------------------------------------
+static double burst_F(const rjp_bursts* hb, int jet, double tl) {
+  double chi = 1.0;
+  for (int i = 0; i < hb->n[jet]; ++i) {
+    const double d = tl - hb->t0[jet][i];
+    chi += hb->amp_rel[jet][i] * std::exp(-d * d * hb->inv2s2[jet][i]);
+  }
+  return chi * chi;
+}
+
+size_t moments_workspace_bytes(int64_t npix) {
+  const int64_t npixp = (npix + kMomSL - 1) / kMomSL * kMomSL;
+  return (size_t)kMomIdx * (size_t)npixp * sizeof(double) + 256;
+}
+
+// Can this scan take the moment path, and if so: its W tables.  `mp.W` = [chunk][idx][32].
+bool moments_plan(const rjp_fields* fl, const rjp_bursts* hb, const double* epochs, int n_epochs,
+                  int mode, bool want_em, size_t work_bytes, MomPlan& mp) {
+  constexpr int K = RJP_MOM_BINS, N = RJP_MOM_ORDER, ET = RJP_MOM_TILE;
+  mp.ok = false;
+  if (!hb || (hb->n[0] <= 0 && hb->n[1] <= 0)) return false;
+  if (want_em || n_epochs < RJP_MOM_MIN_EPOCHS) return false;
+  if (scan_layout(fl, mode, false) != 2 /* LAY_TAU */ || !fl->d_ts) return false;
+  if (!(fl->ts_hi >= fl->ts_lo) || !std::isfinite(fl->ts_lo) || !std::isfinite(fl->ts_hi) ||
+      (fl->ts_lo == 0.0 && fl->ts_hi == 0.0))
+    return false;                                               // range not provided
+  if (work_bytes < moments_workspace_bytes((int64_t)fl->nx * fl->nz)) return false;
+  for (int e = 0; e < n_epochs; ++e)
+    if (!std::isfinite(epochs[e])) return false;
+  // same request as last time?
+  if (mp.key_E == n_epochs && mp.key_lo == fl->ts_lo && mp.key_hi == fl->ts_hi &&
+      mp.key_epochs.size() == (size_t)n_epochs &&
+      std::memcmp(mp.key_epochs.data(), epochs, sizeof(double) * n_epochs) == 0 &&
+      mp.key_n[0] == hb->n[0] && mp.key_n[1] == hb->n[1]) {
+    bool same = true;
+    size_t o = 0;
+    for (int j = 0; j < 2 && same; ++j)
+      for (int i = 0; i < hb->n[j] && same; ++i, o += 3)
+        same = mp.key_bursts[o] == hb->t0[j][i] && mp.key_bursts[o + 1] == hb->amp_rel[j][i] &&
+               mp.key_bursts[o + 2] == hb->inv2s2[j][i];
+    if (same) { mp.ok = mp.key_ok; return mp.ok; }
+  }
+  mp.key_E = n_epochs; mp.key_lo = fl->ts_lo; mp.key_hi = fl->ts_hi;
+  mp.key_epochs.assign(epochs, epochs + n_epochs);
+  mp.key_n[0] = hb->n[0]; mp.key_n[1] = hb->n[1];
+  mp.key_bursts.clear();
+  for (int j = 0; j < 2; ++j)
+    for (int i = 0; i < hb->n[j]; ++i) {
+      mp.key_bursts.push_back(hb->t0[j][i]);
+      mp.key_bursts.push_back(hb->amp_rel[j][i]);
+      mp.key_bursts.push_back(hb->inv2s2[j][i]);
+    }
+  mp.key_ok = false;
+
+  const double span = fl->ts_hi - fl->ts_lo;
+  const double h = span > 0.0 ? span / K : 1.0;
+  mp.s0 = fl->ts_lo;
+  mp.inv_h = 1.0 / h;
+  mp.has_bursts[0] = hb->n[0] > 0;
+  mp.has_bursts[1] = hb->n[1] > 0;
+  mp.nchunk = (n_epochs + ET - 1) / ET;
+  mp.W.assign((size_t)mp.nchunk * kMomIdx * ET, 0.0);
+  // Chebyshev nodes and the DCT matrix
+  const double pi = 3.14159265358979323846;
+  double xn[N], cs[N][N];
+  for (int i = 0; i < N; ++i) {
+    xn[i] = std::cos(pi * (i + 0.5) / N);
+    for (int n = 0; n < N; ++n) cs[n][i] = std::cos(pi * n * (i + 0.5) / N);
+  }
+  constexpr int NT = 2 * N + 1;                       // test points of the accuracy check
+  double worst = 0.0;
+  for (int e = 0; e < n_epochs; ++e) {
+    const int c = e / ET, el = e % ET;
+    double* Wc = mp.W.data() + (size_t)c * kMomIdx * ET;
+    for (int j = 0; j < 2; ++j)
+      for (int k = 0; k < K; ++k) {
+        double* col = Wc + (size_t)((j * K + k) * N) * ET + el;      // stride ET between n
+        if (hb->n[j] <= 0) { col[0] = 1.0; continue; }             // F == 1
+        const double ck = mp.s0 + (k + 0.5) * h;
+        double f[N], cf[N];
+        for (int i = 0; i < N; ++i) f[i] = burst_F(hb, j, epochs[e] - (ck + 0.5 * h * xn[i]));
+        for (int n = 0; n < N; ++n) {
+          double s = 0.0;
+          for (int i = 0; i < N; ++i) s += f[i] * cs[n][i];
+          cf[n] = s * (n == 0 ? 1.0 : 2.0) / N;
+          col[(size_t)n * ET] = cf[n];
+        }
+        // accuracy: the interpolant against F on a finer grid (Clenshaw)
+        for (int m = 0; m < NT; ++m) {
+          const double xv = -1.0 + 2.0 * m / (NT - 1);
+          double b1 = 0.0, b2 = 0.0;
+          for (int n = N - 1; n >= 1; --n) { const double b0 = 2.0 * xv * b1 - b2 + cf[n]; b2 = b1; b1 = b0; }
+          const double val = xv * b1 - b2 + cf[0];
+          const double ref = burst_F(hb, j, epochs[e] - (ck + 0.5 * h * xv));
+          const double err = std::fabs(val - ref) / ref;           // F >= ... > 0 (chi > 0)
+          if (!(err <= worst)) worst = err;
+        }
+      }
+  }
+  mp.worst = worst;
+  mp.key_ok = mp.ok = worst <= RJP_MOM_TOL;
+  return mp.ok;
+}
+
+hipError_t moments_run(const rjp_fields* fl, const MomPlan& mp, const double* d_W, int n_epochs,
+                       double* sumA, double* ws, hipStream_t st) {
+  const int64_t npix = (int64_t)fl->nx * fl->nz;
+  const int64_t npixp = (npix + kMomSL - 1) / kMomSL * kMomSL;
+  const size_t shm = (size_t)kMomIdx * kMomSL * sizeof(double);
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)moments_kernel,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
+  MomDev md;
+  md.s0 = mp.s0; md.inv_h = mp.inv_h;
+  md.has_bursts[0] = mp.has_bursts[0]; md.has_bursts[1] = mp.has_bursts[1];
+  hipLaunchKernelGGL(moments_kernel, dim3((unsigned)(npixp / kMomSL)), dim3(256), shm, st,
+                     (const double*)fl->d_a0, (const double*)fl->d_ts, fl->d_ylo, fl->d_yhi,
+                     fl->ny, fl->nz, npix, npixp, md, ws);
+  hipError_t err = hipGetLastError();
+  if (err != hipSuccess) return err;
+  for (int c = 0; c < mp.nchunk; ++c) {
+    const int ne = std::min(RJP_MOM_TILE, n_epochs - c * RJP_MOM_TILE);
+    hipLaunchKernelGGL(moments_eval_kernel, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, st,
+                       ws, npix, npixp, d_W + (size_t)c * kMomIdx * RJP_MOM_TILE, ne,
+                       sumA + (int64_t)c * RJP_MOM_TILE * npix);
+    err = hipGetLastError();
+    if (err != hipSuccess) return err;
+  }
+  return hipSuccess;
+}
+
+}  // namespace rjp

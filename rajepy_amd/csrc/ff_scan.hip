@@ -163,7 +163,7 @@ __global__ __launch_bounds__(kBlock) void ff_maps_kernel(
 #pragma unroll
     for (int v = 0; v < VEC; ++v) {
       t[v] = ctau[f] * A[v];
-      s[v] = cflux[f] * (ta[v] * (1.0 - exp(-t[v])));
+      s[v] = cflux[f] * (ta[v] * one_minus_exp_neg(t[v]));
     }
     const int64_t o = ((int64_t)e * nchan + f) * npix + p;
     if (live) {
@@ -377,7 +377,12 @@ size_t ff_scan_workspace_bytes(int nx, int ny, int nz, int n_epochs) {
     need = std::max<int64_t>(need, s * nacc(et));
   }
   // (an n_epochs that is no tile size itself is cut into tiles no larger than it)
-  return (size_t)need * npix * sizeof(double) + 256;
+  size_t bytes = (size_t)need * npix * sizeof(double) + 256;
+  // sweeps long enough for the moment path (ff_moments.hip) keep its transposed moments here
+  // (8 KiB per sightline; maps so large that this passes 6 GiB stay on the epoch tiles)
+  if (n_epochs >= RJP_MOM_MIN_EPOCHS && moments_workspace_bytes(npix) <= ((size_t)6 << 30))
+    bytes = std::max(bytes, moments_workspace_bytes(npix));
+  return bytes;
 }
 
 // Decide whether a tile of epochs may use the uniform-spacing recurrence and fill its

@@ -68,13 +68,17 @@ constexpr int kMaxTile = 32;     // largest epoch tile (uniformly spaced epochs,
 // 4-wide (f32) lanes on the wide layout: 2 rows (8 cells per batch, 166 VGPRs; 4 rows need
 // 256 + AGPR spills); on the compact layout 4 rows still fit 3 waves/SIMD and are 3 % faster
 // ... and 2 rows in the power-law Gaunt mode, whose T^-1.35 chains are batched by eight cells
+// single-epoch scan on the tau layout (a0, ts): 6 rows = 12 loads of 16 B in flight per lane,
+// 126 VGPRs, still 4 waves/SIMD -- 1.2-1.8 % faster than 4 rows in an A/B on the same
+// buffers (8 rows: 158 VGPRs, 3 waves, no better; profiles/r03_k1_tau_tuning_ab.log); with
+// the EM accumulators (a third field) 6 rows would cost a wave: 4
 #ifndef RJP_UNROLL_TAU
-#define RJP_UNROLL_TAU 4      /* rows in flight of the single-epoch scan on the tau layout */
+#define RJP_UNROLL_TAU 6
 #endif
-__host__ __device__ constexpr int unroll_for(int vec, int et, int lay, int mode) {
+__host__ __device__ constexpr int unroll_for(int vec, int et, int lay, int mode, bool em = true) {
   return vec * et >= 16 ? 1
          : vec * et >= 8 ? 2
-         : lay == LAY_TAU ? (vec * et >= 4 ? 2 : RJP_UNROLL_TAU)
+         : lay == LAY_TAU ? (vec * et >= 4 ? 2 : em ? 4 : RJP_UNROLL_TAU)
          : vec == 4 && (lay == LAY_WIDE || mode == RJP_GFF_POWERLAW) ? 2 : RJP_UNROLL_BASE;
 }
 // The fast T^-1.35 (power-law Gaunt mode) is a property of the KERNEL, not of a row batch:
@@ -304,7 +308,7 @@ template <typename T, int VEC, int ET, int MODE, bool BURSTS, bool UNIF, int LAY
 __global__ __launch_bounds__(kBlock) void ff_scan_kernel(
     FieldPtrs<T> f, int ny, int nz, int64_t nchunks, int64_t npix, int ylen, int nsplit,
     BurstsDev b, EpochTile<ET> ep, double* __restrict__ ws) {
-  constexpr int kUnroll = unroll_for(VEC, ET, LAY, MODE);
+  constexpr int kUnroll = unroll_for(VEC, ET, LAY, MODE, EM);
   // 1-D grid with the y-split index fastest: workgroups that run together stream consecutive
   // y-ranges of the same sightlines, i.e. neighbouring memory, instead of ranges 16 MiB apart
   // (n_y n_z elements) -- +5 % on cfg4 (6.0 -> 6.3 TB/s)

@@ -52,6 +52,32 @@ hipError_t ff_maps_launch(const double* sumA, const double* tavg, int64_t npix, 
 hipError_t sum_partials_launch(const double* part, int rows, int nblk, double* out,
                                hipStream_t st);
 
+// ---- ff_moments.hip: epoch sweeps by launch-time moments --------------------------------------
+#define RJP_MOM_BINS 32          /* launch-time bins over [ts_lo, ts_hi] */
+#define RJP_MOM_ORDER 16         /* Chebyshev moments per (jet, bin) */
+#define RJP_MOM_TILE 32          /* epochs per pass of the contraction */
+#define RJP_MOM_MIN_EPOCHS 12    /* below: the epoch tiles are faster */
+#define RJP_MOM_TOL 1e-11        /* worst relative error of the expansion the host accepts */
+struct MomPlan {
+  bool ok = false;
+  double s0 = 0.0, inv_h = 0.0, worst = 0.0;
+  int has_bursts[2] = {0, 0};
+  int nchunk = 0;
+  std::vector<double> W;         // [chunk][2 * BINS * ORDER][TILE]
+  // the request the tables were built for (a sweep repeated with the same epochs reuses them)
+  int key_E = -1, key_n[2] = {0, 0};
+  bool key_ok = false;
+  double key_lo = 0.0, key_hi = 0.0;
+  std::vector<double> key_epochs, key_bursts;
+};
+size_t moments_workspace_bytes(int64_t npix);
+bool moments_plan(const rjp_fields* fl, const rjp_bursts* hb, const double* epochs, int n_epochs,
+                  int mode, bool want_em, size_t work_bytes, MomPlan& mp);
+hipError_t moments_run(const rjp_fields* fl, const MomPlan& mp, const double* d_W, int n_epochs,
+                       double* sumA, double* ws, hipStream_t st);
+hipError_t field_range_launch(const void* d_field, int64_t n, int dtype, double* d_part,
+                              hipStream_t st);
+
 // ---- ff_scan_inst.hip: one slice of the K1 kernel family per translation unit -------------
 #define RJP_SCAN_SLICE_ARGS                                                                  \
   const rjp_fields *fl, const BurstsDev &b, bool bursts, const double *t, const UnifDev &un, \

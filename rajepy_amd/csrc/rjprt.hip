@@ -20,6 +20,8 @@ struct rjp_ctx {
   // caller's stream and a slot is overwritten only after its readers have finished.  A call
   // whose tables equal a slot's content (a sweep over epochs at a fixed channel list) reuses
   // the device copy: no host-to-device copy between the scan and the map stage.
+  rjp::MomPlan mom;               // last moment-path request (its tables are reused)
+  int last_path = 0;              // 0 = epoch tiles, 1 = moments
   static constexpr int kSlots = 8;
   struct Slot {
     double* h = nullptr;
@@ -274,6 +276,15 @@ int rjp_unmask_launch_times(rjp_ctx* ctx, const rjp_fields* fields, int32_t jet,
   return RJP_OK;
 }
 
+int rjp_field_range(rjp_ctx* ctx, const void* d_field, int64_t n, int dtype, double* d_partials,
+                    void* stream) {
+  if (int r = bind(ctx)) return r;
+  if (!d_field || !d_partials || n <= 0) return fail(ctx, RJP_ERR_ARG, "rjp_field_range: bad pointers/size");
+  if (dtype != RJP_F32 && dtype != RJP_F64) return fail(ctx, RJP_ERR_ARG, "bad dtype tag");
+  RJP_HIP(ctx, rjp::field_range_launch(d_field, n, dtype, d_partials, (hipStream_t)stream));
+  return RJP_OK;
+}
+
 int rjp_tavg(rjp_ctx* ctx, const rjp_fields* fields, double* d_tavg, void* d_work,
              size_t work_bytes, void* stream) {
   if (int r = bind(ctx)) return r;
@@ -323,6 +334,24 @@ int rjp_ff_scan(rjp_ctx* ctx, const rjp_fields* fields, const rjp_bursts* bursts
   if (work_bytes < rjp::ff_scan_workspace_bytes(fields->nx, fields->ny, fields->nz, n_epochs))
     return fail(ctx, RJP_ERR_WORKSPACE, "rjp_ff_scan: workspace smaller than rjp_ff_scan_workspace()");
   hipStream_t st = (hipStream_t)stream;
+  // epoch sweeps by launch-time moments (ff_moments.hip) when the caller provided the launch-time
+  // range and the host-side accuracy check of the expansion passes
+  if (rjp::moments_plan(fields, bursts, h_epochs_s, n_epochs, gff_mode, d_em != nullptr,
+                        work_bytes, ctx->mom)) {
+    if (d_tavg) {
+      if (!fields->d_temp)
+        return fail(ctx, RJP_ERR_ARG, "rjp_ff_scan: d_tavg on the tau layout needs fields.d_temp");
+      RJP_HIP(ctx, rjp::tavg_launch(fields, d_tavg, (double*)d_work, st));
+    }
+    ctx->last_path = 1;
+    const double* src[1] = {ctx->mom.W.data()};
+    const size_t len[1] = {ctx->mom.W.size()};
+    double* dev[1];
+    if (int r = stage_tables(ctx, st, src, len, 1, dev)) return r;
+    return finish_staged(ctx, st, rjp::moments_run(fields, ctx->mom, dev[0], n_epochs, d_sumA,
+                                                   (double*)d_work, st), "moments_run");
+  }
+  ctx->last_path = 0;
   rjp::ScanPlan plan;
   rjp::ff_scan_plan(fields, bursts, h_epochs_s, n_epochs, gff_mode, d_em != nullptr, plan);
   double* d_ext = nullptr;
@@ -340,6 +369,12 @@ int rjp_ff_scan(rjp_ctx* ctx, const rjp_fields* fields, const rjp_bursts* bursts
   if (d_ext) return finish_staged(ctx, st, e, "ff_scan_run");
   if (e != hipSuccess) return fail(ctx, RJP_ERR_HIP, "ff_scan_run", e);
   return RJP_OK;
+}
+
+int rjp_last_scan_path(const rjp_ctx* ctx, double* worst_rel_err) {
+  if (!ctx) return RJP_ERR_ARG;
+  if (worst_rel_err) *worst_rel_err = ctx->last_path == 1 ? ctx->mom.worst : 0.0;
+  return ctx->last_path;
 }
 
 int rjp_time_ff_scan(rjp_ctx* ctx, const rjp_fields* fields, const rjp_bursts* bursts,

@@ -954,7 +954,7 @@ __global__ __launch_bounds__(kRB) void rrl_maps_kernel(
     // B_nu(T) ~ 1/(exp(h nu/kT) - 1)   (physics.py:571-574)
     const double bnu = 1.0 / (exp(hnu_k[fch] / tavg[p]) - 1.0);
     // rrls.py:445-447
-    s = cflux[fch] * bnu * exp(-tau_ff[o]) * (1.0 - exp(-tau_rrl[o]));
+    s = cflux[fch] * bnu * exp(-tau_ff[o]) * one_minus_exp_neg(tau_rrl[o]);
     if (flux_ff) s += flux_ff[o];
     if (flux) flux[o] = s;
   }

@@ -33,6 +33,8 @@ class DeviceFields:
         self.em0 = None                     # optional compact scan field (rjp_fields.d_em0)
         self.a0 = None                      # optional tau scan field (rjp_fields.d_a0) ...
         self.a0_mode = 0                    # ... and the Gaunt mode it was built for
+        self.ts_range = None                # optional (ts_lo, ts_hi) of the finite launch times
+        self._ts_range_of = None            # ... and the `ts` tensor it was measured on
 
     @property
     def ncells(self):
@@ -49,6 +51,9 @@ class DeviceFields:
         f.d_em0 = self.em0.data_ptr() if self.em0 is not None else None
         f.d_a0 = self.a0.data_ptr() if self.a0 is not None else None
         f.a0_mode = int(self.a0_mode)
+        if (self.ts_range is not None and self.ts is not None and
+                self._ts_range_of == self.ts.data_ptr()):
+            f.ts_lo, f.ts_hi = self.ts_range
         f.d_ts = self.ts.data_ptr() if self.ts is not None else None
         f.d_vy = self.vy.data_ptr() if self.vy is not None else None
         f.nx, f.ny, f.nz = self.shape
@@ -127,6 +132,8 @@ class RTEngine:
         self._work = None
         self.use_compact = not (_lib.DEBUG and os.environ.get("RJP_NO_COMPACT"))
         self.use_tau = not (_lib.DEBUG and os.environ.get("RJP_NO_TAU"))
+        # epoch sweeps by launch-time moments (rjp_fields.ts_lo / ts_hi): off = the epoch tiles
+        self.use_moments = not (_lib.DEBUG and os.environ.get("RJP_NO_MOMENTS"))
 
     def close(self):
         if getattr(self, "ctx", None):
@@ -243,6 +250,24 @@ class RTEngine:
         _lib.check(self.lib.rjp_tavg(self.ctx, C.byref(fs), out.data_ptr(), work.data_ptr(),
                                      work.numel(), self._stream()), self.ctx, "rjp_tavg")
         return out
+
+    def launch_time_range(self, fields):
+        """(min, max) of the finite launch times of `fields` (rjp_field_range), measured once
+        per `ts` tensor: with it, scans of >= 12 epochs without EM maps on the tau layout may
+        take the moment path (include/rjprt.h `rjp_fields.ts_lo`)."""
+        if fields.ts is None:
+            return None
+        if fields.ts_range is not None and fields._ts_range_of == fields.ts.data_ptr():
+            return fields.ts_range
+        part = self._f64(2 * _lib.RJP_RANGE_BLOCKS)
+        _lib.check(self.lib.rjp_field_range(self.ctx, fields.ts.data_ptr(), fields.ncells,
+                                            fields.dtype, part.data_ptr(), self._stream()),
+                   self.ctx, "rjp_field_range")
+        h = part.cpu().numpy().reshape(-1, 2)
+        lo, hi = float(h[:, 0].min()), float(h[:, 1].max())
+        fields.ts_range = (lo, hi) if np.isfinite(lo) and np.isfinite(hi) and hi >= lo else None
+        fields._ts_range_of = fields.ts.data_ptr()
+        return fields.ts_range
 
     def compute_y_bounds(self, fields):
         """Attach the per-sightline occupied y-range to `fields` (rjp_y_bounds): later scans
@@ -365,13 +390,18 @@ class RTEngine:
         return self.tau_layout(out, tau_mode) if tau_mode is not None else out
 
     # -- K1 / K2 -----------------------------------------------------------------------------
-    def _scan_struct(self, fields, bursts):
+    def _scan_struct(self, fields, bursts, n_epochs=1):
         """`rjp_fields` for a free-free scan.  A model with bursts in ONE jet only scans a copy
         of the launch times in which the NaNs of the other jet's cells are cleared
         (rjp_unmask_launch_times): the reference's burst-less jet has a constant mass-loss rate,
         so a NaN launch time does not drop its cells (classes.py:232-233, 442-448).  The copy
         is kept with the fields and rebuilt when `ts` or the flag-carrying field changes."""
+        if (self.use_moments and bursts is not None and fields.a0 is not None and
+                n_epochs >= 12):
+            self.launch_time_range(fields)
         fs = fields.struct()
+        if not self.use_moments:
+            fs.ts_lo = fs.ts_hi = 0.0
         if bursts is None or fields.ts is None:
             return fs
         n_r, n_b = int(bursts.n[0]), int(bursts.n[1])
@@ -407,7 +437,7 @@ class RTEngine:
             sumA, em, tavg = out
         wb = self.lib.rjp_ff_scan_workspace(nx, ny, nz, E)
         work = self._workspace(wb)
-        fs = self._scan_struct(fields, bursts)
+        fs = self._scan_struct(fields, bursts, E)
         ep = _lib.dbl_array(epochs_s)
         _lib.check(self.lib.rjp_ff_scan(
             self.ctx, C.byref(fs), C.byref(bursts) if bursts is not None else None, ep, E,
@@ -415,6 +445,13 @@ class RTEngine:
             tavg.data_ptr() if tavg is not None else None, work.data_ptr(), work.numel(),
             self._stream()), self.ctx, "rjp_ff_scan")
         return sumA, em, tavg
+
+    def last_scan_path(self):
+        """('tiles' | 'moments', worst relative error of the moment expansion) of the last
+        rjp_ff_scan of this engine."""
+        err = C.c_double()
+        path = self.lib.rjp_last_scan_path(self.ctx, C.byref(err))
+        return ("moments" if path == 1 else "tiles"), err.value
 
     def time_ff_scan(self, fields, bursts, epochs_s, gff_mode, reps=5, want_em=True,
                      want_tavg=True):
@@ -426,7 +463,7 @@ class RTEngine:
         tavg = self._f64(P) if want_tavg else None
         wb = self.lib.rjp_ff_scan_workspace(nx, ny, nz, E)
         work = self._workspace(wb)
-        fs = self._scan_struct(fields, bursts)
+        fs = self._scan_struct(fields, bursts, E)
         ep = _lib.dbl_array(epochs_s)
         ms = C.c_double()
         _lib.check(self.lib.rjp_time_ff_scan(

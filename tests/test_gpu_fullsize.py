@@ -128,6 +128,7 @@ def test_cfg4_tau_layout_is_bit_identical_at_full_size(eng, temp_mode):
     mode = E.RJP_GFF_SCALAR if temp_mode == 0 else E.RJP_GFF_POWERLAW
     fields = eng.synth_fields(shape, SEED, temp_mode, 8, csize_au=0.5, tau_mode=mode)
     assert fields.a0 is not None and fields.scan_fields(mode, False) == 2
+    eng.use_moments = False        # the epoch TILES are what is compared bit for bit here
     jet = _sample_jet(shape, [(0, 0)], temp_mode, 0. if temp_mode == 0 else -0.5)
     bursts = U.bursts_from_oracle(jet)
     e1 = [1.0 * orc.YEAR]
@@ -159,6 +160,51 @@ def test_cfg4_tau_layout_is_bit_identical_at_full_size(eng, temp_mode):
         assert torch.equal(tav, tw)
     assert torch.equal(tav, t_cmp)
     fields.em0, fields.a0 = em0, a0
+    eng.use_moments = True
+
+
+def test_cfg5_epoch_sweep_by_launch_time_moments_full_size(eng):
+    """BASELINE configs[4] as benchmarked since round 3: 512x4096x512, 32 uniformly spaced
+    epochs, no EM maps, tau layout -> the moment path (one pass over the grid + one
+    contraction).  Sampled sightlines (incl. the edges of the first / last 16-sightline groups
+    and both sides of the jet plane) against the oracle at epochs 0 / 15 / 31; the whole
+    [32, P] result against the 32-epoch tile of the same sweep at 5e-11; and 40 irregularly
+    spaced epochs (two contraction passes) against the oracle."""
+    from rajepy_amd import engine as E
+    from rajepy_amd.maths import physics as ph
+    shape = (512, 4096, 512)
+    nx, ny, nz = shape
+    fields = eng.synth_fields(shape, SEED, 0, 8, csize_au=0.5, tau_mode=E.RJP_GFF_SCALAR)
+    rng = np.random.default_rng(17)
+    pix = [(int(rng.integers(nx)), int(rng.integers(nz))) for _ in range(10)]
+    pix += _edge_pixels(nx, nz, 16)
+    jet = _sample_jet(shape, pix, 0, 0.)
+    bursts = U.bursts_from_oracle(jet)
+    idx = [x * nz + z for (x, z) in pix]
+    ctau, _ = E.ff_channel_coeffs([5e9], 0.5, 120., E.RJP_GFF_SCALAR, [ph.gff(5e9, 1e4)])
+    ep = [float(t) for t in np.linspace(0., 5., 32) * orc.YEAR]
+    eng.use_moments = True
+    mom = eng.ff_scan(fields, bursts, ep, E.RJP_GFF_SCALAR, want_em=False, want_tavg=False)[0].clone()
+    path, err = eng.last_scan_path()
+    assert path == "moments" and err <= 1e-11
+    eng.use_moments = False
+    til = eng.ff_scan(fields, bursts, ep, E.RJP_GFF_SCALAR, want_em=False, want_tavg=False)[0]
+    eng.use_moments = True
+    eng.synchronize()
+    rel = ((mom - til).abs() / til).max().item()
+    assert rel < 5e-11, rel
+    m_s = mom.cpu().numpy()[:, idx]
+    for e in (0, 15, 31):
+        jet.time = ep[e]
+        np.testing.assert_allclose(ctau[0] * m_s[e], jet.optical_depth_ff(5e9)[:, 0], rtol=1e-10)
+    del mom, til
+    ep2 = sorted(float(t) for t in rng.uniform(0., 5., 40) * orc.YEAR)
+    mom2 = eng.ff_scan(fields, bursts, ep2, E.RJP_GFF_SCALAR, want_em=False, want_tavg=False)[0]
+    assert eng.last_scan_path()[0] == "moments"
+    m2 = mom2.cpu().numpy()[:, idx]
+    for e in (0, 21, 39):
+        jet.time = ep2[e]
+        np.testing.assert_allclose(ctau[0] * m2[e], jet.optical_depth_ff(5e9)[:, 0], rtol=1e-10)
 
 
 def torch_all_finite(t):

@@ -1,0 +1,176 @@
+"""Epoch sweeps by launch-time moments (rajepy_amd/csrc/ff_moments.hip) through the C-ABI.
+
+sum_y a0 chi(t_e - ts)^2 (classes.py:861-875, 1395-1432) is a convolution of the sightline's
+launch-time distribution with chi^2: one pass accumulates Chebyshev moments of a0 over launch-time
+bins, any number of epochs is a contraction with host-computed coefficient tables.  The host
+accepts the expansion only when it is good to 1e-11 for the call's bursts and epochs, so the maps
+must agree with the epoch tiles (themselves at 1e-11 of the oracle) and with the oracle; sweeps
+the expansion cannot serve (narrow bursts over a wide launch-time range, EM maps, few epochs, no
+range given) must run the tiles, bit for bit as before."""
+import copy
+
+import numpy as np
+import pytest
+
+from oracle import rt_oracle as orc
+from tests import gpu_util as U
+
+pytestmark = pytest.mark.gpu
+RTOL = 5e-11          # 1e-11 expansion + the tiles' own 1e-11 + summation order
+
+
+@pytest.fixture(scope="module")
+def eng():
+    from rajepy_amd.engine import RTEngine
+    e = RTEngine(0)
+    yield e
+    e.close()
+
+
+def _jet(shape, seed, ejection=None, temp_mode=0):
+    g = U.synth_host(shape, seed, temp_mode)
+    p = copy.deepcopy(U.load_golden("cfg1_example")[2])
+    p["ejection"] = ejection if ejection is not None else U.example_bursts_params()
+    if temp_mode:
+        p["power_laws"]["q_T"] = -0.5
+    p["grid"].update(n_x=shape[0], n_y=shape[1], n_z=shape[2])
+    jet = orc.OracleJet.from_fields(p, g["nd"], g["xi"], g["temp"], g["ff"], g["areas"],
+                                    g["ts"], g["rr"], g["vy"])
+    return g, p, jet
+
+
+def _both(eng, f, bursts, ep, mode, **kw):
+    eng.use_moments = True
+    a = eng.ff_scan(f, bursts, ep, mode, want_em=False, want_tavg=False, **kw)[0].clone()
+    path = eng.last_scan_path()
+    eng.use_moments = False
+    b = eng.ff_scan(f, bursts, ep, mode, want_em=False, want_tavg=False, **kw)[0].clone()
+    assert eng.last_scan_path()[0] == "tiles"
+    eng.use_moments = True
+    eng.synchronize()
+    return a.cpu().numpy(), b.cpu().numpy(), path
+
+
+@pytest.mark.parametrize("temp_mode", [0, 1])
+@pytest.mark.parametrize("years", [list(np.linspace(0., 5., 32)), list(np.linspace(0.3, 4.1, 12)),
+                                   list(np.linspace(0., 5., 37)),
+                                   sorted([0.0, 0.11, 0.5, 0.52, 0.9, 1.0, 1.3, 1.31, 1.9, 2.2, 2.25,
+                                           2.8, 3.3, 3.9, 4.4, 4.95, 5.0])])
+def test_moments_agree_with_the_epoch_tiles_and_the_oracle(eng, temp_mode, years):
+    """Uniform sweeps of 32 / 12 / 37 epochs (one and two contraction passes) and an irregular
+    list of 17 (which the tiles evaluate directly, 8 epochs at a time): the moment path is
+    taken, agrees with the tiles at 5e-11 and with the oracle's chained closures at 1e-10."""
+    from rajepy_amd import engine as E
+    from rajepy_amd.maths import physics as ph
+    shape = (6, 200, 48)
+    g, p, jet = _jet(shape, 20240777, temp_mode=temp_mode)
+    mode = E.RJP_GFF_SCALAR if temp_mode == 0 else E.RJP_GFF_POWERLAW
+    f = eng.upload_fields(g["nd"], g["xi"], g["temp"], g["ff"], g["areas"], g["ts"],
+                          g["rr"] < 0, csize_au=jet.csize, dtype=8)
+    eng.tau_layout(f, mode)
+    lo, hi = eng.launch_time_range(f)
+    assert lo == np.nanmin(g["ts"]) and hi == np.nanmax(g["ts"])
+    bursts = U.bursts_from_oracle(jet)
+    ep = [y * orc.YEAR for y in years]
+    mom, til, (path, err) = _both(eng, f, bursts, ep, mode)
+    assert path == "moments" and 0 < err <= 1e-11
+    np.testing.assert_allclose(mom, til, rtol=RTOL)
+    gv = [ph.gff(5e9, p["properties"]["T_0"])] if temp_mode == 0 else None
+    ctau, _ = E.ff_channel_coeffs([5e9], jet.csize, p["target"]["dist"], mode, gv)
+    for e in (0, len(ep) // 2, len(ep) - 1):
+        jet.time = ep[e]
+        np.testing.assert_allclose(ctau[0] * mom[e].reshape(shape[0], shape[2]),
+                                   jet.optical_depth_ff(5e9), rtol=1e-10)
+
+
+def test_moments_keep_nan_semantics_y_ranges_and_the_burstless_jet(eng):
+    """NaN / zero entries in every field, occupied y-ranges attached, an odd n_z (sightline
+    groups that straddle rows and a ragged last group), bursts in ONE jet only with NaN launch
+    times in both: the moment path drops exactly the cells the reference drops
+    (classes.py:232-233, 442-448, 1395-1432) -- against the tiles and the oracle."""
+    from rajepy_amd import engine as E
+    from rajepy_amd.maths import physics as ph
+    shape = (5, 90, 23)
+    ej = {"t_0": np.array([0.6, 1.4, 2.6]), "hl": np.array([0.4, 0.5, 0.45]),
+          "chi": np.array([4., 7., 3.]), "which": np.array(["B", "B", "B"])}
+    g, p, jet = _jet(shape, 99, ejection=ej)
+    rng = np.random.default_rng(8)
+    for k, vals in (("nd", [np.nan, 0.0]), ("xi", [np.nan]), ("temp", [np.nan, 0.0, -1.0]),
+                    ("ff", [np.nan, 0.0]), ("ts", [np.nan])):
+        m = rng.random(shape) < 0.1
+        g[k] = np.where(m, rng.choice(vals, size=shape), g[k])
+    g["nd"][:, :7, :] = np.nan                      # empty rows at both ends: y-ranges matter
+    g["nd"][:, -9:, :] = np.nan
+    jet = orc.OracleJet.from_fields(p, g["nd"], g["xi"], g["temp"], g["ff"], g["areas"],
+                                    g["ts"], g["rr"], g["vy"])
+    f = eng.upload_fields(g["nd"], g["xi"], g["temp"], g["ff"], g["areas"], g["ts"],
+                          g["rr"] < 0, csize_au=jet.csize, dtype=8)
+    eng.tau_layout(f, E.RJP_GFF_SCALAR)
+    eng.compute_y_bounds(f)
+    bursts = U.bursts_from_oracle(jet)
+    ep = [y * orc.YEAR for y in np.linspace(0., 4., 20)]
+    mom, til, (path, err) = _both(eng, f, bursts, ep, E.RJP_GFF_SCALAR)
+    assert path == "moments"
+    assert np.array_equal(mom == 0, til == 0)
+    np.testing.assert_allclose(mom, til, rtol=RTOL)
+    ctau, _ = E.ff_channel_coeffs([5e9], jet.csize, p["target"]["dist"], E.RJP_GFF_SCALAR,
+                                  [ph.gff(5e9, p["properties"]["T_0"])])
+    for e in (0, 9, 19):
+        jet.time = ep[e]
+        with np.errstate(all="ignore"):
+            ref = jet.optical_depth_ff(5e9)
+        np.testing.assert_allclose(ctau[0] * mom[e].reshape(shape[0], shape[2]), ref, rtol=1e-10)
+
+
+def test_sweeps_the_expansion_cannot_serve_run_the_tiles(eng):
+    """(a) a burst far narrower than a launch-time bin: the host's accuracy check refuses the
+    tables and the tiles run -- the result is the tiles' bit for bit; (b) EM maps asked for,
+    (c) fewer than 12 epochs, (d) no launch-time range in the struct: tiles as well."""
+    from rajepy_amd import engine as E
+    shape = (4, 64, 32)
+    ej = {"t_0": np.array([1.0, 2.0]), "hl": np.array([0.004, 0.3]), "chi": np.array([6., 3.]),
+          "which": np.array(["RB", "RB"])}
+    g, p, jet = _jet(shape, 5, ejection=ej)
+    f = eng.upload_fields(g["nd"], g["xi"], g["temp"], g["ff"], g["areas"], g["ts"],
+                          g["rr"] < 0, csize_au=jet.csize, dtype=8)
+    eng.tau_layout(f, E.RJP_GFF_SCALAR)
+    ep = [y * orc.YEAR for y in np.linspace(0., 4., 16)]
+    narrow = U.bursts_from_oracle(jet)
+    mom, til, (path, _) = _both(eng, f, narrow, ep, E.RJP_GFF_SCALAR)
+    assert path == "tiles" and np.array_equal(mom, til)
+    wide = E.make_bursts([(1.0 * orc.YEAR, 4., 0.2 * orc.YEAR)], [(2.0 * orc.YEAR, 2., 0.3 * orc.YEAR)])
+    assert _both(eng, f, wide, ep, E.RJP_GFF_SCALAR)[2][0] == "moments"
+    eng.ff_scan(f, wide, ep, E.RJP_GFF_SCALAR, want_em=True, want_tavg=False)
+    assert eng.last_scan_path()[0] == "tiles"
+    eng.ff_scan(f, wide, ep[:11], E.RJP_GFF_SCALAR, want_em=False, want_tavg=False)
+    assert eng.last_scan_path()[0] == "tiles"
+    f.ts_range = None
+    f._ts_range_of = f.ts.data_ptr()          # "measured": no finite launch time known
+    eng.use_moments = False
+    eng.ff_scan(f, wide, ep, E.RJP_GFF_SCALAR, want_em=False, want_tavg=False)
+    eng.use_moments = True
+    assert eng.last_scan_path()[0] == "tiles"
+
+
+def test_jetmodel_light_curves_take_the_moment_path(eng, tmp_path):
+    """JetModel.flux_vs_time on the example jet (K4-built fields, occupied y-ranges): 40 epochs
+    go through the moment path and reproduce the light curve of the reference's anchors
+    (total flux at 5 GHz at t = 0 / 0.5 / 1 / 2 / 3 yr)."""
+    from rajepy_amd import classes, logger
+    from tests.test_host_logic import example_params
+    jm = classes.JetModel(example_params(), log=logger.Log(str(tmp_path / "a.log"), verbose=False),
+                          engine=eng)
+    times = np.array(sorted(set(np.linspace(0., 3., 36)) | {0.5, 1.0, 2.0})) * orc.YEAR
+    lc = jm.flux_vs_time(times, [5e9])[:, 0]
+    assert eng.last_scan_path()[0] == "moments"
+    ref = {0.0: 1.158223515e-3, 0.5: 1.279591671e-3, 1.0: 1.379008153e-3, 2.0: 1.429076011e-3,
+           3.0: 1.418864143e-3}
+    for yr, want in ref.items():
+        k = int(np.argmin(np.abs(times - yr * orc.YEAR)))
+        assert abs(times[k] - yr * orc.YEAR) < 1.0
+        assert abs(lc[k] - want) <= 2e-9 * want
+    eng.use_moments = False
+    jm2 = classes.JetModel(example_params(), log=jm.log, engine=eng)
+    lc2 = jm2.flux_vs_time(times, [5e9])[:, 0]
+    eng.use_moments = True
+    np.testing.assert_allclose(lc, lc2, rtol=RTOL)

@@ -54,7 +54,8 @@ def test_abi_exports_every_declared_symbol():
 
 
 def test_abi_struct_layouts_match_header():
-    assert ctypes.sizeof(_lib.Fields) == 6 * 8 + 4 * 4 + 8 + 3 * 8 + 8 + 2 * 4
+    assert ctypes.sizeof(_lib.Fields) == 6 * 8 + 4 * 4 + 8 + 3 * 8 + 8 + 2 * 4 + 2 * 8
+    assert _lib.Fields.ts_lo.offset == _lib.Fields.d_a0.offset + 16       # appended again (105)
     assert _lib.Fields.d_a0.offset == 6 * 8 + 4 * 4 + 8 + 3 * 8      # appended: ABI 103 prefix kept
     assert _lib.Fields.a0_mode.offset == _lib.Fields.d_a0.offset + 8
     assert ctypes.sizeof(_lib.Bursts) == 8 + 3 * 2 * 8            # counts + 6 host pointers
@@ -81,6 +82,9 @@ def test_workspace_queries_are_host_arithmetic():
     # 4x the sightlines: 32 ranges of a 32-epoch tile would need 17.7 GB -> halved until < 6 GiB
     big = lib.rjp_ff_scan_workspace(1024, 4096, 1024, 32)
     assert big == 16 * (2 * 16 + 2) * 4 * npix * 8 + 256           # its 16-epoch tiles decide
+    # sweeps of >= 12 epochs may take the moment path: 2 x 32 x 16 moments per sightline
+    assert lib.rjp_ff_scan_workspace(64, 128, 64, 12) == 1024 * 64 * 64 * 8 + 256
+    assert lib.rjp_ff_scan_workspace(64, 128, 64, 11) < 1024 * 64 * 64 * 8
     assert lib.rjp_ff_scan_workspace(0, 4, 4, 1) == 0
     assert lib.rjp_ff_maps_workspace(npix, 1, 256) > 0
     assert lib.rjp_ff_maps_workspace(0, 1, 1) == 0

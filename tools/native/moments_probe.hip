@@ -1,0 +1,143 @@
+// Feasibility probe (round 3): how fast can per-sightline Chebyshev moments of
+// a0 over launch-time bins be accumulated in ONE pass over the grid when launch times are
+// uncorrelated along y (the synthetic set)?  tau_e(p) = sum_y a0_y F(t_e - ts_y) is a convolution
+// of the sightline's launch-time distribution with F = chi^2: with K bins x N moments per jet the
+// whole epoch sweep becomes this pass + a small contraction.  Accumulators: LDS, f64 atomics.
+//   hipcc --offload-arch=gfx950 -O3 -o moments_probe moments_probe.hip ; ./moments_probe
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
+
+__global__ void fill(double* a0, double* ts, size_t n, int nz) {
+  size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  const size_t step = (size_t)gridDim.x * 256;
+  for (; i < n; i += step) {
+    unsigned long long x = i * 0x9E3779B97F4A7C15ull; x ^= x >> 29; x *= 0xBF58476D1CE4E5B9ull;
+    unsigned long long y = (i + 0x1234567) * 0xD1B54A32D192ED03ull; y ^= y >> 31; y *= 0x94D049BB133111EBull;
+    const double u = (double)(x >> 11) * (1.0 / 9007199254740992.0);
+    const double v = (double)(y >> 11) * (1.0 / 9007199254740992.0);
+    const bool red = (int)(i % nz) < nz / 2;
+    a0[i] = (red ? -1.0 : 1.0) * (1.0 + 100.0 * u);
+    ts[i] = 5.0 * v;
+  }
+}
+
+// SL sightlines per workgroup (z-adjacent), 256 threads: thread = (sightline, y-row offset)
+template <int K, int N, int SL, int U>
+__global__ __launch_bounds__(256) void moments(const double* __restrict__ a0, const double* __restrict__ ts,
+                                               int ny, int nz, double s0, double inv_h,
+                                               double* __restrict__ MT, size_t npix) {
+  extern __shared__ double lds[];          // [2][K][N][SL]
+  constexpr int TOT = 2 * K * N * SL;
+  for (int i = threadIdx.x; i < TOT; i += 256) lds[i] = 0.0;
+  __syncthreads();
+  const int sl = threadIdx.x % SL, yr = threadIdx.x / SL;
+  constexpr int YR = 256 / SL;
+  const size_t p = (size_t)blockIdx.x * SL + sl;
+  const size_t x = p / nz;
+  const int z = (int)(p - x * nz);
+  const size_t col = x * (size_t)ny * nz + z;
+  for (int y0 = yr; y0 < ny; y0 += YR * U) {
+    double a[U], t[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int y = y0 + u * YR;
+      const bool in = y < ny;
+      a[u] = in ? __builtin_nontemporal_load(a0 + col + (size_t)y * nz) : 0.0;
+      t[u] = in ? __builtin_nontemporal_load(ts + col + (size_t)y * nz) : 0.0;
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const bool red = a[u] < 0.0;
+      const double am = fmax(fabs(a[u]), 0.0);
+      const double w = (t[u] - s0) * inv_h;
+      double kf = floor(w);
+      kf = fmin(fmax(kf, 0.0), (double)(K - 1));
+      const double xi = 2.0 * (w - kf) - 1.0;
+      double* base = lds + (((red ? 0 : K) + (int)kf) * N) * SL + sl;
+      double tm = 1.0, tc = xi;
+      atomicAdd(base, am);
+      atomicAdd(base + SL, am * tc);
+      const double x2 = 2.0 * xi;
+#pragma unroll
+      for (int n = 2; n < N; ++n) {
+        const double tn = __builtin_fma(x2, tc, -tm);
+        tm = tc; tc = tn;
+        atomicAdd(base + n * SL, am * tn);
+      }
+    }
+  }
+  __syncthreads();
+  // flush, transposed: MT[idx][p]
+  for (int i = threadIdx.x; i < TOT; i += 256) {
+    const int idx = i / SL, s = i % SL;
+    MT[(size_t)idx * npix + (size_t)blockIdx.x * SL + s] = lds[i];
+  }
+}
+
+template <int ET>
+__global__ __launch_bounds__(256) void eval(const double* __restrict__ MT, size_t npix, int kn2,
+                                            const double* __restrict__ W, double* __restrict__ out) {
+  const size_t p = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (p >= npix) return;
+  double acc[ET];
+#pragma unroll
+  for (int e = 0; e < ET; ++e) acc[e] = 0.0;
+  for (int i = 0; i < kn2; ++i) {
+    const double m = MT[(size_t)i * npix + p];
+    const double* w = W + (size_t)i * ET;
+#pragma unroll
+    for (int e = 0; e < ET; ++e) acc[e] = __builtin_fma(m, w[e], acc[e]);
+  }
+#pragma unroll
+  for (int e = 0; e < ET; ++e) out[(size_t)e * npix + p] = acc[e];
+}
+
+template <int K, int N, int SL, int U>
+static void run(const double* a0, const double* ts, int nx, int ny, int nz, double* MT, double* W, double* out) {
+  const size_t npix = (size_t)nx * nz;
+  const size_t shm = (size_t)2 * K * N * SL * sizeof(double);
+  CK(hipFuncSetAttribute((const void*)moments<K, N, SL, U>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
+  hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  float best = 1e30f, best2 = 1e30f;
+  for (int rep = 0; rep < 4; ++rep) {
+    CK(hipEventRecord(e0));
+    hipLaunchKernelGGL((moments<K, N, SL, U>), dim3((unsigned)(npix / SL)), dim3(256), shm, 0, a0, ts, ny, nz, 0.0, K / 5.0, MT, npix);
+    CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1)); if (ms < best) best = ms;
+    CK(hipEventRecord(e0));
+    hipLaunchKernelGGL((eval<32>), dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, 0, MT, npix, 2 * K * N, W, out);
+    CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+    CK(hipEventElapsedTime(&ms, e0, e1)); if (ms < best2) best2 = ms;
+  }
+  CK(hipGetLastError());
+  const double gb = (double)nx * ny * nz * 16 / 1e9;
+  printf("K=%d N=%d SL=%d U=%d  LDS %zu KB: moments %.3f ms (%.0f GB/s of a0+ts)  eval(32 epochs) %.3f ms\n",
+         K, N, SL, U, shm / 1024, best, gb / best * 1e3, best2);
+}
+
+int main() {
+  const int nx = 512, ny = 4096, nz = 512;
+  const size_t n = (size_t)nx * ny * nz, npix = (size_t)nx * nz;
+  double *a0, *ts, *MT, *W, *out;
+  CK(hipMalloc(&a0, n * 8)); CK(hipMalloc(&ts, n * 8));
+  CK(hipMalloc(&MT, (size_t)2 * 32 * 20 * npix * 8));
+  CK(hipMalloc(&W, (size_t)2 * 32 * 20 * 32 * 8)); CK(hipMemset(W, 0, (size_t)2 * 32 * 20 * 32 * 8));
+  CK(hipMalloc(&out, 32 * npix * 8));
+  hipLaunchKernelGGL(fill, dim3(8192), dim3(256), 0, 0, a0, ts, n, nz);
+  CK(hipDeviceSynchronize());
+  run<32, 16, 16, 4>(a0, ts, nx, ny, nz, MT, W, out);
+  run<32, 16, 16, 8>(a0, ts, nx, ny, nz, MT, W, out);
+  run<32, 16, 8, 8>(a0, ts, nx, ny, nz, MT, W, out);
+  run<20, 20, 16, 8>(a0, ts, nx, ny, nz, MT, W, out);
+  run<32, 12, 16, 8>(a0, ts, nx, ny, nz, MT, W, out);
+  run<16, 16, 16, 8>(a0, ts, nx, ny, nz, MT, W, out);
+  // sanity: total of the zeroth moments == sum |a0|
+  std::vector<double> h(npix);
+  CK(hipMemcpy(h.data(), MT, npix * 8, hipMemcpyDeviceToHost));
+  printf("M[0][0][0][p=0] = %.6f\n", h[0]);
+  return 0;
+}
