@@ -1,5 +1,5 @@
 #!/bin/bash
-# Builds librjprt.so for gfx950 in-tree (rajepy_amd/librjprt.so) through csrc/Makefile (nine
+# Builds librjprt.so for gfx950 in-tree (rajepy_amd/librjprt.so) through csrc/Makefile (ten
 # translation units, compiled in parallel).  hipcc cross-compiles without a GPU.  Usage: build.sh [--report | --debug-switches]
 #   --report          prints per-kernel register use
 #   --debug-switches  builds rajepy_amd/librjprt_dbg.so with -DRJP_DEBUG_SWITCHES: the only build

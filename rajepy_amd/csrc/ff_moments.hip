@@ -20,8 +20,8 @@
 // Moment pass: launch times are uncorrelated along y in general (and in the synthetic set), so
 // a cell's (jet, bin) is random and the accumulators cannot live in registers: a workgroup owns
 // 16 z-adjacent sightlines over all y and keeps their 16 x 2 x 32 x 16 moments in LDS (128 KB),
-// updated with f64 LDS atomics (16 per cell -- they, not HBM, bound the pass: 6.8 ms at
-// 512x4096x512, tools/native/moments_probe.hip), then writes them transposed, M_T[idx][p].
+// updated with f64 LDS atomics (16 per cell -- they, not HBM, bound the pass: 5.2 ms at
+// 512x4096x512 with 1024 threads per workgroup, tools/native/moments_probe.hip), then writes them transposed, M_T[idx][p].
 // Sums of one sightline come from 16 threads in atomic order: results are reproducible to
 // rounding, not bit for bit (the tiles are).  Contraction: one lane per sightline, the W row
 // of each coefficient through scalar loads, 32 epochs per pass over M_T.
@@ -34,7 +34,10 @@
 namespace rjp {
 
 constexpr int kMomSL = 16;                 // sightlines per workgroup
-constexpr int kMomU = 8;                   // rows of loads in flight per thread
+constexpr int kMomBS = 1024;               // threads per workgroup: 16 sightlines x 64 y-rows (16
+                                           // waves per CU keep more atomics in flight: 5.2 ms
+                                           // against 6.8 with 256 threads, moments_probe.hip)
+constexpr int kMomU = 4;                   // rows of loads in flight per thread
 constexpr int kMomIdx = 2 * RJP_MOM_BINS * RJP_MOM_ORDER;
 
 struct MomDev {
@@ -42,7 +45,7 @@ struct MomDev {
   int has_bursts[2];
 };
 
-__global__ __launch_bounds__(256) void moments_kernel(const double* __restrict__ a0,
+__global__ __launch_bounds__(kMomBS) void moments_kernel(const double* __restrict__ a0,
                                                       const double* __restrict__ ts,
                                                       const int32_t* __restrict__ ylo,
                                                       const int32_t* __restrict__ yhi, int ny,
@@ -51,10 +54,10 @@ __global__ __launch_bounds__(256) void moments_kernel(const double* __restrict__
   constexpr int K = RJP_MOM_BINS, N = RJP_MOM_ORDER, SL = kMomSL, U = kMomU;
   extern __shared__ double s_mom[];        // [2][K][N][SL]
   constexpr int TOT = kMomIdx * SL;
-  for (int i = threadIdx.x; i < TOT; i += 256) s_mom[i] = 0.0;
+  for (int i = threadIdx.x; i < TOT; i += kMomBS) s_mom[i] = 0.0;
   __syncthreads();
   const int sl = threadIdx.x % SL, yr = threadIdx.x / SL;
-  constexpr int YR = 256 / SL;
+  constexpr int YR = kMomBS / SL;
   const int64_t p = (int64_t)blockIdx.x * SL + sl;
   if (p < npix) {
     const int64_t x = p / nz;
@@ -108,7 +111,7 @@ __global__ __launch_bounds__(256) void moments_kernel(const double* __restrict__
   }
   __syncthreads();
   // transposed flush: M_T[idx][p] (a full 128-byte segment per 16 lanes)
-  for (int i = threadIdx.x; i < TOT; i += 256) {
+  for (int i = threadIdx.x; i < TOT; i += kMomBS) {
     const int idx = i / SL, s = i % SL;
     MT[(int64_t)idx * npixp + (int64_t)blockIdx.x * SL + s] = s_mom[i];
   }
@@ -290,7 +293,7 @@ hipError_t moments_run(const rjp_fields* fl, const MomPlan& mp, const double* d_
   MomDev md;
   md.s0 = mp.s0; md.inv_h = mp.inv_h;
   md.has_bursts[0] = mp.has_bursts[0]; md.has_bursts[1] = mp.has_bursts[1];
-  hipLaunchKernelGGL(moments_kernel, dim3((unsigned)(npixp / kMomSL)), dim3(256), shm, st,
+  hipLaunchKernelGGL(moments_kernel, dim3((unsigned)(npixp / kMomSL)), dim3(kMomBS), shm, st,
                      (const double*)fl->d_a0, (const double*)fl->d_ts, fl->d_ylo, fl->d_yhi,
                      fl->ny, fl->nz, npix, npixp, md, ws);
   hipError_t err = hipGetLastError();

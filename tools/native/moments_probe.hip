@@ -26,16 +26,16 @@ __global__ void fill(double* a0, double* ts, size_t n, int nz) {
 }
 
 // SL sightlines per workgroup (z-adjacent), 256 threads: thread = (sightline, y-row offset)
-template <int K, int N, int SL, int U>
-__global__ __launch_bounds__(256) void moments(const double* __restrict__ a0, const double* __restrict__ ts,
+template <int K, int N, int SL, int U, int BS>
+__global__ __launch_bounds__(BS) void moments(const double* __restrict__ a0, const double* __restrict__ ts,
                                                int ny, int nz, double s0, double inv_h,
                                                double* __restrict__ MT, size_t npix) {
   extern __shared__ double lds[];          // [2][K][N][SL]
   constexpr int TOT = 2 * K * N * SL;
-  for (int i = threadIdx.x; i < TOT; i += 256) lds[i] = 0.0;
+  for (int i = threadIdx.x; i < TOT; i += BS) lds[i] = 0.0;
   __syncthreads();
   const int sl = threadIdx.x % SL, yr = threadIdx.x / SL;
-  constexpr int YR = 256 / SL;
+  constexpr int YR = BS / SL;
   const size_t p = (size_t)blockIdx.x * SL + sl;
   const size_t x = p / nz;
   const int z = (int)(p - x * nz);
@@ -72,7 +72,7 @@ __global__ __launch_bounds__(256) void moments(const double* __restrict__ a0, co
   }
   __syncthreads();
   // flush, transposed: MT[idx][p]
-  for (int i = threadIdx.x; i < TOT; i += 256) {
+  for (int i = threadIdx.x; i < TOT; i += BS) {
     const int idx = i / SL, s = i % SL;
     MT[(size_t)idx * npix + (size_t)blockIdx.x * SL + s] = lds[i];
   }
@@ -96,16 +96,16 @@ __global__ __launch_bounds__(256) void eval(const double* __restrict__ MT, size_
   for (int e = 0; e < ET; ++e) out[(size_t)e * npix + p] = acc[e];
 }
 
-template <int K, int N, int SL, int U>
+template <int K, int N, int SL, int U, int BS>
 static void run(const double* a0, const double* ts, int nx, int ny, int nz, double* MT, double* W, double* out) {
   const size_t npix = (size_t)nx * nz;
   const size_t shm = (size_t)2 * K * N * SL * sizeof(double);
-  CK(hipFuncSetAttribute((const void*)moments<K, N, SL, U>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
+  CK(hipFuncSetAttribute((const void*)moments<K, N, SL, U, BS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   float best = 1e30f, best2 = 1e30f;
   for (int rep = 0; rep < 4; ++rep) {
     CK(hipEventRecord(e0));
-    hipLaunchKernelGGL((moments<K, N, SL, U>), dim3((unsigned)(npix / SL)), dim3(256), shm, 0, a0, ts, ny, nz, 0.0, K / 5.0, MT, npix);
+    hipLaunchKernelGGL((moments<K, N, SL, U, BS>), dim3((unsigned)(npix / SL)), dim3(BS), shm, 0, a0, ts, ny, nz, 0.0, K / 5.0, MT, npix);
     CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
     float ms; CK(hipEventElapsedTime(&ms, e0, e1)); if (ms < best) best = ms;
     CK(hipEventRecord(e0));
@@ -115,7 +115,7 @@ static void run(const double* a0, const double* ts, int nx, int ny, int nz, doub
   }
   CK(hipGetLastError());
   const double gb = (double)nx * ny * nz * 16 / 1e9;
-  printf("K=%d N=%d SL=%d U=%d  LDS %zu KB: moments %.3f ms (%.0f GB/s of a0+ts)  eval(32 epochs) %.3f ms\n",
+  printf("BS=%d ", BS); printf("K=%d N=%d SL=%d U=%d  LDS %zu KB: moments %.3f ms (%.0f GB/s of a0+ts)  eval(32 epochs) %.3f ms\n",
          K, N, SL, U, shm / 1024, best, gb / best * 1e3, best2);
 }
 
@@ -129,12 +129,12 @@ int main() {
   CK(hipMalloc(&out, 32 * npix * 8));
   hipLaunchKernelGGL(fill, dim3(8192), dim3(256), 0, 0, a0, ts, n, nz);
   CK(hipDeviceSynchronize());
-  run<32, 16, 16, 4>(a0, ts, nx, ny, nz, MT, W, out);
-  run<32, 16, 16, 8>(a0, ts, nx, ny, nz, MT, W, out);
-  run<32, 16, 8, 8>(a0, ts, nx, ny, nz, MT, W, out);
-  run<20, 20, 16, 8>(a0, ts, nx, ny, nz, MT, W, out);
-  run<32, 12, 16, 8>(a0, ts, nx, ny, nz, MT, W, out);
-  run<16, 16, 16, 8>(a0, ts, nx, ny, nz, MT, W, out);
+  run<32, 16, 16, 8, 256>(a0, ts, nx, ny, nz, MT, W, out);
+  run<32, 16, 16, 8, 512>(a0, ts, nx, ny, nz, MT, W, out);
+  run<32, 16, 16, 4, 512>(a0, ts, nx, ny, nz, MT, W, out);
+  run<32, 16, 16, 4, 1024>(a0, ts, nx, ny, nz, MT, W, out);
+  run<32, 16, 16, 2, 1024>(a0, ts, nx, ny, nz, MT, W, out);
+  run<32, 16, 32, 4, 512>(a0, ts, nx, ny, nz, MT, W, out);
   // sanity: total of the zeroth moments == sum |a0|
   std::vector<double> h(npix);
   CK(hipMemcpy(h.data(), MT, npix * 8, hipMemcpyDeviceToHost));
