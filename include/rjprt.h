@@ -108,10 +108,18 @@ typedef struct rjp_fields {
    * moments of a0 over 32 launch-time bins and any number of epochs -- uniformly spaced or not --
    * becomes a small contraction.  The host checks the expansion against chi^2 for the call's
    * bursts and epochs and uses the path only when every coefficient table is good to 1e-11
-   * relative (else the epoch tiles run, as before); sums are reproducible to rounding, not bit
+   * relative AND a cost model says it is the faster one (long, densely filled sightlines; else
+   * the epoch tiles run, as before); sums are reproducible to rounding, not bit
    * for bit (LDS atomics).  A range that does not contain every finite launch time gives wrong
    * maps: pass what rjp_field_range returned for d_ts, or zeros. */
   double ts_lo, ts_hi;
+  /* Optional hint for the choice between the epoch tiles and the moment path: the number of
+   * cells inside the occupied y-ranges, sum_p max(0, d_yhi[p] - d_ylo[p]) (0 = unknown: all
+   * n_x n_y n_z cells are assumed to matter).  The tiles' cost scales with it, the moment
+   * path's per-sightline costs (8 KiB of moments written and read back) do not: a sparse jet
+   * keeps the tiles.  A negative value skips the cost model (tests: the moment path on grids it
+   * would not pay for). */
+  int64_t occupied_cells;
 } rjp_fields;
 
 /* Ejection bursts (classes.py:399-463): mdot(t)/mdot_ss = 1 + sum_b amp_rel_b *

@@ -39,7 +39,7 @@ class Fields(C.Structure):
                 ("dtype", C.c_int32), ("csize_au", C.c_double),
                 ("d_ylo", C.c_void_p), ("d_yhi", C.c_void_p), ("d_em0", C.c_void_p),
                 ("d_a0", C.c_void_p), ("a0_mode", C.c_int32), ("reserved_", C.c_int32),
-                ("ts_lo", C.c_double), ("ts_hi", C.c_double)]
+                ("ts_lo", C.c_double), ("ts_hi", C.c_double), ("occupied_cells", C.c_int64)]
 
 
 class Bursts(C.Structure):

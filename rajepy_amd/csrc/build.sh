@@ -26,7 +26,7 @@ txt = open(sys.argv[1]).read()
 rows = []
 cur = None
 for line in txt.splitlines():
-    m = re.search(r"remark: +(Function Name|VGPRs|AGPRs|TotalSGPRs|ScratchSize \[bytes/lane\]|Occupancy \[waves/SIMD\]|LDS Size \[bytes/block\]): (.*?) \[-R", line)
+    m = re.search(r"remark: +(Function Name|VGPRs|AGPRs|TotalSGPRs|ScratchSize \[bytes/lane\]|Occupancy \[waves/SIMD\]|LDS Size \[bytes/block\]|SGPRs Spill|VGPRs Spill): (.*?) \[-R", line)
     if not m: continue
     k, v = m.group(1), m.group(2)
     if k == "Function Name":
@@ -39,6 +39,9 @@ for r, n in zip(rows, names):
     n = re.sub(r"\(.*", "", n).replace("void rjp::", "")
     print("%-6s %-6s %-8s %-4s %-6s %s" % (r.get("VGPRs"), r.get("TotalSGPRs"), r.get("ScratchSize"), r.get("Occupancy"), r.get("LDS Size"), n))
 PY
+  # the hand-issued scalar table loads of the uniform-epoch tiles: nothing may read their
+  # destination SGPRs before the s_waitcnt that covers them (tools/check_sgpr_tables.py)
+  python3 "$here/../../tools/check_sgpr_tables.py"
 elif [[ "${1:-}" == "--debug-switches" ]]; then
   out="$here/../librjprt_dbg.so"
   make -s -C "$here" -j"$jobs" OUT="$out" OBJDIR="$here/../../build/rjprt_dbg" EXTRA="-DRJP_DEBUG_SWITCHES ${RJP_EXTRA:-}"

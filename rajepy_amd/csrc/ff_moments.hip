@@ -203,6 +203,24 @@ bool moments_plan(const rjp_fields* fl, const rjp_bursts* hb, const double* epoc
   if (work_bytes < moments_workspace_bytes((int64_t)fl->nx * fl->nz)) return false;
   for (int e = 0; e < n_epochs; ++e)
     if (!std::isfinite(epochs[e])) return false;
+  if (fl->occupied_cells >= 0) {
+    // Cost model (seconds on one MI355X, from the cfg5-size measurements of round 3): the tiles
+    // pay per (cell, epoch) pair -- 0.40 ps in the uniform-epoch recurrence, 0.93 ps when every
+    // epoch is evaluated directly -- on the cells inside the occupied y-ranges; the moment path
+    // pays 4.9 ps per such cell once, plus per SIGHTLINE 8 KiB of moments written and read
+    // back (3.3 ns) and 1.1 ns per contraction pass of 32 epochs.  Short or sparsely filled
+    // sightlines keep the tiles.
+    const double npix = (double)fl->nx * fl->nz;
+    const double cells = fl->occupied_cells > 0 ? (double)fl->occupied_cells : npix * fl->ny;
+    bool uniform = n_epochs >= 4;
+    const double dt = n_epochs > 1 ? (epochs[n_epochs - 1] - epochs[0]) / (n_epochs - 1) : 0.0;
+    for (int e = 0; e < n_epochs && uniform; ++e)
+      uniform = std::fabs(epochs[e] - (epochs[0] + e * dt)) <= 1e-9 * std::fabs(dt);
+    const double t_tiles = cells * n_epochs * (uniform ? 0.40e-12 : 0.93e-12);
+    const double t_mom = cells * 4.9e-12 +
+                         npix * (3.3e-9 + 1.1e-9 * ((n_epochs + RJP_MOM_TILE - 1) / RJP_MOM_TILE));
+    if (!(t_mom < 0.8 * t_tiles)) return false;
+  }
   // same request as last time?
   if (mp.key_E == n_epochs && mp.key_lo == fl->ts_lo && mp.key_hi == fl->ts_hi &&
       mp.key_epochs.size() == (size_t)n_epochs &&

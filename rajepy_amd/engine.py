@@ -33,6 +33,7 @@ class DeviceFields:
         self.em0 = None                     # optional compact scan field (rjp_fields.d_em0)
         self.a0 = None                      # optional tau scan field (rjp_fields.d_a0) ...
         self.a0_mode = 0                    # ... and the Gaunt mode it was built for
+        self.occupied_cells = 0             # cells inside the occupied y-ranges (0 = unknown)
         self.ts_range = None                # optional (ts_lo, ts_hi) of the finite launch times
         self._ts_range_of = None            # ... and the `ts` tensor it was measured on
 
@@ -61,6 +62,7 @@ class DeviceFields:
         f.csize_au = self.csize_au
         f.d_ylo = self.ylo.data_ptr() if self.ylo is not None else None
         f.d_yhi = self.yhi.data_ptr() if self.yhi is not None else None
+        f.occupied_cells = int(self.occupied_cells) if self.ylo is not None else 0
         return f
 
     def scan_fields(self, gff_mode, want_em=True):
@@ -134,6 +136,7 @@ class RTEngine:
         self.use_tau = not (_lib.DEBUG and os.environ.get("RJP_NO_TAU"))
         # epoch sweeps by launch-time moments (rjp_fields.ts_lo / ts_hi): off = the epoch tiles
         self.use_moments = not (_lib.DEBUG and os.environ.get("RJP_NO_MOMENTS"))
+        self.force_moments = False     # tests: skip the library's tiles-or-moments cost model
 
     def close(self):
         if getattr(self, "ctx", None):
@@ -274,12 +277,15 @@ class RTEngine:
         skip the rows no cell of which can contribute.  Recompute after changing a field."""
         torch = _torch()
         fields.ylo = fields.yhi = None
+        fields.occupied_cells = 0
         lo = torch.empty(fields.npix, dtype=torch.int32, device=self.device)
         hi = torch.empty(fields.npix, dtype=torch.int32, device=self.device)
         fs = fields.struct()
         _lib.check(self.lib.rjp_y_bounds(self.ctx, C.byref(fs), lo.data_ptr(), hi.data_ptr(),
                                          self._stream()), self.ctx, "rjp_y_bounds")
         fields.ylo, fields.yhi = lo, hi
+        # (hint for the tiles-or-moments choice of long epoch sweeps, include/rjprt.h)
+        fields.occupied_cells = int((hi - lo).clamp_(min=0).sum(dtype=torch.int64).item())
         return lo, hi
 
     def replace_field(self, fields, name, host_array):
@@ -402,6 +408,8 @@ class RTEngine:
         fs = fields.struct()
         if not self.use_moments:
             fs.ts_lo = fs.ts_hi = 0.0
+        elif self.force_moments:
+            fs.occupied_cells = -1
         if bursts is None or fields.ts is None:
             return fs
         n_r, n_b = int(bursts.n[0]), int(bursts.n[1])

@@ -21,8 +21,12 @@ RTOL = 5e-11          # 1e-11 expansion + the tiles' own 1e-11 + summation order
 
 @pytest.fixture(scope="module")
 def eng():
+    """`force_moments`: the library's cost model would keep the epoch tiles on grids this small
+    (the moment path pays 8 KiB per sightline, so it wins on long, densely filled sightlines:
+    cfg5); the last test checks the model's own decisions."""
     from rajepy_amd.engine import RTEngine
     e = RTEngine(0)
+    e.force_moments = True
     yield e
     e.close()
 
@@ -53,11 +57,11 @@ def _both(eng, f, bursts, ep, mode, **kw):
 
 @pytest.mark.parametrize("temp_mode", [0, 1])
 @pytest.mark.parametrize("years", [list(np.linspace(0., 5., 32)), list(np.linspace(0.3, 4.1, 12)),
-                                   list(np.linspace(0., 5., 37)),
+                                   list(np.linspace(0., 5., 37)), list(np.linspace(0., 5., 100)),
                                    sorted([0.0, 0.11, 0.5, 0.52, 0.9, 1.0, 1.3, 1.31, 1.9, 2.2, 2.25,
                                            2.8, 3.3, 3.9, 4.4, 4.95, 5.0])])
 def test_moments_agree_with_the_epoch_tiles_and_the_oracle(eng, temp_mode, years):
-    """Uniform sweeps of 32 / 12 / 37 epochs (one and two contraction passes) and an irregular
+    """Uniform sweeps of 32 / 12 / 37 / 100 epochs (one to four contraction passes) and an irregular
     list of 17 (which the tiles evaluate directly, 8 epochs at a time): the moment path is
     taken, agrees with the tiles at 5e-11 and with the oracle's chained closures at 1e-10."""
     from rajepy_amd import engine as E
@@ -152,10 +156,10 @@ def test_sweeps_the_expansion_cannot_serve_run_the_tiles(eng):
     assert eng.last_scan_path()[0] == "tiles"
 
 
-def test_jetmodel_light_curves_take_the_moment_path(eng, tmp_path):
-    """JetModel.flux_vs_time on the example jet (K4-built fields, occupied y-ranges): 40 epochs
-    go through the moment path and reproduce the light curve of the reference's anchors
-    (total flux at 5 GHz at t = 0 / 0.5 / 1 / 2 / 3 yr)."""
+def test_jetmodel_light_curves_through_the_moment_path(eng, tmp_path):
+    """JetModel.flux_vs_time on the example jet (K4-built fields, occupied y-ranges): 38 epochs
+    through the (forced) moment path reproduce the light curve of the reference's anchors
+    (total flux at 5 GHz at t = 0 / 0.5 / 1 / 2 / 3 yr) and the tiles'."""
     from rajepy_amd import classes, logger
     from tests.test_host_logic import example_params
     jm = classes.JetModel(example_params(), log=logger.Log(str(tmp_path / "a.log"), verbose=False),
@@ -174,3 +178,27 @@ def test_jetmodel_light_curves_take_the_moment_path(eng, tmp_path):
     lc2 = jm2.flux_vs_time(times, [5e9])[:, 0]
     eng.use_moments = True
     np.testing.assert_allclose(lc, lc2, rtol=RTOL)
+
+
+def test_cost_model_keeps_the_tiles_where_moments_do_not_pay(eng, tmp_path):
+    """The library's own decision (no `force_moments`): the example jet -- 400 rows, 0.4 % of the
+    grid occupied -- keeps the tiles for a 38-epoch light curve; a dense 2000-row grid takes the
+    moment path for 32 uniformly spaced epochs and for 17 irregular ones, not for 12 uniform ones
+    (the recurrence tiles are cheaper there)."""
+    from rajepy_amd import classes, engine as E, logger
+    from tests.test_host_logic import example_params
+    eng.force_moments = False
+    try:
+        jm = classes.JetModel(example_params(), log=logger.Log(str(tmp_path / "a.log"), verbose=False),
+                              engine=eng)
+        jm.flux_vs_time(np.linspace(0., 3., 38) * orc.YEAR, [5e9])
+        assert eng.last_scan_path()[0] == "tiles"
+        f = eng.synth_fields((2, 2000, 32), 11, 0, 8, csize_au=0.5, tau_mode=E.RJP_GFF_SCALAR)
+        bursts = E.make_bursts([(1.0 * orc.YEAR, 4., 0.2 * orc.YEAR)], [(2.0 * orc.YEAR, 2., 0.3 * orc.YEAR)])
+        for years, want in ((np.linspace(0., 5., 32), "moments"), (np.linspace(0., 5., 12), "tiles"),
+                            (np.sort(np.random.default_rng(1).uniform(0., 5., 17)), "moments")):
+            eng.ff_scan(f, bursts, [y * orc.YEAR for y in years], E.RJP_GFF_SCALAR, want_em=False,
+                        want_tavg=False)
+            assert eng.last_scan_path()[0] == want, (len(years), want)
+    finally:
+        eng.force_moments = True

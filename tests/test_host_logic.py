@@ -54,7 +54,7 @@ def test_abi_exports_every_declared_symbol():
 
 
 def test_abi_struct_layouts_match_header():
-    assert ctypes.sizeof(_lib.Fields) == 6 * 8 + 4 * 4 + 8 + 3 * 8 + 8 + 2 * 4 + 2 * 8
+    assert ctypes.sizeof(_lib.Fields) == 6 * 8 + 4 * 4 + 8 + 3 * 8 + 8 + 2 * 4 + 2 * 8 + 8
     assert _lib.Fields.ts_lo.offset == _lib.Fields.d_a0.offset + 16       # appended again (105)
     assert _lib.Fields.d_a0.offset == 6 * 8 + 4 * 4 + 8 + 3 * 8      # appended: ABI 103 prefix kept
     assert _lib.Fields.a0_mode.offset == _lib.Fields.d_a0.offset + 8
@@ -435,3 +435,31 @@ def test_reynolds86_analytic_fluxes_match_the_reference(tmp_path):
         mphys.flux_expected_r86(tj, 5e9, "B", 1.0)
     with pytest.raises(KeyError, match="mlr"):
         mphys.approx_flux_expected_r86(tj, 5e9, "B")
+
+
+def test_sgpr_table_load_checker_sees_a_reader_before_the_wait():
+    """tools/check_sgpr_tables.py (run by `build.sh --report`): a copy or spill of the registers
+    an in-flight s_load_dwordx16 will fill, before the s_waitcnt that covers it, is reported."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location(
+        "check_sgpr_tables", os.path.join(ROOT, "tools", "check_sgpr_tables.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    good = """_ZN3rjp4kernE:
+	s_load_dwordx16 s[36:51], s[2:3], 0x0
+	v_fma_f64 v[0:1], v[2:3], v[4:5], v[6:7]
+	v_writelane_b32 v9, s60, 3
+	s_waitcnt lgkmcnt(0)
+	v_fma_f64 v[0:1], v[2:3], s[36:37], v[6:7]
+	s_endpgm
+"""
+    bad, n = mod.check(good, "t")
+    assert n == 1 and bad == []
+    for culprit in ("v_writelane_b32 v9, s40, 3", "s_mov_b64 s[70:71], s[50:51]",
+                    "v_fma_f64 v[0:1], v[2:3], s[36:37], v[6:7]"):
+        text = good.replace("	v_writelane_b32 v9, s60, 3", "	" + culprit)
+        bad, _ = mod.check(text, "t")
+        assert len(bad) == 1 and bad[0][3] == culprit, (culprit, bad)
+    # a wait for another counter does not count
+    text = good.replace("s_waitcnt lgkmcnt(0)", "s_waitcnt vmcnt(0)\n	v_writelane_b32 v9, s41, 1\n	s_waitcnt lgkmcnt(0)")
+    assert len(mod.check(text, "t")[0]) == 1
