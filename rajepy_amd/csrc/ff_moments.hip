@@ -301,12 +301,16 @@ hipError_t moments_run(const rjp_fields* fl, const MomPlan& mp, const double* d_
   const int64_t npix = (int64_t)fl->nx * fl->nz;
   const int64_t npixp = (npix + kMomSL - 1) / kMomSL * kMomSL;
   const size_t shm = (size_t)kMomIdx * kMomSL * sizeof(double);
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)moments_kernel,
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+  // (128 KB of dynamic LDS must be allowed explicitly, once per device of the process)
+  static int attr_dev = -1;
+  int dev = -1;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return e;
+  if (dev != attr_dev) {
+    e = hipFuncSetAttribute((const void*)moments_kernel,
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
     if (e != hipSuccess) return e;
-    attr_set = true;
+    attr_dev = dev;
   }
   MomDev md;
   md.s0 = mp.s0; md.inv_h = mp.inv_h;

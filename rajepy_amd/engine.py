@@ -303,6 +303,11 @@ class RTEngine:
                                            self._stream()), self.ctx, "rjp_pack_field")
         self.synchronize()
         setattr(fields, name, dst)
+        if name == "ts":
+            # what was measured on / derived from the old launch times (the new tensor may well
+            # sit at the old one's address: never key these on the pointer alone)
+            fields.ts_range = fields._ts_range_of = None
+            fields._ts_unmasked = None
         had_tau = fields.a0 is not None
         if name == "xi" and fields.em0 is not None:
             self.compact(fields)                # em0 holds (nd xi)^2 pf

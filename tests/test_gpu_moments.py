@@ -202,3 +202,28 @@ def test_cost_model_keeps_the_tiles_where_moments_do_not_pay(eng, tmp_path):
             assert eng.last_scan_path()[0] == want, (len(years), want)
     finally:
         eng.force_moments = True
+
+
+def test_replacing_the_launch_times_remeasures_their_range(eng):
+    """The `ts` setter path (engine.replace_field): launch times stretched to twice their range --
+    the moment path must bin them over the NEW range (a stale range would clamp half of the
+    cells into the last bin); against the tiles on the same fields."""
+    from rajepy_amd import engine as E
+    shape = (4, 120, 32)
+    ej = {"t_0": np.array([1.0, 3.0]), "hl": np.array([0.8, 1.0]), "chi": np.array([5., 3.]),
+          "which": np.array(["RB", "RB"])}
+    g, p, jet = _jet(shape, 321, ejection=ej)
+    f = eng.upload_fields(g["nd"], g["xi"], g["temp"], g["ff"], g["areas"], g["ts"],
+                          g["rr"] < 0, csize_au=jet.csize, dtype=8)
+    eng.tau_layout(f, E.RJP_GFF_SCALAR)
+    bursts = U.bursts_from_oracle(jet)
+    ep = [y * orc.YEAR for y in np.linspace(0., 8., 24)]
+    mom, til, (path, _) = _both(eng, f, bursts, ep, E.RJP_GFF_SCALAR)
+    assert path == "moments"
+    np.testing.assert_allclose(mom, til, rtol=RTOL)
+    lo0, hi0 = f.ts_range
+    eng.replace_field(f, "ts", 2.0 * g["ts"])
+    mom2, til2, (path2, _) = _both(eng, f, bursts, ep, E.RJP_GFF_SCALAR)
+    assert path2 == "moments" and f.ts_range == (2.0 * lo0, 2.0 * hi0)
+    np.testing.assert_allclose(mom2, til2, rtol=RTOL)
+    assert not np.allclose(mom2, mom, rtol=1e-3)
