@@ -755,11 +755,14 @@ def main(argv=None):
         if scan_path == "moments":
             roof_extra["moments"] = {
                 "what": "sum_y a0 chi(t_e - ts)^2 as a convolution over launch time: one pass "
-                        "accumulates 2 x 32 x 16 Chebyshev moments of a0 per sightline (LDS "
-                        "atomics: they, not HBM, bound it), every epoch is a contraction with "
-                        "host-built coefficient tables",
+                        "accumulates 2 jets x K bins x N Chebyshev moments of a0 per sightline "
+                        "(LDS atomics: they, not HBM, bound it), every epoch is a contraction "
+                        "with host-built coefficient tables; the host picks the cheapest "
+                        "(K, N) shape that passes its accuracy check",
+                "shape_bins_order": list(eng.last_moment_shape),
                 "worst_rel_err_of_the_expansion": mom_err,
-                "moment_maps_bytes": 2 * 32 * 16 * P * 8}
+                "moment_maps_bytes": 2 * eng.last_moment_shape[0] * eng.last_moment_shape[1]
+                                     * P * 8}
         if n_ep_cfg:
             # 8(d) prices one grid pass PER EPOCH; the fused tiles make `npass` passes serve
             # E_loc epochs -- both figures, as 8(d) asks

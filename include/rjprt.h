@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define RJP_VERSION 105          /* 0.1.5 */
+#define RJP_VERSION 106          /* 0.1.6 */
 #define RJP_RANGE_BLOCKS 2048    /* partial (min, max) pairs rjp_field_range writes */
 #define RJP_MAX_EPOCH_TILE 32    /* most epochs evaluated per grid pass: 32 uniformly spaced ones (with or without d_em), 16 when only 16-31 are left, else tiles of 8, 4, 2, 1 */
 
@@ -227,9 +227,10 @@ int rjp_ff_scan(rjp_ctx* ctx, const rjp_fields* fields, const rjp_bursts* bursts
                 void* d_work, size_t work_bytes, void* stream);
 
 /* Which path the last rjp_ff_scan of this context took: 0 = epoch tiles, 1 = launch-time moments
- * (and, in *worst_rel_err if non-NULL, the worst relative error of the moment expansion the
- * host measured for that call; 0 for the tiles).  For tests and the bench line. */
-int rjp_last_scan_path(const rjp_ctx* ctx, double* worst_rel_err);
+ * (and, if non-NULL: in *worst_rel_err the worst relative error of the moment expansion the
+ * host measured for that call, in moment_shape[0..1] the (bins, order) shape it chose; zeros
+ * for the tiles).  For tests and the bench line. */
+int rjp_last_scan_path(const rjp_ctx* ctx, double* worst_rel_err, int32_t* moment_shape);
 
 /* ---- K2: per-channel map stage --------------------------------------------------------
  * Replaces the map-level arithmetic of optical_depth_ff / intensity_ff / flux_ff

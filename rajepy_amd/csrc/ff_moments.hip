@@ -19,13 +19,21 @@
 //
 // Moment pass: launch times are uncorrelated along y in general (and in the synthetic set), so
 // a cell's (jet, bin) is random and the accumulators cannot live in registers: a workgroup owns
-// 16 z-adjacent sightlines over all y and keeps their 16 x 2 x 32 x 16 moments in LDS (128 KB),
-// updated with f64 LDS atomics (16 per cell -- they, not HBM, bound the pass: 5.2 ms at
-// 512x4096x512 with 1024 threads per workgroup, tools/native/moments_probe.hip), then writes them transposed, M_T[idx][p].
-// Sums of one sightline come from 16 threads in atomic order: results are reproducible to
-// rounding, not bit for bit (the tiles are).  Contraction: one lane per sightline, the W row
-// of each coefficient through scalar loads, 32 epochs per pass over M_T.
+// 16 z-adjacent sightlines over all y and keeps their 16 x 2 x K x N moments in LDS (up to
+// 159 KB), updated with f64 LDS atomics -- N per cell, ~8 LDS cycles per wave-instruction
+// (profiles/r03b_cfg5_moments_sq.json: the LDS is busy 72 % of the pass, HBM is not the
+// bound) -- then writes them transposed, M_T[idx][p].  The (K, N) shapes trade bins for order
+// inside the LDS budget 2 K N <= 1280: the host takes the CHEAPEST shape (fewest atomics per
+// cell) whose expansion passes the accuracy check -- (80, 8), (53, 12), (39, 16); at
+// 512x4096x512: 3.9 / 4.1 / 5.0 ms (tools/native/moments_probe.hip).  The next rows of a
+// thread are fetched (unconditionally, row index clamped) while the atomics of the current
+// ones drain: two register sets in ping-pong, counted vmcnt waits.
+// Sums of one sightline come from 64 threads in atomic order: results are reproducible to
+// rounding, not bit for bit (the tiles are).  Contraction: one lane per sightline, four moment
+// rows in flight, the W row of each coefficient through scalar loads, 32 epochs per pass over
+// M_T.
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -37,77 +45,93 @@ constexpr int kMomSL = 16;                 // sightlines per workgroup
 constexpr int kMomBS = 1024;               // threads per workgroup: 16 sightlines x 64 y-rows (16
                                            // waves per CU keep more atomics in flight: 5.2 ms
                                            // against 6.8 with 256 threads, moments_probe.hip)
-constexpr int kMomU = 4;                   // rows of loads in flight per thread
-constexpr int kMomIdx = 2 * RJP_MOM_BINS * RJP_MOM_ORDER;
+constexpr int kMomU = 4;                   // rows per register set (two sets in ping-pong)
+// (K bins, N moments) shapes, cheapest first; 2 K N <= RJP_MOM_MAX_IDX, a multiple of 4
+struct MomShape { int K, N; };
+constexpr MomShape kMomShapes[] = {{80, 8}, {53, 12}, {39, 16}};
+constexpr int kMomNShapes = sizeof(kMomShapes) / sizeof(kMomShapes[0]);
 
 struct MomDev {
   double s0, inv_h;
   int has_bursts[2];
 };
 
+template <int K, int N>
 __global__ __launch_bounds__(kMomBS) void moments_kernel(const double* __restrict__ a0,
                                                       const double* __restrict__ ts,
                                                       const int32_t* __restrict__ ylo,
                                                       const int32_t* __restrict__ yhi, int ny,
                                                       int nz, int64_t npix, int64_t npixp,
                                                       MomDev md, double* __restrict__ MT) {
-  constexpr int K = RJP_MOM_BINS, N = RJP_MOM_ORDER, SL = kMomSL, U = kMomU;
+  constexpr int SL = kMomSL, U = kMomU;
+  static_assert(2 * K * N <= RJP_MOM_MAX_IDX && (2 * K * N) % 4 == 0, "shape outside the budget");
   extern __shared__ double s_mom[];        // [2][K][N][SL]
-  constexpr int TOT = kMomIdx * SL;
+  constexpr int TOT = 2 * K * N * SL;
   for (int i = threadIdx.x; i < TOT; i += kMomBS) s_mom[i] = 0.0;
   __syncthreads();
   const int sl = threadIdx.x % SL, yr = threadIdx.x / SL;
   constexpr int YR = kMomBS / SL;
   const int64_t p = (int64_t)blockIdx.x * SL + sl;
-  if (p < npix) {
-    const int64_t x = p / nz;
-    const int z = (int)(p - x * nz);
-    const int64_t col = x * (int64_t)ny * nz + z;
-    const int ya = ylo ? ylo[p] : 0, yb = ylo ? yhi[p] : ny;
-    for (int y0 = ya + yr; y0 < yb; y0 += YR * U) {
-      double a[U], t[U];
+  const bool live = p < npix;
+  const int64_t x = live ? p / nz : 0;
+  const int z = live ? (int)(p - x * nz) : 0;
+  const int64_t col = x * (int64_t)ny * nz + z;
+  const int ya = !live ? 0 : ylo ? ylo[p] : 0;
+  const int yb = !live ? 0 : ylo ? yhi[p] : ny;
+
+  // unconditional loads (row index clamped into the grid, the weight is zeroed at use time):
+  // no branch around a load, so the waits are counted and the next rows stay in flight
+  auto fetch = [&](double (&aa)[U], double (&tt)[U], int ybase) __attribute__((always_inline)) {
 #pragma unroll
-      for (int u = 0; u < U; ++u) {
-        const int y = y0 + u * YR;
-        const bool in = y < yb;
-        a[u] = in ? __builtin_nontemporal_load(a0 + col + (int64_t)y * nz) : 0.0;
-        t[u] = in ? __builtin_nontemporal_load(ts + col + (int64_t)y * nz) : 0.0;
-      }
+    for (int u = 0; u < U; ++u) {
+      const int y = ybase + u * YR;
+      const int64_t o = col + (int64_t)(y < ny ? y : ny - 1) * nz;
+      aa[u] = __builtin_nontemporal_load(a0 + o);
+      tt[u] = __builtin_nontemporal_load(ts + o);
+    }
+  };
+  auto cell = [&](double av, double tv) __attribute__((always_inline)) {
+    const bool red = signbit_d(av);
+    double am = __builtin_fmax(__builtin_fabs(av), 0.0);              // nansum: NaN -> 0
+    if (!(tv == tv)) {
+      // a NaN launch time drops the cell -- unless its jet has no burst: F == 1 there,
+      // whatever the bin (classes.py:232-233, 442-448)
+      if (md.has_bursts[red ? 0 : 1]) am = 0.0;
+      tv = md.s0;
+    }
+    if (am != 0.0) {
+      const double w = (tv - md.s0) * md.inv_h;
+      const double kf = __builtin_fmin(__builtin_fmax(__builtin_floor(w), 0.0), (double)(K - 1));
+      const double xi = __builtin_fma(2.0, w - kf, -1.0);
+      double* base = s_mom + (((red ? 0 : K) + (int)kf) * N) * SL + sl;
+      double tm = 1.0, tc = xi;
+      atomicAdd(base, am);
+      // (an infinite term -- T = 0 makes T^-1.5 infinite, and the reference's sum with it --
+      // goes into the zeroth moment only: its coefficient is the bin average of chi^2 > 0,
+      // so the sightline comes out +inf as in the tiles, not inf * T_n(xi) = NaN)
+      if (am <= 1.7976931348623157e308) {
+        atomicAdd(base + SL, am * tc);
+        const double x2 = 2.0 * xi;
 #pragma unroll
-      for (int u = 0; u < U; ++u) {
-        const bool red = signbit_d(a[u]);
-        double am = __builtin_fmax(__builtin_fabs(a[u]), 0.0);          // nansum: NaN -> 0
-        double tv = t[u];
-        if (!(tv == tv)) {
-          // a NaN launch time drops the cell -- unless its jet has no burst: F == 1 there,
-          // whatever the bin (classes.py:232-233, 442-448)
-          if (md.has_bursts[red ? 0 : 1]) am = 0.0;
-          tv = md.s0;
-        }
-        if (am != 0.0) {
-          const double w = (tv - md.s0) * md.inv_h;
-          const double kf = __builtin_fmin(__builtin_fmax(__builtin_floor(w), 0.0), (double)(K - 1));
-          const double xi = __builtin_fma(2.0, w - kf, -1.0);
-          double* base = s_mom + (((red ? 0 : K) + (int)kf) * N) * SL + sl;
-          double tm = 1.0, tc = xi;
-          atomicAdd(base, am);
-          // (an infinite term -- T = 0 makes T^-1.5 infinite, and the reference's sum with it --
-          // goes into the zeroth moment only: its coefficient is the bin average of chi^2 > 0,
-          // so the sightline comes out +inf as in the tiles, not inf * T_n(xi) = NaN)
-          if (am <= 1.7976931348623157e308) {
-            atomicAdd(base + SL, am * tc);
-            const double x2 = 2.0 * xi;
-#pragma unroll
-            for (int n = 2; n < N; ++n) {
-              const double tn = __builtin_fma(x2, tc, -tm);
-              tm = tc;
-              tc = tn;
-              atomicAdd(base + n * SL, am * tn);
-            }
-          }
+        for (int n = 2; n < N; ++n) {
+          const double tn = __builtin_fma(x2, tc, -tm);
+          tm = tc;
+          tc = tn;
+          atomicAdd(base + n * SL, am * tn);
         }
       }
     }
+  };
+
+  double a[U], t[U], an[U], tn[U];
+  fetch(a, t, ya + yr);
+  for (int y0 = ya + yr; y0 < yb; y0 += 2 * YR * U) {        // ping-pong: no register copies
+    fetch(an, tn, y0 + YR * U);
+#pragma unroll
+    for (int u = 0; u < U; ++u) cell(y0 + u * YR < yb ? a[u] : 0.0, t[u]);
+    fetch(a, t, y0 + 2 * YR * U);
+#pragma unroll
+    for (int u = 0; u < U; ++u) cell(y0 + (U + u) * YR < yb ? an[u] : 0.0, tn[u]);
   }
   __syncthreads();
   // transposed flush: M_T[idx][p] (a full 128-byte segment per 16 lanes)
@@ -117,22 +141,28 @@ __global__ __launch_bounds__(kMomBS) void moments_kernel(const double* __restric
   }
 }
 
-// sumA[e][p] = sum_idx M_T[idx][p] * W[idx][e], e < ne <= 32
+// sumA[e][p] = sum_idx M_T[idx][p] * W[idx][e], e < ne <= 32; four moment rows in flight per
+// lane (one at a time left the loop latency-bound: 0.66 -> 0.47 ms at 512x512 sightlines x 1024)
 __global__ __launch_bounds__(256) void moments_eval_kernel(const double* __restrict__ MT,
-                                                           int64_t npix, int64_t npixp,
+                                                           int64_t npix, int64_t npixp, int nidx,
                                                            const double* __restrict__ W, int ne,
                                                            double* __restrict__ sumA) {
-  constexpr int ET = RJP_MOM_TILE;
+  constexpr int ET = RJP_MOM_TILE, UI = 4;
   const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (p >= npix) return;
   double acc[ET];
 #pragma unroll
   for (int e = 0; e < ET; ++e) acc[e] = 0.0;
-  for (int i = 0; i < kMomIdx; ++i) {
-    const double m = MT[(int64_t)i * npixp + p];
-    const double* w = W + (size_t)i * ET;          // wave-uniform: scalar loads
+  for (int i0 = 0; i0 < nidx; i0 += UI) {
+    double m[UI];
 #pragma unroll
-    for (int e = 0; e < ET; ++e) acc[e] = __builtin_fma(m, w[e], acc[e]);
+    for (int j = 0; j < UI; ++j) m[j] = MT[(int64_t)(i0 + j) * npixp + p];
+#pragma unroll
+    for (int j = 0; j < UI; ++j) {
+      const double* w = W + (size_t)(i0 + j) * ET;          // wave-uniform: scalar loads
+#pragma unroll
+      for (int e = 0; e < ET; ++e) acc[e] = __builtin_fma(m[j], w[e], acc[e]);
+    }
   }
 #pragma unroll
   for (int e = 0; e < ET; ++e)
@@ -186,13 +216,67 @@ static double burst_F(const rjp_bursts* hb, int jet, double tl) {
 
 size_t moments_workspace_bytes(int64_t npix) {
   const int64_t npixp = (npix + kMomSL - 1) / kMomSL * kMomSL;
-  return (size_t)kMomIdx * (size_t)npixp * sizeof(double) + 256;
+  return (size_t)RJP_MOM_MAX_IDX * (size_t)npixp * sizeof(double) + 256;
 }
 
-// Can this scan take the moment path, and if so: its W tables.  `mp.W` = [chunk][idx][32].
+// W tables of one shape; false as soon as one (jet, bin, epoch) misses the tolerance
+static bool moments_tables(const rjp_bursts* hb, const double* epochs, int n_epochs, int K, int N,
+                           MomPlan& mp) {
+  constexpr int ET = RJP_MOM_TILE, NMAX = 16;
+  const int nidx = 2 * K * N;
+  const double span = mp.key_hi - mp.key_lo;
+  const double h = span > 0.0 ? span / K : 1.0;
+  mp.s0 = mp.key_lo;
+  mp.inv_h = 1.0 / h;
+  mp.K = K; mp.N = N;
+  mp.nchunk = (n_epochs + ET - 1) / ET;
+  mp.W.assign((size_t)mp.nchunk * nidx * ET, 0.0);
+  // Chebyshev nodes and the DCT matrix
+  const double pi = 3.14159265358979323846;
+  double xn[NMAX], cs[NMAX][NMAX];
+  for (int i = 0; i < N; ++i) {
+    xn[i] = std::cos(pi * (i + 0.5) / N);
+    for (int n = 0; n < N; ++n) cs[n][i] = std::cos(pi * n * (i + 0.5) / N);
+  }
+  const int NT = 2 * N + 1;                           // test points of the accuracy check
+  double worst = 0.0;
+  for (int e = 0; e < n_epochs; ++e) {
+    const int c = e / ET, el = e % ET;
+    double* Wc = mp.W.data() + (size_t)c * nidx * ET;
+    for (int j = 0; j < 2; ++j)
+      for (int k = 0; k < K; ++k) {
+        double* col = Wc + (size_t)((j * K + k) * N) * ET + el;      // stride ET between n
+        if (hb->n[j] <= 0) { col[0] = 1.0; continue; }             // F == 1
+        const double ck = mp.s0 + (k + 0.5) * h;
+        double f[NMAX], cf[NMAX];
+        for (int i = 0; i < N; ++i) f[i] = burst_F(hb, j, epochs[e] - (ck + 0.5 * h * xn[i]));
+        for (int n = 0; n < N; ++n) {
+          double s = 0.0;
+          for (int i = 0; i < N; ++i) s += f[i] * cs[n][i];
+          cf[n] = s * (n == 0 ? 1.0 : 2.0) / N;
+          col[(size_t)n * ET] = cf[n];
+        }
+        // accuracy: the interpolant against F on a finer grid (Clenshaw)
+        for (int m = 0; m < NT; ++m) {
+          const double xv = -1.0 + 2.0 * m / (NT - 1);
+          double b1 = 0.0, b2 = 0.0;
+          for (int n = N - 1; n >= 1; --n) { const double b0 = 2.0 * xv * b1 - b2 + cf[n]; b2 = b1; b1 = b0; }
+          const double val = xv * b1 - b2 + cf[0];
+          const double ref = burst_F(hb, j, epochs[e] - (ck + 0.5 * h * xv));
+          const double err = std::fabs(val - ref) / ref;           // F >= ... > 0 (chi > 0)
+          if (!(err <= worst)) worst = err;
+        }
+        if (!(worst <= RJP_MOM_TOL)) { mp.worst = worst; return false; }
+      }
+  }
+  mp.worst = worst;
+  return true;
+}
+
+// Can this scan take the moment path, and if so: its shape and W tables.
+// `mp.W` = [chunk][2 K N][32].
 bool moments_plan(const rjp_fields* fl, const rjp_bursts* hb, const double* epochs, int n_epochs,
                   int mode, bool want_em, size_t work_bytes, MomPlan& mp) {
-  constexpr int K = RJP_MOM_BINS, N = RJP_MOM_ORDER, ET = RJP_MOM_TILE;
   mp.ok = false;
   if (!hb || (hb->n[0] <= 0 && hb->n[1] <= 0)) return false;
   if (want_em || n_epochs < RJP_MOM_MIN_EPOCHS) return false;
@@ -207,9 +291,9 @@ bool moments_plan(const rjp_fields* fl, const rjp_bursts* hb, const double* epoc
     // Cost model (seconds on one MI355X, from the cfg5-size measurements of round 3): the tiles
     // pay per (cell, epoch) pair -- 0.40 ps in the uniform-epoch recurrence, 0.93 ps when every
     // epoch is evaluated directly -- on the cells inside the occupied y-ranges; the moment path
-    // pays 4.9 ps per such cell once, plus per SIGHTLINE 8 KiB of moments written and read
-    // back (3.3 ns) and 1.1 ns per contraction pass of 32 epochs.  Short or sparsely filled
-    // sightlines keep the tiles.
+    // pays 4.7 ps per such cell once (its most expensive shape), plus per SIGHTLINE 10 KiB of
+    // moments written and read back (3.6 ns) and 1.1 ns per contraction pass of 32 epochs.
+    // Short or sparsely filled sightlines keep the tiles.
     const double npix = (double)fl->nx * fl->nz;
     const double cells = fl->occupied_cells > 0 ? (double)fl->occupied_cells : npix * fl->ny;
     bool uniform = n_epochs >= 4;
@@ -217,8 +301,8 @@ bool moments_plan(const rjp_fields* fl, const rjp_bursts* hb, const double* epoc
     for (int e = 0; e < n_epochs && uniform; ++e)
       uniform = std::fabs(epochs[e] - (epochs[0] + e * dt)) <= 1e-9 * std::fabs(dt);
     const double t_tiles = cells * n_epochs * (uniform ? 0.40e-12 : 0.93e-12);
-    const double t_mom = cells * 4.9e-12 +
-                         npix * (3.3e-9 + 1.1e-9 * ((n_epochs + RJP_MOM_TILE - 1) / RJP_MOM_TILE));
+    const double t_mom = cells * 4.7e-12 +
+                         npix * (3.6e-9 + 1.1e-9 * ((n_epochs + RJP_MOM_TILE - 1) / RJP_MOM_TILE));
     if (!(t_mom < 0.8 * t_tiles)) return false;
   }
   // same request as last time?
@@ -245,85 +329,60 @@ bool moments_plan(const rjp_fields* fl, const rjp_bursts* hb, const double* epoc
       mp.key_bursts.push_back(hb->inv2s2[j][i]);
     }
   mp.key_ok = false;
-
-  const double span = fl->ts_hi - fl->ts_lo;
-  const double h = span > 0.0 ? span / K : 1.0;
-  mp.s0 = fl->ts_lo;
-  mp.inv_h = 1.0 / h;
   mp.has_bursts[0] = hb->n[0] > 0;
   mp.has_bursts[1] = hb->n[1] > 0;
-  mp.nchunk = (n_epochs + ET - 1) / ET;
-  mp.W.assign((size_t)mp.nchunk * kMomIdx * ET, 0.0);
-  // Chebyshev nodes and the DCT matrix
-  const double pi = 3.14159265358979323846;
-  double xn[N], cs[N][N];
-  for (int i = 0; i < N; ++i) {
-    xn[i] = std::cos(pi * (i + 0.5) / N);
-    for (int n = 0; n < N; ++n) cs[n][i] = std::cos(pi * n * (i + 0.5) / N);
+  // cheapest shape first (fewest atomics per cell); RJP_MOM_SHAPE=<i> pins one (debug builds'
+  // A/B switch, as the other RJP_* switches)
+  int pin = -1;
+#ifdef RJP_DEBUG_SWITCHES
+  if (const char* e = getenv("RJP_MOM_SHAPE")) pin = atoi(e);
+#endif
+  for (int sh = 0; sh < kMomNShapes && !mp.key_ok; ++sh) {
+    if (pin >= 0 && sh != pin) continue;
+    mp.key_ok = moments_tables(hb, epochs, n_epochs, kMomShapes[sh].K, kMomShapes[sh].N, mp);
   }
-  constexpr int NT = 2 * N + 1;                       // test points of the accuracy check
-  double worst = 0.0;
-  for (int e = 0; e < n_epochs; ++e) {
-    const int c = e / ET, el = e % ET;
-    double* Wc = mp.W.data() + (size_t)c * kMomIdx * ET;
-    for (int j = 0; j < 2; ++j)
-      for (int k = 0; k < K; ++k) {
-        double* col = Wc + (size_t)((j * K + k) * N) * ET + el;      // stride ET between n
-        if (hb->n[j] <= 0) { col[0] = 1.0; continue; }             // F == 1
-        const double ck = mp.s0 + (k + 0.5) * h;
-        double f[N], cf[N];
-        for (int i = 0; i < N; ++i) f[i] = burst_F(hb, j, epochs[e] - (ck + 0.5 * h * xn[i]));
-        for (int n = 0; n < N; ++n) {
-          double s = 0.0;
-          for (int i = 0; i < N; ++i) s += f[i] * cs[n][i];
-          cf[n] = s * (n == 0 ? 1.0 : 2.0) / N;
-          col[(size_t)n * ET] = cf[n];
-        }
-        // accuracy: the interpolant against F on a finer grid (Clenshaw)
-        for (int m = 0; m < NT; ++m) {
-          const double xv = -1.0 + 2.0 * m / (NT - 1);
-          double b1 = 0.0, b2 = 0.0;
-          for (int n = N - 1; n >= 1; --n) { const double b0 = 2.0 * xv * b1 - b2 + cf[n]; b2 = b1; b1 = b0; }
-          const double val = xv * b1 - b2 + cf[0];
-          const double ref = burst_F(hb, j, epochs[e] - (ck + 0.5 * h * xv));
-          const double err = std::fabs(val - ref) / ref;           // F >= ... > 0 (chi > 0)
-          if (!(err <= worst)) worst = err;
-        }
-      }
-  }
-  mp.worst = worst;
-  mp.key_ok = mp.ok = worst <= RJP_MOM_TOL;
+  mp.ok = mp.key_ok;
   return mp.ok;
+}
+
+template <int K, int N>
+static hipError_t moments_pass(const rjp_fields* fl, const MomDev& md, int64_t npix, int64_t npixp,
+                               double* ws, hipStream_t st) {
+  const size_t shm = (size_t)2 * K * N * kMomSL * sizeof(double);
+  // (more than 64 KB of dynamic LDS must be allowed explicitly, once per device of the process)
+  static int attr_dev = -1;
+  int dev = -1;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return e;
+  if (dev != attr_dev) {
+    e = hipFuncSetAttribute((const void*)moments_kernel<K, N>,
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+    if (e != hipSuccess) return e;
+    attr_dev = dev;
+  }
+  hipLaunchKernelGGL((moments_kernel<K, N>), dim3((unsigned)(npixp / kMomSL)), dim3(kMomBS), shm,
+                     st, (const double*)fl->d_a0, (const double*)fl->d_ts, fl->d_ylo, fl->d_yhi,
+                     fl->ny, fl->nz, npix, npixp, md, ws);
+  return hipGetLastError();
 }
 
 hipError_t moments_run(const rjp_fields* fl, const MomPlan& mp, const double* d_W, int n_epochs,
                        double* sumA, double* ws, hipStream_t st) {
   const int64_t npix = (int64_t)fl->nx * fl->nz;
   const int64_t npixp = (npix + kMomSL - 1) / kMomSL * kMomSL;
-  const size_t shm = (size_t)kMomIdx * kMomSL * sizeof(double);
-  // (128 KB of dynamic LDS must be allowed explicitly, once per device of the process)
-  static int attr_dev = -1;
-  int dev = -1;
-  hipError_t e = hipGetDevice(&dev);
-  if (e != hipSuccess) return e;
-  if (dev != attr_dev) {
-    e = hipFuncSetAttribute((const void*)moments_kernel,
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
-    if (e != hipSuccess) return e;
-    attr_dev = dev;
-  }
   MomDev md;
   md.s0 = mp.s0; md.inv_h = mp.inv_h;
   md.has_bursts[0] = mp.has_bursts[0]; md.has_bursts[1] = mp.has_bursts[1];
-  hipLaunchKernelGGL(moments_kernel, dim3((unsigned)(npixp / kMomSL)), dim3(kMomBS), shm, st,
-                     (const double*)fl->d_a0, (const double*)fl->d_ts, fl->d_ylo, fl->d_yhi,
-                     fl->ny, fl->nz, npix, npixp, md, ws);
-  hipError_t err = hipGetLastError();
+  hipError_t err = hipErrorInvalidValue;
+  if (mp.K == 80 && mp.N == 8) err = moments_pass<80, 8>(fl, md, npix, npixp, ws, st);
+  else if (mp.K == 53 && mp.N == 12) err = moments_pass<53, 12>(fl, md, npix, npixp, ws, st);
+  else if (mp.K == 39 && mp.N == 16) err = moments_pass<39, 16>(fl, md, npix, npixp, ws, st);
   if (err != hipSuccess) return err;
+  const int nidx = 2 * mp.K * mp.N;
   for (int c = 0; c < mp.nchunk; ++c) {
     const int ne = std::min(RJP_MOM_TILE, n_epochs - c * RJP_MOM_TILE);
     hipLaunchKernelGGL(moments_eval_kernel, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, st,
-                       ws, npix, npixp, d_W + (size_t)c * kMomIdx * RJP_MOM_TILE, ne,
+                       ws, npix, npixp, nidx, d_W + (size_t)c * nidx * RJP_MOM_TILE, ne,
                        sumA + (int64_t)c * RJP_MOM_TILE * npix);
     err = hipGetLastError();
     if (err != hipSuccess) return err;

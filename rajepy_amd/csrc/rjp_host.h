@@ -53,8 +53,8 @@ hipError_t sum_partials_launch(const double* part, int rows, int nblk, double* o
                                hipStream_t st);
 
 // ---- ff_moments.hip: epoch sweeps by launch-time moments --------------------------------------
-#define RJP_MOM_BINS 32          /* launch-time bins over [ts_lo, ts_hi] */
-#define RJP_MOM_ORDER 16         /* Chebyshev moments per (jet, bin) */
+#define RJP_MOM_MAX_IDX 1280      /* 2 jets x K bins x N Chebyshev moments <= this (160 KB of LDS
+                                    for 16 sightlines); the (K, N) shapes: ff_moments.hip */
 #define RJP_MOM_TILE 32          /* epochs per pass of the contraction */
 #define RJP_MOM_MIN_EPOCHS 12    /* below: the epoch tiles are faster */
 #define RJP_MOM_TOL 1e-11        /* worst relative error of the expansion the host accepts */
@@ -63,7 +63,8 @@ struct MomPlan {
   double s0 = 0.0, inv_h = 0.0, worst = 0.0;
   int has_bursts[2] = {0, 0};
   int nchunk = 0;
-  std::vector<double> W;         // [chunk][2 * BINS * ORDER][TILE]
+  int K = 0, N = 0;              // the shape the tables were built for
+  std::vector<double> W;         // [chunk][2 * K * N][TILE]
   // the request the tables were built for (a sweep repeated with the same epochs reuses them)
   int key_E = -1, key_n[2] = {0, 0};
   bool key_ok = false;

@@ -371,9 +371,13 @@ int rjp_ff_scan(rjp_ctx* ctx, const rjp_fields* fields, const rjp_bursts* bursts
   return RJP_OK;
 }
 
-int rjp_last_scan_path(const rjp_ctx* ctx, double* worst_rel_err) {
+int rjp_last_scan_path(const rjp_ctx* ctx, double* worst_rel_err, int32_t* moment_shape) {
   if (!ctx) return RJP_ERR_ARG;
   if (worst_rel_err) *worst_rel_err = ctx->last_path == 1 ? ctx->mom.worst : 0.0;
+  if (moment_shape) {
+    moment_shape[0] = ctx->last_path == 1 ? ctx->mom.K : 0;
+    moment_shape[1] = ctx->last_path == 1 ? ctx->mom.N : 0;
+  }
   return ctx->last_path;
 }
 

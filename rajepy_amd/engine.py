@@ -137,6 +137,7 @@ class RTEngine:
         # epoch sweeps by launch-time moments (rjp_fields.ts_lo / ts_hi): off = the epoch tiles
         self.use_moments = not (_lib.DEBUG and os.environ.get("RJP_NO_MOMENTS"))
         self.force_moments = False     # tests: skip the library's tiles-or-moments cost model
+        self.last_moment_shape = (0, 0)
 
     def close(self):
         if getattr(self, "ctx", None):
@@ -463,7 +464,9 @@ class RTEngine:
         """('tiles' | 'moments', worst relative error of the moment expansion) of the last
         rjp_ff_scan of this engine."""
         err = C.c_double()
-        path = self.lib.rjp_last_scan_path(self.ctx, C.byref(err))
+        shape = (C.c_int32 * 2)()
+        path = self.lib.rjp_last_scan_path(self.ctx, C.byref(err), shape)
+        self.last_moment_shape = (int(shape[0]), int(shape[1]))      # (bins, order); (0, 0) = tiles
         return ("moments" if path == 1 else "tiles"), err.value
 
     def time_ff_scan(self, fields, bursts, epochs_s, gff_mode, reps=5, want_em=True,

@@ -22,7 +22,7 @@ RTOL = 5e-11          # 1e-11 expansion + the tiles' own 1e-11 + summation order
 @pytest.fixture(scope="module")
 def eng():
     """`force_moments`: the library's cost model would keep the epoch tiles on grids this small
-    (the moment path pays 8 KiB per sightline, so it wins on long, densely filled sightlines:
+    (the moment path pays up to 10 KiB per sightline, so it wins on long, densely filled sightlines:
     cfg5); the last test checks the model's own decisions."""
     from rajepy_amd.engine import RTEngine
     e = RTEngine(0)
@@ -85,6 +85,30 @@ def test_moments_agree_with_the_epoch_tiles_and_the_oracle(eng, temp_mode, years
         jet.time = ep[e]
         np.testing.assert_allclose(ctau[0] * mom[e].reshape(shape[0], shape[2]),
                                    jet.optical_depth_ff(5e9), rtol=1e-10)
+
+
+@pytest.mark.parametrize("hl_scale,shape_kn", [(2.5, (80, 8)), (1.0, (53, 12)), (0.8, (39, 16))])
+def test_the_cheapest_shape_that_passes_the_accuracy_check_is_taken(eng, hl_scale, shape_kn):
+    """The moment pass exists for three (bins, order) shapes inside its LDS budget; the host
+    tries them in order of cost (atomics per cell) and keeps the first whose expansion is
+    good to 1e-11 for the call: broad bursts (the example's half lives x 2.5) take (80, 8),
+    the example's (53, 12), narrower ones (x 0.8) need (39, 16).  Each against the tiles."""
+    from rajepy_amd import engine as E
+    shape = (3, 160, 40)
+    ej = U.example_bursts_params()
+    ej["hl"] = np.asarray(ej["hl"], float) * hl_scale
+    g, p, jet = _jet(shape, 4242, ejection=ej)
+    f = eng.upload_fields(g["nd"], g["xi"], g["temp"], g["ff"], g["areas"], g["ts"],
+                          g["rr"] < 0, csize_au=jet.csize, dtype=8)
+    eng.tau_layout(f, E.RJP_GFF_SCALAR)
+    ep = [y * orc.YEAR for y in np.linspace(0., 5., 32)]
+    mom, til, (path, err) = _both(eng, f, U.bursts_from_oracle(jet), ep, E.RJP_GFF_SCALAR)
+    assert path == "moments" and err <= 1e-11
+    eng.use_moments = True
+    eng.ff_scan(f, U.bursts_from_oracle(jet), ep, E.RJP_GFF_SCALAR, want_em=False, want_tavg=False)
+    eng.last_scan_path()
+    assert eng.last_moment_shape == shape_kn
+    np.testing.assert_allclose(mom, til, rtol=RTOL)
 
 
 def test_moments_keep_nan_semantics_y_ranges_and_the_burstless_jet(eng):

@@ -26,12 +26,12 @@ __global__ void fill(double* a0, double* ts, size_t n, int nz) {
 }
 
 // SL sightlines per workgroup (z-adjacent), 256 threads: thread = (sightline, y-row offset)
-template <int K, int N, int SL, int U, int BS>
+template <int K, int N, int SL, int U, int BS, int JETS = 2, bool PF = false>
 __global__ __launch_bounds__(BS) void moments(const double* __restrict__ a0, const double* __restrict__ ts,
                                                int ny, int nz, double s0, double inv_h,
                                                double* __restrict__ MT, size_t npix) {
-  extern __shared__ double lds[];          // [2][K][N][SL]
-  constexpr int TOT = 2 * K * N * SL;
+  extern __shared__ double lds[];          // [JETS][K][N][SL]
+  constexpr int TOT = JETS * K * N * SL;
   for (int i = threadIdx.x; i < TOT; i += BS) lds[i] = 0.0;
   __syncthreads();
   const int sl = threadIdx.x % SL, yr = threadIdx.x / SL;
@@ -40,24 +40,14 @@ __global__ __launch_bounds__(BS) void moments(const double* __restrict__ a0, con
   const size_t x = p / nz;
   const int z = (int)(p - x * nz);
   const size_t col = x * (size_t)ny * nz + z;
-  for (int y0 = yr; y0 < ny; y0 += YR * U) {
-    double a[U], t[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int y = y0 + u * YR;
-      const bool in = y < ny;
-      a[u] = in ? __builtin_nontemporal_load(a0 + col + (size_t)y * nz) : 0.0;
-      t[u] = in ? __builtin_nontemporal_load(ts + col + (size_t)y * nz) : 0.0;
-    }
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const bool red = a[u] < 0.0;
-      const double am = fmax(fabs(a[u]), 0.0);
-      const double w = (t[u] - s0) * inv_h;
+  auto cell = [&](double av, double tv) __attribute__((always_inline)) {
+      const bool red = av < 0.0;
+      const double am = fmax(fabs(av), 0.0);
+      const double w = (tv - s0) * inv_h;
       double kf = floor(w);
       kf = fmin(fmax(kf, 0.0), (double)(K - 1));
       const double xi = 2.0 * (w - kf) - 1.0;
-      double* base = lds + (((red ? 0 : K) + (int)kf) * N) * SL + sl;
+      double* base = lds + ((((red || JETS == 1) ? 0 : K) + (int)kf) * N) * SL + sl;
       double tm = 1.0, tc = xi;
       atomicAdd(base, am);
       atomicAdd(base + SL, am * tc);
@@ -68,7 +58,48 @@ __global__ __launch_bounds__(BS) void moments(const double* __restrict__ a0, con
         tm = tc; tc = tn;
         atomicAdd(base + n * SL, am * tn);
       }
+  };
+  if (PF) {
+    // unconditional loads (row index clamped, weight zeroed instead): no branches around the
+    // loads, so the waits can be counted and the next rows stay in flight behind the atomics
+    double a[U], t[U], an[U], tn_[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int y = yr + u * YR;
+      const int yc = y < ny ? y : ny - 1;
+      a[u] = __builtin_nontemporal_load(a0 + col + (size_t)yc * nz);
+      t[u] = __builtin_nontemporal_load(ts + col + (size_t)yc * nz);
     }
+    auto fetch = [&](double (&aa)[U], double (&tt)[U], int yb) __attribute__((always_inline)) {
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int y = yb + u * YR;
+        const int yc = y < ny ? y : ny - 1;
+        aa[u] = __builtin_nontemporal_load(a0 + col + (size_t)yc * nz);
+        tt[u] = __builtin_nontemporal_load(ts + col + (size_t)yc * nz);
+      }
+    };
+    for (int y0 = yr; y0 < ny; y0 += 2 * YR * U) {       // ping-pong: no register copies
+      fetch(an, tn_, y0 + YR * U);
+#pragma unroll
+      for (int u = 0; u < U; ++u) cell((y0 + u * YR < ny) ? a[u] : 0.0, t[u]);
+      fetch(a, t, y0 + 2 * YR * U);
+#pragma unroll
+      for (int u = 0; u < U; ++u) cell((y0 + YR * U + u * YR < ny) ? an[u] : 0.0, tn_[u]);
+    }
+  } else {
+  for (int y0 = yr; y0 < ny; y0 += YR * U) {
+    double a[U], t[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int y = y0 + u * YR;
+      const bool in = y < ny;
+      a[u] = in ? __builtin_nontemporal_load(a0 + col + (size_t)y * nz) : 0.0;
+      t[u] = in ? __builtin_nontemporal_load(ts + col + (size_t)y * nz) : 0.0;
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) cell(a[u], t[u]);
+  }
   }
   __syncthreads();
   // flush, transposed: MT[idx][p]
@@ -78,44 +109,72 @@ __global__ __launch_bounds__(BS) void moments(const double* __restrict__ a0, con
   }
 }
 
-template <int ET>
+template <int ET, int UI, int PP>
 __global__ __launch_bounds__(256) void eval(const double* __restrict__ MT, size_t npix, int kn2,
                                             const double* __restrict__ W, double* __restrict__ out) {
+  // PP pixels per thread (p, p + npix/PP ...), UI moment rows in flight per pixel
   const size_t p = (size_t)blockIdx.x * 256 + threadIdx.x;
-  if (p >= npix) return;
-  double acc[ET];
+  const size_t half = npix / PP;
+  if (p >= half) return;
+  double acc[PP][ET];
 #pragma unroll
-  for (int e = 0; e < ET; ++e) acc[e] = 0.0;
-  for (int i = 0; i < kn2; ++i) {
-    const double m = MT[(size_t)i * npix + p];
-    const double* w = W + (size_t)i * ET;
+  for (int q = 0; q < PP; ++q)
 #pragma unroll
-    for (int e = 0; e < ET; ++e) acc[e] = __builtin_fma(m, w[e], acc[e]);
+    for (int e = 0; e < ET; ++e) acc[q][e] = 0.0;
+  for (int i0 = 0; i0 < kn2; i0 += UI) {
+    double m[PP][UI];
+#pragma unroll
+    for (int j = 0; j < UI; ++j)
+#pragma unroll
+      for (int q = 0; q < PP; ++q) m[q][j] = MT[(size_t)(i0 + j) * npix + p + q * half];
+#pragma unroll
+    for (int j = 0; j < UI; ++j) {
+      const double* w = W + (size_t)(i0 + j) * ET;
+#pragma unroll
+      for (int e = 0; e < ET; ++e)
+#pragma unroll
+        for (int q = 0; q < PP; ++q) acc[q][e] = __builtin_fma(m[q][j], w[e], acc[q][e]);
+    }
   }
 #pragma unroll
-  for (int e = 0; e < ET; ++e) out[(size_t)e * npix + p] = acc[e];
+  for (int q = 0; q < PP; ++q)
+#pragma unroll
+    for (int e = 0; e < ET; ++e) out[(size_t)e * npix + p + q * half] = acc[q][e];
 }
 
-template <int K, int N, int SL, int U, int BS>
+template <int UI, int PP>
+static void run_eval(const double* MT, size_t npix, int kn2, const double* W, double* out) {
+  hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  float best = 1e30f;
+  for (int rep = 0; rep < 4; ++rep) {
+    CK(hipEventRecord(e0));
+    hipLaunchKernelGGL((eval<32, UI, PP>), dim3((unsigned)((npix / PP + 255) / 256)), dim3(256), 0, 0, MT, npix, kn2, W, out);
+    CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1)); if (ms < best) best = ms;
+  }
+  printf("eval UI=%d PP=%d kn2=%d: %.3f ms\n", UI, PP, kn2, best);
+}
+
+template <int K, int N, int SL, int U, int BS, int JETS = 2, bool PF = false>
 static void run(const double* a0, const double* ts, int nx, int ny, int nz, double* MT, double* W, double* out) {
   const size_t npix = (size_t)nx * nz;
-  const size_t shm = (size_t)2 * K * N * SL * sizeof(double);
-  CK(hipFuncSetAttribute((const void*)moments<K, N, SL, U, BS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
+  const size_t shm = (size_t)JETS * K * N * SL * sizeof(double);
+  CK(hipFuncSetAttribute((const void*)moments<K, N, SL, U, BS, JETS, PF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   float best = 1e30f, best2 = 1e30f;
   for (int rep = 0; rep < 4; ++rep) {
     CK(hipEventRecord(e0));
-    hipLaunchKernelGGL((moments<K, N, SL, U, BS>), dim3((unsigned)(npix / SL)), dim3(BS), shm, 0, a0, ts, ny, nz, 0.0, K / 5.0, MT, npix);
+    hipLaunchKernelGGL((moments<K, N, SL, U, BS, JETS, PF>), dim3((unsigned)(npix / SL)), dim3(BS), shm, 0, a0, ts, ny, nz, 0.0, K / 5.0, MT, npix);
     CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
     float ms; CK(hipEventElapsedTime(&ms, e0, e1)); if (ms < best) best = ms;
     CK(hipEventRecord(e0));
-    hipLaunchKernelGGL((eval<32>), dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, 0, MT, npix, 2 * K * N, W, out);
+    hipLaunchKernelGGL((eval<32, 1, 1>), dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, 0, MT, npix, JETS * K * N, W, out);
     CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
     CK(hipEventElapsedTime(&ms, e0, e1)); if (ms < best2) best2 = ms;
   }
   CK(hipGetLastError());
   const double gb = (double)nx * ny * nz * 16 / 1e9;
-  printf("BS=%d ", BS); printf("K=%d N=%d SL=%d U=%d  LDS %zu KB: moments %.3f ms (%.0f GB/s of a0+ts)  eval(32 epochs) %.3f ms\n",
+  printf("BS=%d JETS=%d PF=%d ", BS, JETS, (int)PF); printf("K=%d N=%d SL=%d U=%d  LDS %zu KB: moments %.3f ms (%.0f GB/s of a0+ts)  eval(32 epochs) %.3f ms\n",
          K, N, SL, U, shm / 1024, best, gb / best * 1e3, best2);
 }
 
@@ -129,12 +188,14 @@ int main() {
   CK(hipMalloc(&out, 32 * npix * 8));
   hipLaunchKernelGGL(fill, dim3(8192), dim3(256), 0, 0, a0, ts, n, nz);
   CK(hipDeviceSynchronize());
-  run<32, 16, 16, 8, 256>(a0, ts, nx, ny, nz, MT, W, out);
-  run<32, 16, 16, 8, 512>(a0, ts, nx, ny, nz, MT, W, out);
-  run<32, 16, 16, 4, 512>(a0, ts, nx, ny, nz, MT, W, out);
-  run<32, 16, 16, 4, 1024>(a0, ts, nx, ny, nz, MT, W, out);
-  run<32, 16, 16, 2, 1024>(a0, ts, nx, ny, nz, MT, W, out);
-  run<32, 16, 32, 4, 512>(a0, ts, nx, ny, nz, MT, W, out);
+  run<32, 16, 16, 4, 1024, 2, true>(a0, ts, nx, ny, nz, MT, W, out);
+  run_eval<1, 1>(MT, npix, 1024, W, out);
+  run_eval<4, 1>(MT, npix, 1024, W, out);
+  run_eval<8, 1>(MT, npix, 1024, W, out);
+  run_eval<16, 1>(MT, npix, 1024, W, out);
+  run_eval<4, 2>(MT, npix, 1024, W, out);
+  run_eval<8, 2>(MT, npix, 1024, W, out);
+  run_eval<8, 1>(MT, npix, 1272, W, out);
   // sanity: total of the zeroth moments == sum |a0|
   std::vector<double> h(npix);
   CK(hipMemcpy(h.data(), MT, npix * 8, hipMemcpyDeviceToHost));
