@@ -43,6 +43,11 @@ __device__ __forceinline__ double poison_unless(double x, bool keep) {
                                           ((unsigned long long)b & 0xFFFFFFFFull)));
 }
 
+// x if neither x nor t is NaN, else +0 (x >= 0 or NaN: a magnitude as load_rows leaves it)
+__device__ __forceinline__ double keep_if_ordered(double x, double t) {
+  return __builtin_isunordered(x, t) ? 0.0 : x;
+}
+
 // nansum: NaN -> 0.  A compact-layout term is never negative ((n x)^2 pf with pf >= 0 times a
 // temperature power), so max(x, 0) does it in one instruction; the wide layout admits any
 // sign of pf and selects.
@@ -105,6 +110,7 @@ struct RowBatch {
   double tp[U][VEC];     // temperature (wide and compact layouts)
   double ts[U][VEC];     // launch time
   bool rj[U][VEC];       // red-jet flag
+  uint32_t sg[U][VEC];   // high dword of the field that carries it in its sign bit
 };
 
 template <typename T, int VEC, bool BURSTS, int LAY, bool EM, int U>
@@ -126,6 +132,7 @@ __device__ __forceinline__ void load_rows(const FieldPtrs<T>& f, int64_t off, in
 #pragma unroll
       for (int v = 0; v < VEC; ++v) {
         rj[u][v] = signbit_d(a[u][v]);
+        rb.sg[u][v] = hi_dword(a[u][v]);
         a[u][v] = fabs(a[u][v]);
         if (EM) g0[u][v] = fabs(g0[u][v]);
       }
@@ -142,6 +149,7 @@ __device__ __forceinline__ void load_rows(const FieldPtrs<T>& f, int64_t off, in
 #pragma unroll
       for (int v = 0; v < VEC; ++v) {
         rj[u][v] = signbit_d(g0[u][v]);
+        rb.sg[u][v] = hi_dword(g0[u][v]);
         g0[u][v] = fabs(g0[u][v]);
       }
   } else {
@@ -162,6 +170,7 @@ __device__ __forceinline__ void load_rows(const FieldPtrs<T>& f, int64_t off, in
         const double n0 = fabs(nd[u][v]) * xi[u][v];   // steady-state electron density
         g0[u][v] = n0 * n0 * pf[u][v];
         rj[u][v] = signbit_d(nd[u][v]);
+        rb.sg[u][v] = hi_dword(nd[u][v]);
       }
   }
 }
@@ -188,7 +197,7 @@ __device__ __forceinline__ void compute_rows(const RowBatch<VEC, U>& rb, const B
     chi_batch_uniform<ET, U * VEC>(b, ep.un, red, tlm, chi);
   } else if (BURSTS) {
     double tl[NB];
-    bool red[NB];
+    uint32_t sg[U * VEC];
 #pragma unroll
     for (int e = 0; e < ET; ++e)
 #pragma unroll
@@ -197,12 +206,12 @@ __device__ __forceinline__ void compute_rows(const RowBatch<VEC, U>& rb, const B
         for (int v = 0; v < VEC; ++v) {
           const int k = (e * U + u) * VEC + v;
           // a NaN launch time needs no special care on this path: the Gaussian argument is
-          // NaN, exp's clamp max(arg, -708) returns the number, the burst adds ~1e-308 and
-          // chi stays 1; the cell is masked when it is accumulated (poison_unless below)
+          // NaN, exp's clamp max(arg, -1021) returns the number, the burst adds ~1e-308 and
+          // chi stays 1; the cell is masked when it is accumulated
           tl[k] = ep.t[e] - ts[u][v];
-          red[k] = rj[u][v];
+          sg[u * VEC + v] = rb.sg[u][v];
         }
-    chi_batch<NB, sizeof(T) == 4>(b, red, tl, chi);
+    chi_batch<NB, U * VEC, sizeof(T) == 4>(b, sg, tl, chi);
   }
 
   if constexpr (LAY == LAY_TAU) {
@@ -214,9 +223,11 @@ __device__ __forceinline__ void compute_rows(const RowBatch<VEC, U>& rb, const B
 #pragma unroll
       for (int v = 0; v < VEC; ++v) {
         if (BURSTS) {
-          const bool ok = ts[u][v] == ts[u][v];
-          const double am = nan_to_zero<true>(poison_unless(rb.a[u][v], ok));
-          const double gm = EM ? nan_to_zero<true>(poison_unless(g0[u][v], ok)) : 0.0;
+          // nansum: a term is dropped when the field or the launch time is NaN -- ONE unordered
+          // compare of the two and a select of the magnitude (3 instructions; poisoning the
+          // high dword and two fmax took 5)
+          const double am = keep_if_ordered(rb.a[u][v], ts[u][v]);
+          const double gm = EM ? keep_if_ordered(g0[u][v], ts[u][v]) : 0.0;
 #pragma unroll
           for (int e = 0; e < ET; ++e) {
             const double c = chi[(e * U + u) * VEC + v];
@@ -469,6 +480,7 @@ void ff_scan_tile_kernel(
       const double a = q[0];
       rb.ts[0][0] = q[2 * RJP_WAVE];
       rb.rj[0][0] = signbit_d(a);
+      rb.sg[0][0] = hi_dword(a);
       rb.a[0][0] = fabs(a);
       if constexpr (EM) rb.g0[0][0] = fabs(q[4 * RJP_WAVE]);
     } else if constexpr (LAY == LAY_CMP) {
@@ -476,6 +488,7 @@ void ff_scan_tile_kernel(
       rb.tp[0][0] = q[2 * RJP_WAVE];
       rb.ts[0][0] = q[4 * RJP_WAVE];
       rb.rj[0][0] = signbit_d(g);
+      rb.sg[0][0] = hi_dword(g);
       rb.g0[0][0] = fabs(g);
     } else {
       const double nd = q[0], xi = q[2 * RJP_WAVE], pf = q[6 * RJP_WAVE];
@@ -484,6 +497,7 @@ void ff_scan_tile_kernel(
       const double n0 = fabs(nd) * xi;
       rb.g0[0][0] = n0 * n0 * pf;
       rb.rj[0][0] = signbit_d(nd);
+      rb.sg[0][0] = hi_dword(nd);
     }
     compute_rows<double, 1, ET, MODE, true, true, LAY, EM, 1>(rb, b, ep, accA, accE, accT, cnt);
   };

@@ -202,6 +202,51 @@ __device__ __forceinline__ double exp2_burst(double t) {
   return F32ACC ? exp2_nonpos_f32acc(t) : exp2_nonpos(t);
 }
 
+// The burst Gaussian where it is evaluated once per (cell, epoch, burst) -- the direct scans,
+// K3's per-cell burst factor: 2^(k2 (tl - t0)^2).  The single-epoch scan is bound by HBM AND
+// by vector-ALU issue at a power-limited clock (61 instructions per cell, 87 % issue at
+// 1.65 GHz: profiles/r03b_cfg4_k1_tau_sq.json), so the instruction count is bandwidth: 2^f
+// by a degree-8 near-minimax polynomial (relative error 1.1e-12 before rounding,
+// tools/minimax_fit.py; degree 10 / 4e-16 in rounds 1-2): 18 instructions per Gaussian
+// instead of 20.  chi carries at most that error, tau = sum a0 chi^2 at most 2.2e-12 -- seven
+// orders inside BASELINE.json's 1e-5, and inside the 1e-11 the parity tests hold against the
+// reference's maps.  The anchors of the uniform-epoch recurrences keep degree 10 (two
+// exponentials per cell and burst serve a whole tile there, and the step ratio's error is
+// raised to the power of the step; with a second constant set in the tile kernels they ran
+// 1-2 % slower).  A NaN argument counts as -inf (fmax), as before.
+// (Forming u = tl sk + c0 with one fma and 2^(-u^2) was tried: both constants are SGPR pairs
+// and a VOP3 instruction reads one, so the fma costs two moves -- no gain.)
+#define RJP_EXP2_D8 1.33441841430774186e-06
+#define RJP_EXP2_D7 1.53142092581519469e-05
+#define RJP_EXP2_D6 1.54030982836854641e-04
+#define RJP_EXP2_D5 1.33334341574215041e-03
+#define RJP_EXP2_D4 9.61812955884247880e-03
+#define RJP_EXP2_D3 5.55041095922895744e-02
+#define RJP_EXP2_D2 2.40226506947425783e-01
+#define RJP_EXP2_D1 6.93147180541232588e-01
+// 2^t, t <= 0 or NaN (the argument of a burst Gaussian)
+template <bool F32ACC>
+__device__ __forceinline__ double exp2_gauss(double targ) {
+  const double t = __builtin_fmax(targ, -1021.0);
+  const double kd = __builtin_rint(t);
+  const double f = t - kd;
+  if (F32ACC) return __builtin_ldexp((double)__builtin_amdgcn_exp2f((float)f), (int)kd);
+  double p = RJP_EXP2_D8;
+  p = __builtin_fma(p, f, RJP_EXP2_D7);
+  p = __builtin_fma(p, f, RJP_EXP2_D6);
+  p = __builtin_fma(p, f, RJP_EXP2_D5);
+  p = __builtin_fma(p, f, RJP_EXP2_D4);
+  p = __builtin_fma(p, f, RJP_EXP2_D3);
+  p = __builtin_fma(p, f, RJP_EXP2_D2);
+  p = __builtin_fma(p, f, RJP_EXP2_D1);
+  return __builtin_ldexp(__builtin_fma(p, f, 1.0), (int)kd);
+}
+template <bool F32ACC>
+__device__ __forceinline__ double gauss2(double tl, double t0, double k2) {
+  const double d = tl - t0;
+  return exp2_gauss<F32ACC>((d * d) * k2);
+}
+
 // exp(x) for |x| <= 700, relative error < 1e-14: Cody-Waite reduction + the degree-10
 // polynomial of exp(r) above (K3's pole term and the power-law Gaunt factor)
 __device__ __forceinline__ double exp_any(double x) {
@@ -262,14 +307,11 @@ __device__ __forceinline__ double chi_jet(const BurstsDev& b, int jet, double tl
   const int nb = b.n[jet];
   if (nb > 0 && !(tl == tl)) return __builtin_nan("");
   const int n0 = nb < RJP_SGPR_BURSTS ? nb : RJP_SGPR_BURSTS;
-  for (int i = 0; i < n0; ++i) {
-    double d = tl - b.t0[jet][i];
-    chi = __builtin_fma(b.amp_rel[jet][i], exp2_nonpos((d * d) * b.k2[jet][i]), chi);
-  }
+  for (int i = 0; i < n0; ++i)
+    chi = __builtin_fma(b.amp_rel[jet][i], gauss2<false>(tl, b.t0[jet][i], b.k2[jet][i]), chi);
   for (int i = RJP_SGPR_BURSTS; i < nb; ++i) {
     const double* e = b.ext + (size_t)(jet * 3) * b.next + (i - RJP_SGPR_BURSTS);
-    double d = tl - e[0];
-    chi = __builtin_fma(e[b.next], exp2_nonpos((d * d) * e[2 * b.next]), chi);
+    chi = __builtin_fma(e[b.next], gauss2<false>(tl, e[0], e[2 * b.next]), chi);
   }
   return chi;
 }
@@ -282,44 +324,55 @@ __device__ __forceinline__ double chi_cell(const BurstsDev& b, bool red, double 
 // the NB exp() evaluations inside it are independent, so their dependent FMA chains overlap.
 // A wave whose lanes all sit in one jet reads that jet's parameters from SGPRs; a wave that
 // straddles the red/blue plane selects them per lane (unused slots have amp_rel = 0).
-template <int NB, bool F32ACC>
-__device__ __forceinline__ void chi_batch(const BurstsDev& b, const bool (&red)[NB],
+// `sg` = the high dwords of the NS = NB / ET signed fields the cells' jet flags sit in (bit 31
+// = red jet; pair k belongs to cell k % NS): "any red / any blue lane in the wave" comes from one
+// OR and one AND chain over the raw words (three-input ops) instead of a flag per cell.
+template <int NB, int NS, bool F32ACC>
+__device__ __forceinline__ void chi_batch(const BurstsDev& b, const uint32_t (&sg)[NS],
                                           const double (&tl)[NB], double (&chi)[NB]) {
-  bool any_red = false, any_blue = false;
+  static_assert(NB % NS == 0, "pairs per cell");
+  uint32_t wor = 0u, wand = 0xffffffffu;
 #pragma unroll
-  for (int k = 0; k < NB; ++k) { any_red |= red[k]; any_blue |= !red[k]; }
-  const bool wave_red = __builtin_amdgcn_ballot_w64(any_red) != 0;
-  const bool wave_blue = __builtin_amdgcn_ballot_w64(any_blue) != 0;
-#pragma unroll
-  for (int k = 0; k < NB; ++k) chi[k] = 1.0;
+  for (int k = 0; k < NS; ++k) { wor |= sg[k]; wand &= sg[k]; }
+  const bool wave_red = __builtin_amdgcn_ballot_w64((int)wor < 0) != 0;
+  const bool wave_blue = __builtin_amdgcn_ballot_w64((int)wand >= 0) != 0;
   if (!(wave_red && wave_blue)) {
     const int jet = wave_red ? 0 : 1;
     const int nb = b.n[jet];
     const int n0 = nb < RJP_SGPR_BURSTS ? nb : RJP_SGPR_BURSTS;
+    // the first burst starts the sums from the constant 1 (no register initialisation)
+    if (n0 > 0) {
+      const double t0 = b.t0[jet][0], k2 = b.k2[jet][0], amp = b.amp_rel[jet][0];
+#pragma unroll
+      for (int k = 0; k < NB; ++k) chi[k] = __builtin_fma(amp, gauss2<F32ACC>(tl[k], t0, k2), 1.0);
+    } else {
+#pragma unroll
+      for (int k = 0; k < NB; ++k) chi[k] = 1.0;
+    }
     auto one = [&](double t0, double k2, double amp) __attribute__((always_inline)) {
 #pragma unroll
-      for (int k = 0; k < NB; ++k) {
-        const double d = tl[k] - t0;
-        chi[k] = __builtin_fma(amp, exp2_burst<F32ACC>((d * d) * k2), chi[k]);
-      }
+      for (int k = 0; k < NB; ++k)
+        chi[k] = __builtin_fma(amp, gauss2<F32ACC>(tl[k], t0, k2), chi[k]);
     };
-    for (int i = 0; i < n0; ++i) one(b.t0[jet][i], b.k2[jet][i], b.amp_rel[jet][i]);
+    for (int i = 1; i < n0; ++i) one(b.t0[jet][i], b.k2[jet][i], b.amp_rel[jet][i]);
     for (int i = RJP_SGPR_BURSTS; i < nb; ++i) {
       const double* e = b.ext + (size_t)(jet * 3) * b.next + (i - RJP_SGPR_BURSTS);
       one(e[0], e[2 * b.next], e[b.next]);
     }
   } else {
+#pragma unroll
+    for (int k = 0; k < NB; ++k) chi[k] = 1.0;
     const int nb = b.n[0] > b.n[1] ? b.n[0] : b.n[1];
     const int n0 = nb < RJP_SGPR_BURSTS ? nb : RJP_SGPR_BURSTS;
     auto one = [&](double t0r, double k2r, double ampr, double t0b, double k2b,
                    double ampb) __attribute__((always_inline)) {
 #pragma unroll
       for (int k = 0; k < NB; ++k) {
-        const double t0 = red[k] ? t0r : t0b;
-        const double k2 = red[k] ? k2r : k2b;
-        const double amp = red[k] ? ampr : ampb;
-        const double d = tl[k] - t0;
-        chi[k] = __builtin_fma(amp, exp2_burst<F32ACC>((d * d) * k2), chi[k]);
+        const bool red = (int)sg[k % NS] < 0;
+        const double t0 = red ? t0r : t0b;
+        const double k2 = red ? k2r : k2b;
+        const double amp = red ? ampr : ampb;
+        chi[k] = __builtin_fma(amp, gauss2<F32ACC>(tl[k], t0, k2), chi[k]);
       }
     };
     for (int i = 0; i < n0; ++i)
@@ -597,6 +650,9 @@ __device__ __forceinline__ void pow_m1p35_batch(const double (&T)[N], double (&o
 
 __device__ __forceinline__ bool signbit_d(double v) {
   return (__double_as_longlong(v) < 0);
+}
+__device__ __forceinline__ uint32_t hi_dword(double v) {
+  return (uint32_t)((unsigned long long)__double_as_longlong(v) >> 32);
 }
 
 // The temperature factor of a cell's free-free optical depth exactly as K1 evaluates it on the
