@@ -822,7 +822,7 @@ def main(argv=None):
                  else "compact (3 fields/cell)"}.get(nf)
     layout_desc = k1_layout if not rrl else \
         "K3 reads the 6 wide fields; K1 %s" % ("tau" if has_tau else "compact")
-    for rnd in ("r03", "r02e", "r02", "r01"):
+    for rnd in ("r03c", "r03", "r02e", "r02", "r01"):
         rel = os.path.join("profiles", "%s_%s_%s%s_pmc.json" % (rnd, args.config, args.storage,
                                                                 lay_tag))
         if os.path.exists(os.path.join(ROOT, rel)):

@@ -463,3 +463,24 @@ def test_sgpr_table_load_checker_sees_a_reader_before_the_wait():
     # a wait for another counter does not count
     text = good.replace("s_waitcnt lgkmcnt(0)", "s_waitcnt vmcnt(0)\n	v_writelane_b32 v9, s41, 1\n	s_waitcnt lgkmcnt(0)")
     assert len(mod.check(text, "t")[0]) == 1
+
+
+def test_burst_gaussian_polynomial_meets_its_documented_bound():
+    """K1's direct scans evaluate 2^f, |f| <= 1/2, by the degree-8 polynomial whose
+    coefficients sit in rjp_device.h (RJP_EXP2_D8 .. D1): the header documents 1.1e-12
+    relative before rounding -- the float64 Horner chain the kernel runs must stay inside it
+    (and the degree-10 one of the recurrence anchors inside 1e-15)."""
+    hdr = open(os.path.join(ROOT, "rajepy_amd", "csrc", "rjp_device.h")).read()
+    f = np.linspace(-0.5, 0.5, 400001)
+
+    def horner(prefix, deg):
+        c = [float(re.search(r"#define %s%d ([-+0-9.eE]+)" % (prefix, k), hdr).group(1))
+             for k in range(deg, 0, -1)]
+        p = np.full_like(f, c[0])
+        for ck in c[1:]:
+            p = p * f + ck
+        return p * f + 1.0
+
+    ref = np.exp2(f)
+    assert np.max(np.abs(horner("RJP_EXP2_D", 8) / ref - 1.0)) < 1.2e-12
+    assert np.max(np.abs(horner("RJP_EXP2_C", 10) / ref - 1.0)) < 1e-15
