@@ -17,8 +17,8 @@
 //            for its channel and accumulates tau in FP64; the per-(sightline, channel)
 //            accumulators live in LDS, so the sightline loop is not unrolled (< 128 VGPRs,
 //            4 waves per SIMD).  Cells outside the jet are skipped with a scalar branch.
-// Compute-bound (vector FP64) by construction -- ~105 VALU instructions per (cell, channel) on
-// cfg3's fields, census in profiles/r03_k3_census.md; HBM traffic is 6 fields per cell, read
+// Compute-bound (vector FP64) by construction -- 105 VALU instructions per (cell, channel) on
+// cfg3's fields (counted: profiles/r03c_cfg3_k3_sq.json), census in profiles/r03_k3_census.md; HBM traffic is 6 fields per cell, read
 // once per block of 256 channels.
 //
 // Accuracy budget.  The wave-uniform paths (far-field series, plain lattice with or without the
@@ -128,8 +128,8 @@ __device__ __forceinline__ double kmul(double K, double b);
 struct PoleTop { double cos_top, exp_top; };
 __device__ __forceinline__ PoleTop pole_top() {
   PoleTop t;
-  asm volatile("v_mov_b64 %0, %1" : "=v"(t.cos_top) : "s"(2.00440237723759486e-09));
-  asm volatile("v_mov_b64 %0, %1" : "=v"(t.exp_top) : "s"(2.50213726461024045e-05));
+  asm volatile("v_mov_b64 %0, %1" : "=v"(t.cos_top) : "s"(-2.62979486641630506e-07));
+  asm volatile("v_mov_b64 %0, %1" : "=v"(t.exp_top) : "s"(1.73659676346479309e-04));
   return t;
 }
 
@@ -144,15 +144,17 @@ __device__ __forceinline__ void cos_2pi_x3(double u0, double u1, double u2, doub
     w2[i] = w * w;
   }
   // near-minimax on |w| <= pi/2 with the two leading coefficients kept at 1, -1/2 (inline
-  // constants): degree 12, max abs error 3.9e-12 (tools/minimax_fit.py; the pole term enters
-  // Re w amplified by at most ~10 where sum and pole term cancel, y >= 0.03) -- degree 14
-  // (1e-14) in round 2, degree-20 Taylor in round 1
-  constexpr double cf[4] = {-2.75347756843411723e-07, 2.48013152427276996e-05,
-                            -1.38888875194187922e-03, 4.16666666468048091e-02};
+  // constants): degree 10, max abs error 1.1e-9 (tools/minimax_fit.py) -- the worst error of
+  // the whole path stays the lattice's 3.1e-9 (tools/voigt_design.py; the pole term enters
+  // Re w amplified by at most ~10 where sum and pole term cancel, and is itself <= 1e-1 of
+  // it there).  Degree 12 (3.9e-12) in the first half of round 3, 14 in round 2, a degree-20
+  // Taylor polynomial in round 1.
+  constexpr double cf[3] = {2.47753637598607603e-05, -1.38886802208908807e-03,
+                            4.16666619921366096e-02};
 #pragma unroll
   for (int i = 0; i < 3; ++i) p[i] = fma_k(top, w2[i], cf[0]);
 #pragma unroll
-  for (int j = 1; j < 4; ++j)
+  for (int j = 1; j < 3; ++j)
 #pragma unroll
     for (int i = 0; i < 3; ++i) p[i] = fma_k(p[i], w2[i], cf[j]);
 #pragma unroll
@@ -176,13 +178,13 @@ __device__ __forceinline__ double exp_k(double x, double top) {
   const double kd = __builtin_rint(kmul(1.4426950408889634074, x));
   double r = kfma(-6.93147180369123816490e-01, kd, x);
   r = kfma(-1.90821492927058770002e-10, kd, r);
-  // degree 8, near-minimax on |r| <= ln2/2 with 1, 1, 1/2 kept: relative error 1.6e-12
-  // (tools/minimax_fit.py); only the pole term uses this exp
-  double p = fma_k(top, r, 1.99141676370814211e-04);
-  p = fma_k(p, r, 1.38885875111343206e-03);
-  p = fma_k(p, r, 8.33327326606923997e-03);
-  p = fma_k(p, r, 4.16666677111410463e-02);
-  p = fma_k(p, r, 1.66666668158620745e-01);
+  // degree 7, near-minimax on |r| <= ln2/2 with 1, 1, 1/2 kept: relative error 3.9e-10
+  // (tools/minimax_fit.py; degree 8 / 1.6e-12 before -- the path's worst error is unchanged,
+  // tools/voigt_design.py); only the pole term uses this exp
+  double p = fma_k(top, r, 1.39332571536309119e-03);
+  p = fma_k(p, r, 8.33781514566415451e-03);
+  p = fma_k(p, r, 4.16664825818220744e-02);
+  p = fma_k(p, r, 1.66666480404710465e-01);
   p = __builtin_fma(p, r, 0.5);
   p = __builtin_fma(p, r, 1.0);
   p = __builtin_fma(p, r, 1.0);

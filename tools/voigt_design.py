@@ -26,12 +26,13 @@ FAR = ((6, 64.0), (4, 196.0))     # (series terms K, |z|^2 above which every lan
 TOL_POLE = 3e-8            # pole term skipped where a rigorous bound puts it below this * Re w
 C_FAR = [1.0, 0.5, 0.75, 1.875, 6.5625, 29.53125, 162.421875, 1055.7421875, 7918.06640625]
 
-# near-minimax polynomials (tools/minimax_fit.py): cos on |w| <= pi/2 in s = w^2 (degree 12 in
-# w, abs err 3.9e-12), exp on |r| <= ln2/2 (degree 8, rel err 1.6e-12)
-COS12 = [2.00440237723759486e-09, -2.75347756843411723e-07, 2.48013152427276996e-05,
-         -1.38888875194187922e-03, 4.16666666468048091e-02, -0.5, 1.0]
-EXP8 = [2.50213726461024045e-05, 1.99141676370814211e-04, 1.38885875111343206e-03,
-        8.33327326606923997e-03, 4.16666677111410463e-02, 1.66666668158620745e-01, 0.5, 1.0, 1.0]
+# near-minimax polynomials (tools/minimax_fit.py): cos on |w| <= pi/2 in s = w^2 (degree 10 in
+# w, abs err 1.1e-9), exp on |r| <= ln2/2 (degree 7, rel err 3.9e-10); the names are those of
+# the first half of round 3 (degree 12 / 8)
+COS12 = [-2.62979486641630506e-07, 2.47753637598607603e-05, -1.38886802208908807e-03,
+         4.16666619921366096e-02, -0.5, 1.0]
+EXP8 = [1.73659676346479309e-04, 1.39332571536309119e-03, 8.33781514566415451e-03,
+        4.16664825818220744e-02, 1.66666480404710465e-01, 0.5, 1.0, 1.0]
 
 
 def horner(c, x):
