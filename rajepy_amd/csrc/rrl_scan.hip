@@ -311,8 +311,8 @@ __device__ __forceinline__ double voigt_far(double ax, double y) {
   return 0.56418958354775628695 * wi * rcp_fast(__builtin_fma(wr, wr, wi * wi));
 }
 
-__device__ __forceinline__ double voigt_centred(double ax, double y, double q, double cq,
-                                                double* tab) {
+__device__ __forceinline__ double voigt_centred(double ax, double y, double ky, double q,
+                                                double cq, double* tab) {
   // per-cell table, written by the 64 lanes of this wave (all of them are here: y is
   // wave-uniform and so is the branch that leads here)
   {
@@ -361,7 +361,7 @@ __device__ __forceinline__ double voigt_centred(double ax, double y, double q, d
     e *= r; r *= kQ;
     s = __builtin_fma(e, t[-j], s);
   }
-  s *= y * (kHW / 3.14159265358979323846);
+  s *= ky;                                                      // y h / pi
   // pole term: below 3e-8 Re w by a rigorous bound (measured: 1e-9) once x^2 exceeds the
   // per-cell bound cq; skipped when no lane of the wave needs it
   if (__builtin_amdgcn_ballot_w64(ax * ax < cq) != 0) {
@@ -403,7 +403,7 @@ __device__ __forceinline__ double voigt_rew(double ax, double y, double q, doubl
   const bool far = r2 > 64.0 && (ax * ax > 64.0 || y > 1.0);
   if (__builtin_amdgcn_ballot_w64(!far) == 0) return voigt_far(ax, y);
   if constexpr (CEN) {
-    if (y < kCenYMax) return voigt_centred(ax, y, q, cq, tab);
+    if (y < kCenYMax) return voigt_centred(ax, y, y * (kHW / 3.14159265358979323846), q, cq, tab);
   } else {
     if (y < 0.03) return voigt_core_shifted(ax, y, q, -2.0 * (3.14159265358979323846 / kH) * y);
   }
@@ -496,8 +496,12 @@ __device__ __forceinline__ double kmul(double K, double b) {                 // 
 // there): K = 6 -> 4.1e-9 (K = 8 -> 8e-11: rounds 1-2); |z|^2 > 196: K = 4 -> 1.2e-9.
 template <int K>
 __device__ __forceinline__ double voigt_far_series(double ax, double y) {
-  constexpr double c[9] = {1.0, 0.5, 0.75, 1.875, 6.5625, 29.53125, 162.421875, 1055.7421875,
-                           7918.06640625};
+  // (2k-1)!!/2^k, times 1/sqrt(pi): the series is linear in its coefficients, so the constant
+  // factor of w(z) rides in them (one multiplication fewer per evaluation)
+  constexpr double kIsp = 0.56418958354775628695;
+  constexpr double c[9] = {1.0 * kIsp, 0.5 * kIsp, 0.75 * kIsp, 1.875 * kIsp, 6.5625 * kIsp,
+                           29.53125 * kIsp, 162.421875 * kIsp, 1055.7421875 * kIsp,
+                           7918.06640625 * kIsp};
   static_assert(K >= 2 && K <= 8, "series length");
   const double x2 = ax * ax, y2 = y * y;
   const double r2 = x2 + y2;
@@ -509,14 +513,12 @@ __device__ __forceinline__ double voigt_far_series(double ax, double y) {
 #pragma unroll
   for (int k = K - 2; k >= 0; --k) {
     // S <- S u + c[k]:  Re: pr ur - pi ui + c[k],  Im: pr ui + pi ur,  ui = -nui
-    const double t = (c[k] == 1.0 || c[k] == 0.5)
-                         ? __builtin_fma(pr, ur, __builtin_fma(pi, nui, c[k]))
-                         : __builtin_fma(pr, ur, fma_k(pi, nui, c[k]));
+    const double t = __builtin_fma(pr, ur, fma_k(pi, nui, c[k]));
     pi = __builtin_fma(-pr, nui, pi * ur);
     pr = t;
   }
   // 1/|z|^2 = |z|^2 * inv
-  return __builtin_fma(y, pr, -ax * pi) * (r2 * inv) * 0.56418958354775628695;
+  return __builtin_fma(y, pr, -ax * pi) * (r2 * inv);
 }
 
 // Plain lattice (y >= 0.03), every lane of the wave: the eight node pairs (h = 0.675) over ONE
@@ -531,8 +533,9 @@ __device__ __forceinline__ double voigt_far_series(double ax, double y) {
 // of the generic path does.  Relative error <= 3.4e-9 against wofz for 0.03 <= y, x^2 <= 64,
 // pole term included (worst at x = 0 just above y = pi/h, where the pole term ends;
 // tools/voigt_design.py).  Rounds 1-2: h = 0.6, ten pairs, 1e-11.
+// `ky` = y h / pi, staged per cell.
 template <bool POLE>
-__device__ __forceinline__ double voigt_plain_wave(double ax, double y, double q,
+__device__ __forceinline__ double voigt_plain_wave(double ax, double y, double ky, double q,
                                                    const PoleTop& top) {
   constexpr double tau[kNPairW] = {0.0, 0.45562500000000006, 1.8225000000000002,
                                    4.100625000000002, 7.290000000000001, 11.390625,
@@ -562,8 +565,8 @@ __device__ __forceinline__ double voigt_plain_wave(double ax, double y, double q
   const double N01 = __builtin_fma(N[0], D[1], kmul(w2[2] / w2[0], N[1] * D[0])), D01 = D[0] * D[1];
   const double N23 = __builtin_fma(N[2], D[3], kmul(w2[6] / w2[4], N[3] * D[2])), D23 = D[2] * D[3];
   const double Nall = __builtin_fma(N01, D23, kmul(w2[4] / w2[0], N23 * D01)), Dall = D01 * D23;
-  // sum = w2[0] * Nall / Dall; Re w = (h y / pi) * sum
-  const double ky = kmul(w2[0] * kHW / 3.14159265358979323846, y);
+  // sum = w2[0] * Nall / Dall (w2[0] = 1); Re w = (h y / pi) * sum = ky * sum
+  static_assert(w2[0] == 1.0, "ky carries no node weight");
   if (!POLE) return Nall * rcp_fast(Dall) * ky;
   // P = Re[ 2 exp(-z^2) q / (q - exp(-i theta)) ], theta = 2 pi x / h, for every lane (it
   // is negligible where x^2 exceeds the per-cell bound cq, and harmless there):
@@ -625,6 +628,11 @@ struct CellLine {
   double a = 0.0;      // h / (k T) [1/Hz]
   double E0 = 0.0;     // exp(-a nu_ref)
   double q = -1.0, cq = 0.0;   // pole-term constants (see voigt_rew)
+  // the forms the wave-uniform channel loop reads (one fma each instead of sub + mul and of
+  // the five-instruction stimulated-emission tail):
+  double c1 = 0.0;     // -nu0 * is2:  x = nu * is2 + c1
+  double A = 0.0;      // C (1 - E0):  C (1 - E0 (1 - a dnu)) = A + B dnu
+  double B = 0.0;      // C E0 a
 };
 
 template <typename T, bool BURSTS, bool CEN>
@@ -650,6 +658,9 @@ __device__ __forceinline__ CellLine cell_line(const RrlFields<T>& f, int64_t o,
   c.C = ln.kappa0 * (ne * ne / (Tk * sqrt(Tk))) * exp(ln.en_over_k / Tk) *
         (ln.path0 * pf) / (sigma * 2.5066282746310002);
   c.E0 = exp(-c.a * ln.nu_ref);
+  c.c1 = -c.nu0 * c.is2;
+  c.A = -c.C * expm1(-c.a * ln.nu_ref);
+  c.B = c.C * c.E0 * c.a;
   const double lnq = -2.0 * kPiOverH * c.y;
   c.q = (c.y < kPiOverH) ? exp(lnq) : -1.0;
   const double omq = -expm1(lnq);                                  // 1 - q
@@ -679,7 +690,8 @@ __device__ __forceinline__ int path_code(const CellLine& c, const double (&rg)[4
   double xmin = __builtin_inf(), xmax = 0.0;
 #pragma unroll
   for (int g = 0; g < 2; ++g) {
-    const double lo = (rg[2 * g] - c.nu0) * c.is2, hi = (rg[2 * g + 1] - c.nu0) * c.is2;
+    const double lo = __builtin_fma(rg[2 * g], c.is2, c.c1),
+                 hi = __builtin_fma(rg[2 * g + 1], c.is2, c.c1);
     if (!(rg[2 * g] <= rg[2 * g + 1])) continue;                  // no live lane in this run
     const double alo = fabs(lo), ahi = fabs(hi);
     xmin = fmin(xmin, (lo <= 0.0 && hi >= 0.0) ? 0.0 : fmin(alo, ahi));
@@ -715,22 +727,18 @@ __device__ __forceinline__ double line_term(const CellLine& c, double nu_f, doub
 }
 
 // Out of line: the cold generic path of the wave-uniform kernels must not cost their channel
-// loop registers.
-__device__ __attribute__((noinline)) double line_term_generic(double C, double nu0, double is2,
-                                                              double y, double a, double E0,
-                                                              double q, double cq, double nu_f,
-                                                              double dnu, double dnu_max) {
-  CellLine c;
-  c.C = C; c.nu0 = nu0; c.is2 = is2; c.y = y; c.a = a; c.E0 = E0;
-  // q and cq as staged belong to the wave-uniform lattice (h = 0.675); the generic code runs
-  // its own (h = 0.6, pole term kept down to 1e-13 Re w): as cell_line<.., CEN = false>
-  (void)q; (void)cq;
-  const double kPiOverH = 3.14159265358979323846 / kH;
-  const double lnq = -2.0 * kPiOverH * y;
-  c.q = (y < kPiOverH) ? exp(lnq) : -1.0;
-  c.cq = y * y + lnq + 1.7917594692280550 - 2.0 * log(-expm1(lnq)) - log(0.25 * y) +
-         29.9336062089226 + 4.2046926193909657;
-  return line_term<false>(c, nu_f, dnu, dnu_max, nullptr);
+// loop registers.  It takes nothing from the staged constants (they are stored in the forms
+// the fast paths read, and q / cq belong to the h = 0.675 lattice): the cell is evaluated
+// again from the fields with the generic code's own constants (h = 0.6, pole term kept down
+// to 1e-13 Re w), as cell_line<.., CEN = false>.
+template <typename T, bool BURSTS>
+__device__ __attribute__((noinline)) double line_term_generic(const RrlFields<T>& f, int64_t o,
+                                                              const BurstsDev& b, double time_s,
+                                                              const LineDev& ln, double nu_f,
+                                                              double dnu) {
+  const CellLine c = cell_line<T, BURSTS, false>(f, o, b, time_s, ln);
+  if (c.C == 0.0) return 0.0;
+  return line_term<false>(c, nu_f, dnu, ln.dnu_max, nullptr);
 }
 
 // collapse=False: the 3-D per-cell optical depths (classes.py:1176-1177, 1382-1383).  One
@@ -785,7 +793,13 @@ __global__ __launch_bounds__(kRB, RJP_K3_WAVES) void rrl_scan_kernel(
   __shared__ double s_tab[CEN ? kRB / RJP_WAVE : 1][RJP_WAVE];
   // path codes (one byte per wave of the channel block) and the waves' channel ranges
   constexpr int NWC = CEN ? LF / RJP_WAVE : 1;
-  __shared__ int s_code[CEN ? kRB : 1];
+  // one byte per (wave of the channel block, sightline of the tile, y-row of the slab), rows
+  // adjacent: a wave fetches the codes of eight rows with ONE 8-byte read and two
+  // readfirstlane, then shifts them out of an SGPR pair (it used to read, add an address and
+  // readfirstlane per evaluation)
+  static_assert(YC % 8 == 0, "eight codes per read");
+  __shared__ __attribute__((aligned(8))) uint8_t s_cb[CEN ? NWC * ZT * YC : 8];
+  __shared__ double s_ky[CEN ? kRB : 1];     // y h / pi of the wave-uniform lattice
   __shared__ double s_rng[NWC][4];
 
   const int ntz = (nz + ZT - 1) / ZT;
@@ -847,8 +861,7 @@ __global__ __launch_bounds__(kRB, RJP_K3_WAVES) void rrl_scan_kernel(
   }
 
   // (a scalar: the path code must reach the branches below as a wave-uniform value)
-  const int wsel = (CEN && LF > RJP_WAVE)
-                       ? __builtin_amdgcn_readfirstlane((tid / RJP_WAVE) * 8) : 0;
+  const int wq = (CEN && LF > RJP_WAVE) ? __builtin_amdgcn_readfirstlane(tid / RJP_WAVE) : 0;
 
   for (int yb = ya; yb < ye; yb += YC) {
     // ---- phase 1: per-cell line constants --------------------------------------------
@@ -860,16 +873,17 @@ __global__ __launch_bounds__(kRB, RJP_K3_WAVES) void rrl_scan_kernel(
                                                     time_s, ln);
       const double C = cl.C, nu0 = cl.nu0, is2 = cl.is2, yv = cl.y, a = cl.a, E0 = cl.E0,
                    q = cl.q, cq = cl.cq;
-      s_C[tid] = C; s_nu0[tid] = nu0; s_is2[tid] = is2; s_y[tid] = yv; s_a[tid] = a;
-      s_E0[tid] = E0; s_q[tid] = q; s_cq[tid] = cq;
+      // wave-uniform kernels stage the derived forms in the same slots: s_C <- A, s_nu0 <- c1,
+      // s_E0 <- B (the per-lane layouts keep the plain constants)
+      s_C[tid] = CEN ? cl.A : C; s_nu0[tid] = CEN ? cl.c1 : nu0; s_is2[tid] = is2; s_y[tid] = yv;
+      s_a[tid] = a; s_E0[tid] = CEN ? cl.B : E0; s_q[tid] = q; s_cq[tid] = cq;
       if constexpr (CEN) {
-        int code = 0;
+        s_ky[tid] = yv * (kHW / 3.14159265358979323846);
 #pragma unroll
         for (int w = 0; w < NWC; ++w) {
           const double rg[4] = {s_rng[w][0], s_rng[w][1], s_rng[w][2], s_rng[w][3]};
-          code |= path_code(cl, rg, ln.dnu_max) << (8 * w);
+          s_cb[(w * ZT + cz) * YC + cy] = (uint8_t)path_code(cl, rg, ln.dnu_max);
         }
-        s_code[tid] = code;
       }
     }
     __syncthreads();
@@ -880,39 +894,48 @@ __global__ __launch_bounds__(kRB, RJP_K3_WAVES) void rrl_scan_kernel(
       double acc = s_acc[j * kRB + tid];
       if constexpr (CEN) {
         // the wave works on ONE cell per trip: its path was decided in phase 1
+        const uint8_t* cb = s_cb + (wq * ZT + g * NZP + j) * YC;
+        uint32_t q_lo = 0, q_hi = 0;            // the codes of eight rows, in an SGPR pair
 #pragma unroll 1
         for (int r = 0; r < YC; ++r) {
           const int ci = r * ZT + g * NZP + j;
-          const int pc = (__builtin_amdgcn_readfirstlane(s_code[ci]) >> wsel) & 0xff;
+          if ((r & 7) == 0) {
+            const uint2 v = *reinterpret_cast<const uint2*>(cb + r);
+            q_lo = __builtin_amdgcn_readfirstlane(v.x);
+            q_hi = __builtin_amdgcn_readfirstlane(v.y);
+          }
+          const int pc = (int)(q_lo & 0xffu);
+          q_lo = (q_lo >> 8) | (q_hi << 24);
+          q_hi >>= 8;
           if (pc == kPathSkip) continue;
           const int path = pc & 7;
           if (path == kPathGeneric) {
             // irregular constants or absurd |x| beside core lanes: per-lane generic code,
             // NaN terms dropped as numpy.nansum does
-            // (for y < 0.03 the generic code takes its shifted lattice, which has its own
-            // pole-term test and does not read cq; above, cq is the plain-lattice bound)
             static_assert(kCenYMax == 0.03, "generic path assumes the centred bound ends at 0.03");
-            const double term = line_term_generic(s_C[ci], s_nu0[ci], s_is2[ci], s_y[ci], s_a[ci],
-                                                  s_E0[ci], s_q[ci], s_cq[ci], nu_f, dnu,
-                                                  ln.dnu_max);
+            const int64_t o = ((int64_t)x * ny + (yb + r)) * nz + (z0 + g * NZP + j);
+            const double term = line_term_generic<T, BURSTS>(f, o, b, time_s, ln, nu_f, dnu);
             if (term == term) acc += term;
             continue;
           }
           const double yv = s_y[ci];
-          const double ax = fabs((nu_f - s_nu0[ci]) * s_is2[ci]);
+          const double ax = fabs(__builtin_fma(nu_f, s_is2[ci], s_nu0[ci]));     // s_nu0 holds c1
           double V;
           if (path == kPathFarA) V = voigt_far_series<6>(ax, yv);
           else if (path == kPathFarB) V = voigt_far_series<4>(ax, yv);
-          else if (path == kPathPlain) V = voigt_plain_wave<false>(ax, yv, 0.0, ptop);
-          else if (path == kPathPlainPole) V = voigt_plain_wave<true>(ax, yv, s_q[ci], ptop);
-          else V = voigt_centred(ax, yv, s_q[ci], s_cq[ci], s_tab[tid / RJP_WAVE]);
-          // 1 - exp(-h nu / kT) = 1 - E0 * exp(-a (nu - nu_ref))
-          // (to first order in a dnu over the band unless the path code says otherwise)
-          const double eps = s_a[ci] * dnu;
-          double ex;
-          if (pc & kPathExpFlag) ex = exp(-eps);
-          else ex = 1.0 - eps;
-          acc = __builtin_fma(s_C[ci] * V, __builtin_fma(-s_E0[ci], ex, 1.0), acc);
+          else if (path == kPathPlain) V = voigt_plain_wave<false>(ax, yv, s_ky[ci], 0.0, ptop);
+          else if (path == kPathPlainPole) V = voigt_plain_wave<true>(ax, yv, s_ky[ci], s_q[ci], ptop);
+          else V = voigt_centred(ax, yv, s_ky[ci], s_q[ci], s_cq[ci], s_tab[tid / RJP_WAVE]);
+          // C V (1 - exp(-h nu / kT)) with 1 - exp(...) = 1 - E0 exp(-a (nu - nu_ref)); to first
+          // order in a dnu over the band (unless the path code says otherwise) that is
+          // V (A + B dnu), A = C (1 - E0), B = C E0 a staged per cell: two fmas
+          if (pc & kPathExpFlag) {
+            const double a = s_a[ci];
+            const double ce0 = s_E0[ci] / a;                  // C E0
+            acc = __builtin_fma(V, (s_C[ci] + ce0) - ce0 * exp(-a * dnu), acc);
+          } else {
+            acc = __builtin_fma(V, __builtin_fma(s_E0[ci], dnu, s_C[ci]), acc);
+          }
         }
       } else {
 #pragma unroll 1
