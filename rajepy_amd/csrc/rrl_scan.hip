@@ -17,8 +17,8 @@
 //            for its channel and accumulates tau in FP64; the per-(sightline, channel)
 //            accumulators live in LDS, so the sightline loop is not unrolled (< 128 VGPRs,
 //            4 waves per SIMD).  Cells outside the jet are skipped with a scalar branch.
-// Compute-bound (vector FP64) by construction -- 105 VALU instructions per (cell, channel) on
-// cfg3's fields (counted: profiles/r03c_cfg3_k3_sq.json), census in profiles/r03_k3_census.md; HBM traffic is 6 fields per cell, read
+// Compute-bound (vector FP64) by construction -- 102.5 VALU instructions per (cell, channel) on
+// cfg3's fields (counted: profiles/r03e_cfg3_k3_sq.json), census in profiles/r03_k3_census.md; HBM traffic is 6 fields per cell, read
 // once per block of 256 channels.
 //
 // Accuracy budget.  The wave-uniform paths (far-field series, plain lattice with or without the
@@ -28,7 +28,7 @@
 // (3.4e-9), 6- and 4-term far-field series (4.1e-9 / 1.2e-9), pole term skipped where a
 // rigorous bound puts it below 3e-8 Re w (measured <= 1.5e-9), centred lattice with 7 nodes a
 // side (7e-10); tools/voigt_design.py restates each path in NumPy and prints this table.
-// Rounds 1-2 held them to 1e-11 (h = 0.6, 10 pairs, 8/5 terms): 131 instead of ~105
+// Rounds 1-2 held them to 1e-11 (h = 0.6, 10 pairs, 8/5 terms): 131 instead of ~102
 // instructions.  The generic per-lane path (16-lane layout, collapse=False, irregular cells)
 // keeps h = 0.6 / 10 pairs / 1e-11.
 #include "rjp_host.h"
