@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
-"""Does K1's single-epoch time depend on WHERE the driver puts the fields?  Allocates the
-three compact fields of cfg4 several times in one process -- as three separate allocations,
-with perturbing allocations in between, and as slices of one arena -- and times the scan."""
+"""Does the RELATIVE placement of the two streams of the single-epoch scan (a0, ts) set its
+time?  At 512x4096x512 each field is exactly 2^33 bytes: buffers allocated back to back put
+a0[i] and ts[i] a power of two apart.  Here ts is copied into one large buffer at chosen byte
+offsets and the same scan is timed for each, in one process.
+    python tools/k1_placement_probe.py"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -13,6 +15,8 @@ from rajepy_amd import engine as E
 shape = bench.CONFIGS["cfg4"][0]
 n = shape[0] * shape[1] * shape[2]
 eng = E.RTEngine(0)
+fields = eng.synth_fields(shape, 20240504, 0, E.RJP_F64, csize_au=0.5, tau_mode=E.RJP_GFF_SCALAR,
+                          wide=False)
 ej = bench.EXAMPLE_BURSTS
 red, blue = [], []
 for t0, hl, chi, which in zip(ej["t_0"], ej["hl"], ej["chi"], ej["which"]):
@@ -21,33 +25,29 @@ for t0, hl, chi, which in zip(ej["t_0"], ej["hl"], ej["chi"], ej["which"]):
         if jet in str(which):
             lst.append((t0 * bench.YEAR, chi - 1., sig))
 bursts = E.make_bursts(red, blue)
-base = eng.synth_fields(shape, 20240504, 0, E.RJP_F64, csize_au=0.5, wide=False)
+ep = [1.0 * bench.YEAR]
+ts0 = fields.ts
+pad = (1 << 28) // 8                       # 256 MiB of slack, in doubles
+big = torch.empty(n + pad, dtype=torch.float64, device=eng.device)
+a_ptr = fields.a0.data_ptr()
 
 
-def run(tag, em0, temp, ts):
-    em0.copy_(base.em0); temp.copy_(base.temp); ts.copy_(base.ts)
-    f = E.DeviceFields(shape, E.RJP_F64, 0.5, None, None, temp, None, ts)
-    f.em0 = em0
-    eng.time_ff_scan(f, bursts, [bench.YEAR], E.RJP_GFF_SCALAR, reps=2)
-    ms = [eng.time_ff_scan(f, bursts, [bench.YEAR], E.RJP_GFF_SCALAR, reps=5) for _ in range(3)]
-    print("%-34s %.3f %.3f %.3f ms   ptr%%1GiB = %s" % (
-        tag, *ms, [hex(t.data_ptr() % (1 << 30)) for t in (em0, temp, ts)]), flush=True)
+def timed():
+    eng.time_ff_scan(fields, bursts, ep, E.RJP_GFF_SCALAR, reps=2, want_em=False, want_tavg=False)
+    return min(eng.time_ff_scan(fields, bursts, ep, E.RJP_GFF_SCALAR, reps=8, want_em=False,
+                                want_tavg=False) for _ in range(2))
 
 
-print("the synth fields themselves:", flush=True)
-run("synth (own allocations)", base.em0.clone(), base.temp.clone(), base.ts.clone())
-junk = []
-for trial in range(4):
-    bufs = [torch.empty(n, dtype=torch.float64, device=eng.device) for _ in range(3)]
-    run("separate allocations #%d" % trial, *bufs)
-    # perturb the allocator: keep an odd-sized block alive, drop the fields
-    junk.append(torch.empty((trial + 1) * 77777777, dtype=torch.uint8, device=eng.device))
-    del bufs
-    torch.cuda.empty_cache()
-for trial in range(3):
-    arena = torch.empty(3 * n + 3 * 4096, dtype=torch.float64, device=eng.device)
-    pad = trial * 512          # doubles between the fields: 0, 4 KiB, 8 KiB
-    run("one arena, gap %d B" % (pad * 8), arena[:n], arena[n + pad: 2 * n + pad],
-        arena[2 * n + 2 * pad: 3 * n + 2 * pad])
-    del arena
-    torch.cuda.empty_cache()
+fields.ts = ts0
+d = ts0.data_ptr() - a_ptr
+print("as allocated: ts - a0 = %d B = 2^33 * %.6f  (mod 2 MiB: %d, mod 4 KiB: %d): %.3f ms" % (
+    d, d / 2.0 ** 33, d % (1 << 21), d % 4096, timed()), flush=True)
+for off_bytes in (0, 256, 512, 1024, 2048, 4096, 8192, 16384, 65536, 262144, 1 << 20,
+                  (1 << 20) + 4096, 1 << 21, (1 << 21) + 2048, 1 << 24, (1 << 24) + 4096 + 256):
+    view = big[off_bytes // 8: off_bytes // 8 + n]
+    view.copy_(ts0)
+    fields.ts = view
+    fields.ts_range = fields._ts_range_of = None
+    d = view.data_ptr() - a_ptr
+    print("offset %9d B: ts - a0 mod 2^33 = %d (mod 2 MiB %7d, mod 4 KiB %4d): %.3f ms" % (
+        off_bytes, d % (1 << 33), d % (1 << 21), d % 4096, timed()), flush=True)
