@@ -22,14 +22,20 @@ for t0, hl, chi, which in zip(ej["t_0"], ej["hl"], ej["chi"], ej["which"]):
         if jet in str(which):
             lst.append((t0 * bench.YEAR, chi - 1., sig))
 bursts = E.make_bursts(red, blue)
+LAYOUT = os.environ.get("PROBE_LAYOUT", "tau")          # tau | compact | wide
+WANT_EM = os.environ.get("PROBE_EM") is not None
+if LAYOUT in ("compact", "wide"):
+    fields.a0 = None
+if LAYOUT == "wide":
+    fields.em0 = None
 ep = [1.0 * bench.YEAR]
 for rnd in range(2):
-    for ys in ("0", "1", "2", "3", "4", "6", "8", "12", "16"):
+    for ys in os.environ.get("PROBE_YS", "0,1,2,3,4,6,8,12,16").split(","):
         os.environ["RJP_YSPLIT"] = ys
         out = []
         for flag in (False, None):
             b = bursts if flag is not None else None
-            em = flag is None                      # the chi-free skeleton streams a0 + em0
+            em = flag is None or WANT_EM           # the chi-free skeleton streams a0 + em0
             eng.time_ff_scan(fields, b, ep, E.RJP_GFF_SCALAR, reps=2, want_em=em, want_tavg=False)
             out.append(eng.time_ff_scan(fields, b, ep, E.RJP_GFF_SCALAR, reps=8, want_em=em,
                                         want_tavg=False))
