@@ -775,9 +775,16 @@ def main(argv=None):
                              want_tavg=False)
             em_ms = eng.time_ff_scan(fields, wl.bursts, wl.my_epochs, wl.gmode, reps=3,
                                      want_em=True, want_tavg=False)
-            b3 = npass * 3 * ncell_loc * dsz + E_loc * P * 2 * 8
-            roof_extra["with_em"] = {"ms_per_launch": em_ms, "fields_streamed_per_cell": 3,
-                                     "algorithmic_bytes": b3,
+            em_path = eng.last_scan_path()[0]
+            if em_path == "moments":
+                # two moment passes: (a0, ts) for the optical-depth sums, (em0, ts) for the EM
+                b3 = 2 * 2 * ncell_loc * dsz + E_loc * P * 2 * 8
+                nf3 = "2 + 2 (two passes)"
+            else:
+                b3 = npass * 3 * ncell_loc * dsz + E_loc * P * 2 * 8
+                nf3 = 3
+            roof_extra["with_em"] = {"ms_per_launch": em_ms, "fields_streamed_per_cell": nf3,
+                                     "scan_path": em_path, "algorithmic_bytes": b3,
                                      "frac": b3 / (em_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
         if nfld < 5 and fields.nd is not None:
             # the 8(d) bytes are what the WIDE layout moves: time that kernel on the same

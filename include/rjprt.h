@@ -102,8 +102,8 @@ typedef struct rjp_fields {
   int32_t a0_mode;          /* enum rjp_gff_mode d_a0 was built for */
   int32_t reserved_;        /* 0 */
   /* Optional: the range of the finite launch times, [ts_lo, ts_hi] in seconds (rjp_field_range;
-   * both 0 = not provided).  With it, a tau-layout scan of >= 12 epochs without EM maps may take
-   * the MOMENT path: sum_y a0 chi(t_e - ts)^2 is a convolution of the sightline's launch-time
+   * both 0 = not provided).  With it, a tau-layout scan of >= 12 epochs (with EM maps: when
+   * d_em0 is attached -- a second pass takes the moments of em0) may take the MOMENT path: sum_y a0 chi(t_e - ts)^2 is a convolution of the sightline's launch-time
    * distribution with chi^2, so ONE pass over the grid accumulates per-sightline Chebyshev
    * moments of a0 over 32 launch-time bins and any number of epochs -- uniformly spaced or not --
    * becomes a small contraction.  The host checks the expansion against chi^2 for the call's

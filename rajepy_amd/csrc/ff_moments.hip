@@ -146,6 +146,7 @@ __global__ __launch_bounds__(kMomBS) void moments_kernel(const double* __restric
 __global__ __launch_bounds__(256) void moments_eval_kernel(const double* __restrict__ MT,
                                                            int64_t npix, int64_t npixp, int nidx,
                                                            const double* __restrict__ W, int ne,
+                                                           double scale,
                                                            double* __restrict__ sumA) {
   constexpr int ET = RJP_MOM_TILE, UI = 4;
   const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -166,7 +167,7 @@ __global__ __launch_bounds__(256) void moments_eval_kernel(const double* __restr
   }
 #pragma unroll
   for (int e = 0; e < ET; ++e)
-    if (e < ne) sumA[(int64_t)e * npix + p] = acc[e];
+    if (e < ne) sumA[(int64_t)e * npix + p] = acc[e] * scale;      // (scale == 1: exact)
 }
 
 // ---- per-block min / max of a field, NaN ignored (rjp_field_range) -----------------------------
@@ -279,8 +280,9 @@ bool moments_plan(const rjp_fields* fl, const rjp_bursts* hb, const double* epoc
                   int mode, bool want_em, size_t work_bytes, MomPlan& mp) {
   mp.ok = false;
   if (!hb || (hb->n[0] <= 0 && hb->n[1] <= 0)) return false;
-  if (want_em || n_epochs < RJP_MOM_MIN_EPOCHS) return false;
-  if (scan_layout(fl, mode, false) != 2 /* LAY_TAU */ || !fl->d_ts) return false;
+  if (n_epochs < RJP_MOM_MIN_EPOCHS) return false;
+  // (with EM maps: the tau layout with its em0 field attached -- a second pass weighs by em0)
+  if (scan_layout(fl, mode, want_em) != 2 /* LAY_TAU */ || !fl->d_ts) return false;
   if (!(fl->ts_hi >= fl->ts_lo) || !std::isfinite(fl->ts_lo) || !std::isfinite(fl->ts_hi) ||
       (fl->ts_lo == 0.0 && fl->ts_hi == 0.0))
     return false;                                               // range not provided
@@ -300,9 +302,12 @@ bool moments_plan(const rjp_fields* fl, const rjp_bursts* hb, const double* epoc
     const double dt = n_epochs > 1 ? (epochs[n_epochs - 1] - epochs[0]) / (n_epochs - 1) : 0.0;
     for (int e = 0; e < n_epochs && uniform; ++e)
       uniform = std::fabs(epochs[e] - (epochs[0] + e * dt)) <= 1e-9 * std::fabs(dt);
-    const double t_tiles = cells * n_epochs * (uniform ? 0.40e-12 : 0.93e-12);
-    const double t_mom = cells * 4.7e-12 +
-                         npix * (3.6e-9 + 1.1e-9 * ((n_epochs + RJP_MOM_TILE - 1) / RJP_MOM_TILE));
+    // (EM maps: a second moment pass + contraction; the tiles carry a third field and a
+    // second set of sums: 0.51 ps per pair in the 32-epoch recurrence on cfg5's grid)
+    const double t_tiles = cells * n_epochs * (uniform ? 0.40e-12 : 0.93e-12) * (want_em ? 1.25 : 1.0);
+    const double t_mom = (cells * 4.7e-12 +
+                          npix * (3.6e-9 + 1.1e-9 * ((n_epochs + RJP_MOM_TILE - 1) / RJP_MOM_TILE))) *
+                         (want_em ? 2.0 : 1.0);
     if (!(t_mom < 0.8 * t_tiles)) return false;
   }
   // same request as last time?
@@ -346,8 +351,8 @@ bool moments_plan(const rjp_fields* fl, const rjp_bursts* hb, const double* epoc
 }
 
 template <int K, int N>
-static hipError_t moments_pass(const rjp_fields* fl, const MomDev& md, int64_t npix, int64_t npixp,
-                               double* ws, hipStream_t st) {
+static hipError_t moments_pass(const rjp_fields* fl, const double* weights, const MomDev& md,
+                               int64_t npix, int64_t npixp, double* ws, hipStream_t st) {
   const size_t shm = (size_t)2 * K * N * kMomSL * sizeof(double);
   // (more than 64 KB of dynamic LDS must be allowed explicitly, once per device of the process)
   static int attr_dev = -1;
@@ -361,28 +366,32 @@ static hipError_t moments_pass(const rjp_fields* fl, const MomDev& md, int64_t n
     attr_dev = dev;
   }
   hipLaunchKernelGGL((moments_kernel<K, N>), dim3((unsigned)(npixp / kMomSL)), dim3(kMomBS), shm,
-                     st, (const double*)fl->d_a0, (const double*)fl->d_ts, fl->d_ylo, fl->d_yhi,
+                     st, weights, (const double*)fl->d_ts, fl->d_ylo, fl->d_yhi,
                      fl->ny, fl->nz, npix, npixp, md, ws);
   return hipGetLastError();
 }
 
+// `weights` = the field whose launch-time moments are taken (a0 for the optical-depth sums,
+// em0 for the emission measure: both carry the jet flag in their sign bit), `scale` = the
+// constant factor of the result (1 for the sums of a0).
 hipError_t moments_run(const rjp_fields* fl, const MomPlan& mp, const double* d_W, int n_epochs,
-                       double* sumA, double* ws, hipStream_t st) {
+                       double* sumA, double* ws, hipStream_t st, const double* weights,
+                       double scale) {
   const int64_t npix = (int64_t)fl->nx * fl->nz;
   const int64_t npixp = (npix + kMomSL - 1) / kMomSL * kMomSL;
   MomDev md;
   md.s0 = mp.s0; md.inv_h = mp.inv_h;
   md.has_bursts[0] = mp.has_bursts[0]; md.has_bursts[1] = mp.has_bursts[1];
   hipError_t err = hipErrorInvalidValue;
-  if (mp.K == 80 && mp.N == 8) err = moments_pass<80, 8>(fl, md, npix, npixp, ws, st);
-  else if (mp.K == 53 && mp.N == 12) err = moments_pass<53, 12>(fl, md, npix, npixp, ws, st);
-  else if (mp.K == 39 && mp.N == 16) err = moments_pass<39, 16>(fl, md, npix, npixp, ws, st);
+  if (mp.K == 80 && mp.N == 8) err = moments_pass<80, 8>(fl, weights, md, npix, npixp, ws, st);
+  else if (mp.K == 53 && mp.N == 12) err = moments_pass<53, 12>(fl, weights, md, npix, npixp, ws, st);
+  else if (mp.K == 39 && mp.N == 16) err = moments_pass<39, 16>(fl, weights, md, npix, npixp, ws, st);
   if (err != hipSuccess) return err;
   const int nidx = 2 * mp.K * mp.N;
   for (int c = 0; c < mp.nchunk; ++c) {
     const int ne = std::min(RJP_MOM_TILE, n_epochs - c * RJP_MOM_TILE);
     hipLaunchKernelGGL(moments_eval_kernel, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, st,
-                       ws, npix, npixp, nidx, d_W + (size_t)c * nidx * RJP_MOM_TILE, ne,
+                       ws, npix, npixp, nidx, d_W + (size_t)c * nidx * RJP_MOM_TILE, ne, scale,
                        sumA + (int64_t)c * RJP_MOM_TILE * npix);
     err = hipGetLastError();
     if (err != hipSuccess) return err;

@@ -75,7 +75,8 @@ size_t moments_workspace_bytes(int64_t npix);
 bool moments_plan(const rjp_fields* fl, const rjp_bursts* hb, const double* epochs, int n_epochs,
                   int mode, bool want_em, size_t work_bytes, MomPlan& mp);
 hipError_t moments_run(const rjp_fields* fl, const MomPlan& mp, const double* d_W, int n_epochs,
-                       double* sumA, double* ws, hipStream_t st);
+                       double* sumA, double* ws, hipStream_t st, const double* weights,
+                       double scale);
 hipError_t field_range_launch(const void* d_field, int64_t n, int dtype, double* d_part,
                               hipStream_t st);
 

@@ -348,8 +348,16 @@ int rjp_ff_scan(rjp_ctx* ctx, const rjp_fields* fields, const rjp_bursts* bursts
     const size_t len[1] = {ctx->mom.W.size()};
     double* dev[1];
     if (int r = stage_tables(ctx, st, src, len, 1, dev)) return r;
-    return finish_staged(ctx, st, rjp::moments_run(fields, ctx->mom, dev[0], n_epochs, d_sumA,
-                                                   (double*)d_work, st), "moments_run");
+    hipError_t e = rjp::moments_run(fields, ctx->mom, dev[0], n_epochs, d_sumA, (double*)d_work,
+                                    st, (const double*)fields->d_a0, 1.0);
+    if (e == hipSuccess && d_em) {
+      // the emission measure of every epoch: the same pass and tables with em0 as the weight
+      // (em = sum (n x)^2 * csize*au/pc * pf, classes.py:1116-1118)
+      const double em_scale = fields->csize_au * 149597870700.0 / 3.085677581491367e+16;
+      e = rjp::moments_run(fields, ctx->mom, dev[0], n_epochs, d_em, (double*)d_work, st,
+                           (const double*)fields->d_em0, em_scale);
+    }
+    return finish_staged(ctx, st, e, "moments_run");
   }
   ctx->last_path = 0;
   rjp::ScanPlan plan;

@@ -55,6 +55,20 @@ def _both(eng, f, bursts, ep, mode, **kw):
     return a.cpu().numpy(), b.cpu().numpy(), path
 
 
+def _both_em(eng, f, bursts, ep, mode):
+    """(sums, EM maps) by the moment path and by the tiles, EM maps asked for."""
+    eng.use_moments = True
+    a, ea, _ = eng.ff_scan(f, bursts, ep, mode, want_em=True, want_tavg=False)
+    a, ea = a.clone(), ea.clone()
+    path = eng.last_scan_path()
+    eng.use_moments = False
+    b, eb, _ = eng.ff_scan(f, bursts, ep, mode, want_em=True, want_tavg=False)
+    assert eng.last_scan_path()[0] == "tiles"
+    eng.use_moments = True
+    eng.synchronize()
+    return (a.cpu().numpy(), ea.cpu().numpy()), (b.cpu().numpy(), eb.cpu().numpy()), path
+
+
 @pytest.mark.parametrize("temp_mode", [0, 1])
 @pytest.mark.parametrize("years", [list(np.linspace(0., 5., 32)), list(np.linspace(0.3, 4.1, 12)),
                                    list(np.linspace(0., 5., 37)), list(np.linspace(0., 5., 100)),
@@ -79,12 +93,19 @@ def test_moments_agree_with_the_epoch_tiles_and_the_oracle(eng, temp_mode, years
     mom, til, (path, err) = _both(eng, f, bursts, ep, mode)
     assert path == "moments" and 0 < err <= 1e-11
     np.testing.assert_allclose(mom, til, rtol=RTOL)
+    # with the emission-measure maps of every epoch: a second pass takes the moments of em0
+    (mom2, em_m), (til2, em_t), (path2, _) = _both_em(eng, f, bursts, ep, mode)
+    assert path2 == "moments"
+    np.testing.assert_allclose(mom2, til2, rtol=RTOL)
+    np.testing.assert_allclose(em_m, em_t, rtol=RTOL)
     gv = [ph.gff(5e9, p["properties"]["T_0"])] if temp_mode == 0 else None
     ctau, _ = E.ff_channel_coeffs([5e9], jet.csize, p["target"]["dist"], mode, gv)
     for e in (0, len(ep) // 2, len(ep) - 1):
         jet.time = ep[e]
         np.testing.assert_allclose(ctau[0] * mom[e].reshape(shape[0], shape[2]),
                                    jet.optical_depth_ff(5e9), rtol=1e-10)
+        np.testing.assert_allclose(em_m[e].reshape(shape[0], shape[2]), jet.emission_measure(),
+                                   rtol=1e-10)
 
 
 @pytest.mark.parametrize("hl_scale,shape_kn", [(2.5, (80, 8)), (1.0, (53, 12)), (0.8, (39, 16))])
@@ -152,8 +173,8 @@ def test_moments_keep_nan_semantics_y_ranges_and_the_burstless_jet(eng):
 
 def test_sweeps_the_expansion_cannot_serve_run_the_tiles(eng):
     """(a) a burst far narrower than a launch-time bin: the host's accuracy check refuses the
-    tables and the tiles run -- the result is the tiles' bit for bit; (b) EM maps asked for,
-    (c) fewer than 12 epochs, (d) no launch-time range in the struct: tiles as well."""
+    tables and the tiles run -- the result is the tiles' bit for bit; (b) EM maps asked for
+    without the em0 field, (c) fewer than 12 epochs, (d) no launch-time range in the struct: tiles as well."""
     from rajepy_amd import engine as E
     shape = (4, 64, 32)
     ej = {"t_0": np.array([1.0, 2.0]), "hl": np.array([0.004, 0.3]), "chi": np.array([6., 3.]),
@@ -169,7 +190,11 @@ def test_sweeps_the_expansion_cannot_serve_run_the_tiles(eng):
     wide = E.make_bursts([(1.0 * orc.YEAR, 4., 0.2 * orc.YEAR)], [(2.0 * orc.YEAR, 2., 0.3 * orc.YEAR)])
     assert _both(eng, f, wide, ep, E.RJP_GFF_SCALAR)[2][0] == "moments"
     eng.ff_scan(f, wide, ep, E.RJP_GFF_SCALAR, want_em=True, want_tavg=False)
-    assert eng.last_scan_path()[0] == "tiles"
+    assert eng.last_scan_path()[0] == "moments"       # em0 is attached: two moment passes
+    em0, f.em0 = f.em0, None
+    eng.ff_scan(f, wide, ep, E.RJP_GFF_SCALAR, want_em=True, want_tavg=False)
+    assert eng.last_scan_path()[0] == "tiles"         # EM maps without em0: the wide layout
+    f.em0 = em0
     eng.ff_scan(f, wide, ep[:11], E.RJP_GFF_SCALAR, want_em=False, want_tavg=False)
     assert eng.last_scan_path()[0] == "tiles"
     f.ts_range = None
