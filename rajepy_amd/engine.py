@@ -257,7 +257,7 @@ class RTEngine:
 
     def launch_time_range(self, fields):
         """(min, max) of the finite launch times of `fields` (rjp_field_range), measured once
-        per `ts` tensor: with it, scans of >= 12 epochs without EM maps on the tau layout may
+        per `ts` tensor: with it, scans of >= 12 epochs on the tau layout (EM maps: with em0) may
         take the moment path (include/rjprt.h `rjp_fields.ts_lo`)."""
         if fields.ts is None:
             return None
