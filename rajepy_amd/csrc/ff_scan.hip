@@ -182,6 +182,56 @@ __global__ __launch_bounds__(kBlock) void ff_maps_kernel(
   }
 }
 
+// Light curves (no cube is written): the per-channel totals alone.  The map kernel above pays a
+// six-step wave reduction per channel and pixel pair -- a quarter of its instructions once
+// there is nothing to store; here a lane walks kFtotKP pixel groups for up to kFtotFC channels
+// with one accumulator per channel in registers, and the wave reduction comes once per channel
+// and lane.  Same arithmetic per (pixel, channel); sums in a fixed order.
+constexpr int kFtotKP = 4;       // pixel groups per lane
+constexpr int kFtotFC = 16;      // channels per workgroup (gridDim.z slices the channel axis)
+template <int VEC>
+__global__ __launch_bounds__(kBlock) void ff_ftot_kernel(
+    const double* __restrict__ sumA, const double* __restrict__ tavg, int64_t npix,
+    const double* __restrict__ ctau, const double* __restrict__ cflux, int nchan,
+    double* __restrict__ part, int nparts) {
+  const int e = blockIdx.y;
+  const int f0 = blockIdx.z * kFtotFC;
+  const int nf = min(nchan - f0, kFtotFC);
+  double acc[kFtotFC];
+#pragma unroll
+  for (int j = 0; j < kFtotFC; ++j) acc[j] = 0.0;
+#pragma unroll 1
+  for (int k = 0; k < kFtotKP; ++k) {
+    const int64_t p = (((int64_t)blockIdx.x * kFtotKP + k) * kBlock + threadIdx.x) * VEC;
+    if (p >= npix) continue;                       // npix % VEC == 0
+    double A[VEC], ta[VEC];
+    load_plain(sumA + (int64_t)e * npix + p, A);
+    load_plain(tavg + p, ta);
+#pragma unroll
+    for (int j = 0; j < kFtotFC; ++j) {
+      if (j < nf) {
+        const double ct = ctau[f0 + j], cf = cflux[f0 + j];
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) {
+          const double s = cf * (ta[v] * one_minus_exp_neg(ct * A[v]));
+          acc[j] += s == s ? s : 0.0;              // nansum
+        }
+      }
+    }
+  }
+  const int slot = blockIdx.x * (kBlock / RJP_WAVE) + threadIdx.x / RJP_WAVE;
+#pragma unroll
+  for (int j = 0; j < kFtotFC; ++j) {
+    if (j < nf) {
+      double a = acc[j];
+#pragma unroll
+      for (int d = RJP_WAVE / 2; d > 0; d >>= 1) a += __shfl_down(a, d, RJP_WAVE);
+      if ((threadIdx.x & (RJP_WAVE - 1)) == 0)
+        part[((int64_t)e * nchan + f0 + j) * nparts + slot] = a;
+    }
+  }
+}
+
 // sums the per-block partials of one (epoch, channel) in a fixed order
 __global__ __launch_bounds__(kBlock) void sum_partials_kernel(const double* __restrict__ part,
                                                               int nblk,
@@ -647,6 +697,21 @@ hipError_t ff_maps_launch(const double* sumA, const double* tavg, int64_t npix, 
     if (q && ((uintptr_t)q % 16) != 0) vec2 = false;
   const int vec = vec2 ? 2 : 1;
   const int64_t lanes = npix / vec;
+  if (!tau && !flux && ftot) {
+    // totals only (light curves): the register-accumulator kernel
+    const unsigned nb = (unsigned)((lanes + (int64_t)kBlock * kFtotKP - 1) / ((int64_t)kBlock * kFtotKP));
+    const int np = (int)nb * (kBlock / RJP_WAVE);
+    dim3 g(nb, (unsigned)n_epochs, (unsigned)((n_chan + kFtotFC - 1) / kFtotFC));
+    if (vec2)
+      hipLaunchKernelGGL(ff_ftot_kernel<2>, g, dim3(kBlock), 0, st, sumA, tavg, npix, d_ctau,
+                         d_cflux, n_chan, part, np);
+    else
+      hipLaunchKernelGGL(ff_ftot_kernel<1>, g, dim3(kBlock), 0, st, sumA, tavg, npix, d_ctau,
+                         d_cflux, n_chan, part, np);
+    hipError_t e0 = hipGetLastError();
+    if (e0 != hipSuccess) return e0;
+    return sum_partials_launch(part, n_epochs * n_chan, np, ftot, st);
+  }
   const unsigned nblk = (unsigned)((lanes + kBlock - 1) / kBlock);
   const int nparts = (int)nblk * (kBlock / RJP_WAVE);
   // split channels over gridDim.z so that small maps still expose >= ~2048 blocks
