@@ -26,7 +26,7 @@ __global__ void fill(double* a0, double* ts, size_t n, int nz) {
 }
 
 // SL sightlines per workgroup (z-adjacent), 256 threads: thread = (sightline, y-row offset)
-template <int K, int N, int SL, int U, int BS, int JETS = 2, bool PF = false>
+template <int K, int N, int SL, int U, int BS, int JETS = 2, bool PF = false, bool PAIR = false>
 __global__ __launch_bounds__(BS) void moments(const double* __restrict__ a0, const double* __restrict__ ts,
                                                int ny, int nz, double s0, double inv_h,
                                                double* __restrict__ MT, size_t npix) {
@@ -36,7 +36,10 @@ __global__ __launch_bounds__(BS) void moments(const double* __restrict__ a0, con
   __syncthreads();
   const int sl = threadIdx.x % SL, yr = threadIdx.x / SL;
   constexpr int YR = BS / SL;
-  const size_t p = (size_t)blockIdx.x * SL + sl;
+  // PAIR: tiles 2k and 2k+1 (the two 64-byte halves of a row's 128-byte lines when SL = 8) go to
+  // workgroups b and b + 8 -- the same XCD, launched together: the second half hits in L2
+  const unsigned bid = PAIR ? ((blockIdx.x % 8) * 2 + (blockIdx.x / 8) % 2 + 16 * (blockIdx.x / 16)) : blockIdx.x;
+  const size_t p = (size_t)bid * SL + sl;
   const size_t x = p / nz;
   const int z = (int)(p - x * nz);
   const size_t col = x * (size_t)ny * nz + z;
@@ -105,7 +108,7 @@ __global__ __launch_bounds__(BS) void moments(const double* __restrict__ a0, con
   // flush, transposed: MT[idx][p]
   for (int i = threadIdx.x; i < TOT; i += BS) {
     const int idx = i / SL, s = i % SL;
-    MT[(size_t)idx * npix + (size_t)blockIdx.x * SL + s] = lds[i];
+    MT[(size_t)idx * npix + (size_t)(PAIR ? ((blockIdx.x % 8) * 2 + (blockIdx.x / 8) % 2 + 16 * (blockIdx.x / 16)) : blockIdx.x) * SL + s] = lds[i];
   }
 }
 
@@ -155,16 +158,16 @@ static void run_eval(const double* MT, size_t npix, int kn2, const double* W, do
   printf("eval UI=%d PP=%d kn2=%d: %.3f ms\n", UI, PP, kn2, best);
 }
 
-template <int K, int N, int SL, int U, int BS, int JETS = 2, bool PF = false>
+template <int K, int N, int SL, int U, int BS, int JETS = 2, bool PF = false, bool PAIR = false>
 static void run(const double* a0, const double* ts, int nx, int ny, int nz, double* MT, double* W, double* out) {
   const size_t npix = (size_t)nx * nz;
   const size_t shm = (size_t)JETS * K * N * SL * sizeof(double);
-  CK(hipFuncSetAttribute((const void*)moments<K, N, SL, U, BS, JETS, PF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
+  CK(hipFuncSetAttribute((const void*)moments<K, N, SL, U, BS, JETS, PF, PAIR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   float best = 1e30f, best2 = 1e30f;
   for (int rep = 0; rep < 4; ++rep) {
     CK(hipEventRecord(e0));
-    hipLaunchKernelGGL((moments<K, N, SL, U, BS, JETS, PF>), dim3((unsigned)(npix / SL)), dim3(BS), shm, 0, a0, ts, ny, nz, 0.0, K / 5.0, MT, npix);
+    hipLaunchKernelGGL((moments<K, N, SL, U, BS, JETS, PF, PAIR>), dim3((unsigned)(npix / SL)), dim3(BS), shm, 0, a0, ts, ny, nz, 0.0, K / 5.0, MT, npix);
     CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
     float ms; CK(hipEventElapsedTime(&ms, e0, e1)); if (ms < best) best = ms;
     CK(hipEventRecord(e0));
@@ -174,7 +177,7 @@ static void run(const double* a0, const double* ts, int nx, int ny, int nz, doub
   }
   CK(hipGetLastError());
   const double gb = (double)nx * ny * nz * 16 / 1e9;
-  printf("BS=%d JETS=%d PF=%d ", BS, JETS, (int)PF); printf("K=%d N=%d SL=%d U=%d  LDS %zu KB: moments %.3f ms (%.0f GB/s of a0+ts)  eval(32 epochs) %.3f ms\n",
+  printf("BS=%d JETS=%d PF=%d PAIR=%d ", BS, JETS, (int)PF, (int)PAIR); printf("K=%d N=%d SL=%d U=%d  LDS %zu KB: moments %.3f ms (%.0f GB/s of a0+ts)  eval(32 epochs) %.3f ms\n",
          K, N, SL, U, shm / 1024, best, gb / best * 1e3, best2);
 }
 
@@ -188,14 +191,12 @@ int main() {
   CK(hipMalloc(&out, 32 * npix * 8));
   hipLaunchKernelGGL(fill, dim3(8192), dim3(256), 0, 0, a0, ts, n, nz);
   CK(hipDeviceSynchronize());
-  run<32, 16, 16, 4, 1024, 2, true>(a0, ts, nx, ny, nz, MT, W, out);
-  run_eval<1, 1>(MT, npix, 1024, W, out);
-  run_eval<4, 1>(MT, npix, 1024, W, out);
-  run_eval<8, 1>(MT, npix, 1024, W, out);
-  run_eval<16, 1>(MT, npix, 1024, W, out);
-  run_eval<4, 2>(MT, npix, 1024, W, out);
-  run_eval<8, 2>(MT, npix, 1024, W, out);
-  run_eval<8, 1>(MT, npix, 1272, W, out);
+  run<53, 12, 16, 4, 1024, 2, true>(a0, ts, nx, ny, nz, MT, W, out);
+  run<53, 12, 8, 4, 512, 2, true>(a0, ts, nx, ny, nz, MT, W, out);
+  run<53, 12, 8, 4, 512, 2, true, true>(a0, ts, nx, ny, nz, MT, W, out);
+  run<53, 12, 8, 8, 512, 2, true, true>(a0, ts, nx, ny, nz, MT, W, out);
+  run<53, 12, 8, 4, 256, 2, true, true>(a0, ts, nx, ny, nz, MT, W, out);
+  run<39, 16, 8, 4, 512, 2, true, true>(a0, ts, nx, ny, nz, MT, W, out);
   // sanity: total of the zeroth moments == sum |a0|
   std::vector<double> h(npix);
   CK(hipMemcpy(h.data(), MT, npix * 8, hipMemcpyDeviceToHost));
