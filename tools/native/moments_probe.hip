@@ -181,6 +181,95 @@ static void run(const double* a0, const double* ts, int nx, int ny, int nz, doub
          K, N, SL, U, shm / 1024, best, gb / best * 1e3, best2);
 }
 
+
+// mixed precision: orders n < NS are accumulated in f64, the higher ones (whose coefficients
+// decay geometrically) in f32 -- half the LDS cycles and bytes each
+template <int K, int N, int NS, int SL, int U, int BS>
+__global__ __launch_bounds__(BS) void moments_mixed(const double* __restrict__ a0, const double* __restrict__ ts,
+                                                    int ny, int nz, double s0, double inv_h,
+                                                    double* __restrict__ MT, size_t npix) {
+  extern __shared__ double lds[];          // [2][K][NS][SL] doubles, then [2][K][N-NS][SL] floats
+  constexpr int TOTD = 2 * K * NS * SL, TOTF = 2 * K * (N - NS) * SL;
+  float* ldsf = reinterpret_cast<float*>(lds + TOTD);
+  for (int i = threadIdx.x; i < TOTD; i += BS) lds[i] = 0.0;
+  for (int i = threadIdx.x; i < TOTF; i += BS) ldsf[i] = 0.0f;
+  __syncthreads();
+  const int sl = threadIdx.x % SL, yr = threadIdx.x / SL;
+  constexpr int YR = BS / SL;
+  const size_t p = (size_t)blockIdx.x * SL + sl;
+  const size_t x = p / nz;
+  const int z = (int)(p - x * nz);
+  const size_t col = x * (size_t)ny * nz + z;
+  auto cell = [&](double av, double tv) __attribute__((always_inline)) {
+      const bool red = av < 0.0;
+      const double am = fmax(fabs(av), 0.0);
+      const double w = (tv - s0) * inv_h;
+      double kf = floor(w);
+      kf = fmin(fmax(kf, 0.0), (double)(K - 1));
+      const double xi = 2.0 * (w - kf) - 1.0;
+      const int bin = (red ? 0 : K) + (int)kf;
+      double* based = lds + (bin * NS) * SL + sl;
+      float* basef = ldsf + (bin * (N - NS)) * SL + sl;
+      double tm = 1.0, tc = xi;
+      atomicAdd(based, am);
+      atomicAdd(based + SL, am * tc);
+      const double x2 = 2.0 * xi;
+#pragma unroll
+      for (int n = 2; n < N; ++n) {
+        const double tn = __builtin_fma(x2, tc, -tm);
+        tm = tc; tc = tn;
+        if (n < NS) atomicAdd(based + n * SL, am * tn);
+        else atomicAdd(basef + (n - NS) * SL, (float)(am * tn));
+      }
+  };
+  double a[U], t[U], an[U], tn_[U];
+  auto fetch = [&](double (&aa)[U], double (&tt)[U], int yb) __attribute__((always_inline)) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int y = yb + u * YR;
+      const int yc = y < ny ? y : ny - 1;
+      aa[u] = __builtin_nontemporal_load(a0 + col + (size_t)yc * nz);
+      tt[u] = __builtin_nontemporal_load(ts + col + (size_t)yc * nz);
+    }
+  };
+  fetch(a, t, yr);
+  for (int y0 = yr; y0 < ny; y0 += 2 * YR * U) {
+    fetch(an, tn_, y0 + YR * U);
+#pragma unroll
+    for (int u = 0; u < U; ++u) cell((y0 + u * YR < ny) ? a[u] : 0.0, t[u]);
+    fetch(a, t, y0 + 2 * YR * U);
+#pragma unroll
+    for (int u = 0; u < U; ++u) cell((y0 + YR * U + u * YR < ny) ? an[u] : 0.0, tn_[u]);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < TOTD; i += BS) {
+    const int idx = i / SL, s = i % SL;
+    MT[(size_t)idx * npix + (size_t)blockIdx.x * SL + s] = lds[i];
+  }
+  float* MTF = reinterpret_cast<float*>(MT + (size_t)2 * K * NS * npix);
+  for (int i = threadIdx.x; i < TOTF; i += BS) {
+    const int idx = i / SL, s = i % SL;
+    MTF[(size_t)idx * npix + (size_t)blockIdx.x * SL + s] = ldsf[i];
+  }
+}
+
+template <int K, int N, int NS, int SL, int U, int BS>
+static void run_mixed(const double* a0, const double* ts, int nx, int ny, int nz, double* MT) {
+  const size_t npix = (size_t)nx * nz;
+  const size_t shm = (size_t)2 * K * NS * SL * 8 + (size_t)2 * K * (N - NS) * SL * 4;
+  CK(hipFuncSetAttribute((const void*)moments_mixed<K, N, NS, SL, U, BS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
+  hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  float best = 1e30f;
+  for (int rep = 0; rep < 4; ++rep) {
+    CK(hipEventRecord(e0));
+    hipLaunchKernelGGL((moments_mixed<K, N, NS, SL, U, BS>), dim3((unsigned)(npix / SL)), dim3(BS), shm, 0, a0, ts, ny, nz, 0.0, K / 5.0, MT, npix);
+    CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1)); if (ms < best) best = ms;
+  }
+  CK(hipGetLastError());
+  printf("mixed K=%d N=%d (f64 orders %d, f32 orders %d) SL=%d U=%d BS=%d LDS %zu KB: moments %.3f ms\n", K, N, NS, N - NS, SL, U, BS, shm / 1024, best);
+}
+
 int main() {
   const int nx = 512, ny = 4096, nz = 512;
   const size_t n = (size_t)nx * ny * nz, npix = (size_t)nx * nz;
@@ -197,6 +286,11 @@ int main() {
   run<53, 12, 8, 8, 512, 2, true, true>(a0, ts, nx, ny, nz, MT, W, out);
   run<53, 12, 8, 4, 256, 2, true, true>(a0, ts, nx, ny, nz, MT, W, out);
   run<39, 16, 8, 4, 512, 2, true, true>(a0, ts, nx, ny, nz, MT, W, out);
+  run_mixed<53, 12, 12, 16, 4, 1024>(a0, ts, nx, ny, nz, MT);
+  run_mixed<53, 12, 6, 16, 4, 1024>(a0, ts, nx, ny, nz, MT);
+  run_mixed<53, 12, 4, 16, 4, 1024>(a0, ts, nx, ny, nz, MT);
+  run_mixed<64, 12, 5, 16, 4, 1024>(a0, ts, nx, ny, nz, MT);
+  run_mixed<53, 12, 5, 16, 4, 512>(a0, ts, nx, ny, nz, MT);
   // sanity: total of the zeroth moments == sum |a0|
   std::vector<double> h(npix);
   CK(hipMemcpy(h.data(), MT, npix * 8, hipMemcpyDeviceToHost));
