@@ -105,8 +105,9 @@ typedef struct rjp_fields {
    * both 0 = not provided).  With it, a tau-layout scan of >= 12 epochs (with EM maps: when
    * d_em0 is attached -- a second pass takes the moments of em0) may take the MOMENT path: sum_y a0 chi(t_e - ts)^2 is a convolution of the sightline's launch-time
    * distribution with chi^2, so ONE pass over the grid accumulates per-sightline Chebyshev
-   * moments of a0 over 32 launch-time bins and any number of epochs -- uniformly spaced or not --
-   * becomes a small contraction.  The host checks the expansion against chi^2 for the call's
+   * moments of a0 over K launch-time bins of order N -- (K, N) one of (80, 8), (53, 12), (39, 16),
+   * the cheapest the host's accuracy check accepts -- and any number of epochs, uniformly spaced or
+   * not, becomes a small contraction.  The host checks the expansion against chi^2 for the call's
    * bursts and epochs and uses the path only when every coefficient table is good to 1e-11
    * relative AND a cost model says it is the faster one (long, densely filled sightlines; else
    * the epoch tiles run, as before); sums are reproducible to rounding, not bit
@@ -116,7 +117,7 @@ typedef struct rjp_fields {
   /* Optional hint for the choice between the epoch tiles and the moment path: the number of
    * cells inside the occupied y-ranges, sum_p max(0, d_yhi[p] - d_ylo[p]) (0 = unknown: all
    * n_x n_y n_z cells are assumed to matter).  The tiles' cost scales with it, the moment
-   * path's per-sightline costs (8 KiB of moments written and read back) do not: a sparse jet
+   * path's per-sightline costs (2 K N doubles of moments, <= 10 KiB, written and read back) do not: a sparse jet
    * keeps the tiles.  A negative value skips the cost model (tests: the moment path on grids it
    * would not pay for). */
   int64_t occupied_cells;

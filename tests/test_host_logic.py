@@ -53,15 +53,131 @@ def test_abi_exports_every_declared_symbol():
         assert hasattr(lib, name)
 
 
-def test_abi_struct_layouts_match_header():
-    assert ctypes.sizeof(_lib.Fields) == 6 * 8 + 4 * 4 + 8 + 3 * 8 + 8 + 2 * 4 + 2 * 8 + 8
-    assert _lib.Fields.ts_lo.offset == _lib.Fields.d_a0.offset + 16       # appended again (105)
-    assert _lib.Fields.d_a0.offset == 6 * 8 + 4 * 4 + 8 + 3 * 8      # appended: ABI 103 prefix kept
-    assert _lib.Fields.a0_mode.offset == _lib.Fields.d_a0.offset + 8
-    assert ctypes.sizeof(_lib.Bursts) == 8 + 3 * 2 * 8            # counts + 6 host pointers
-    assert ctypes.sizeof(_lib.Line) == 6 * 8
-    assert ctypes.sizeof(_lib.Geometry) == 4 * 4 + 24 * 8 + 2 * 4
-    assert _lib.Geometry.rb_frac.offset == 4 * 4 + 23 * 8
+_ABI_STRUCTS = {"rjp_fields": "Fields", "rjp_bursts": "Bursts", "rjp_line": "Line",
+                "rjp_geometry": "Geometry"}
+
+
+def _header_struct_members(hdr):
+    """{struct name: [member names in declaration order]} parsed from include/rjprt.h."""
+    out = {}
+    for m in re.finditer(r"typedef struct (rjp_\w+) \{(.*?)\}\s*\1;", hdr, re.S):
+        body = re.sub(r"/\*.*?\*/", "", m.group(2), flags=re.S)
+        names = []
+        for decl in body.split(";"):
+            decl = decl.strip()
+            if not decl:
+                continue
+            # "const void* d_nd" / "int32_t nx, ny, nz" / "const double* t0[2]"
+            first, *rest = decl.split(",")
+            names.append(re.search(r"(\w+)\s*(\[\d+\])?$", first.strip()).group(1))
+            names += [re.search(r"(\w+)", r).group(1) for r in rest]
+        out[m.group(1)] = names
+    return out
+
+
+def _compiled_layouts(tmp_path):
+    """sizeof / offsetof / member size of every struct of include/rjprt.h as the C++ compiler
+    lays them out: a small program generated from the HEADER's member list, built with g++."""
+    import shutil
+    import subprocess
+    hdr = open(os.path.join(ROOT, "include", "rjprt.h")).read()
+    members = _header_struct_members(hdr)
+    assert set(members) == set(_ABI_STRUCTS), members.keys()
+    lines = ['#include <cstdio>', '#include <cstddef>', '#include "rjprt.h"', "int main() {",
+             '  std::printf("{\\"version\\": %d", RJP_VERSION);']
+    for st, names in members.items():
+        lines.append('  std::printf(", \\"%s\\": {\\"sizeof\\": %%zu, \\"members\\": ["'
+                     ', sizeof(%s));' % (st, st))
+        for i, nm in enumerate(names):
+            lines.append('  std::printf("%s[\\"%s\\", %%zu, %%zu]", offsetof(%s, %s), '
+                         'sizeof(((%s*)0)->%s));' % (", " if i else "", nm, st, nm, st, nm))
+        lines.append('  std::printf("]}");')
+    lines += ['  std::printf("}\\n");', "  return 0;", "}"]
+    src = tmp_path / "abi_layout.cpp"
+    src.write_text("\n".join(lines))
+    cxx = shutil.which("g++") or shutil.which("c++") or shutil.which("hipcc")
+    assert cxx, "no C++ compiler"
+    exe = tmp_path / "abi_layout"
+    subprocess.run([cxx, "-std=c++17", "-I", os.path.join(ROOT, "include"), str(src), "-o",
+                    str(exe)], check=True)
+    return json.loads(subprocess.run([str(exe)], check=True, capture_output=True,
+                                     text=True).stdout)
+
+
+def _ctypes_layout(cls):
+    return [[n, getattr(cls, n).offset, getattr(cls, n).size] for n, _ in cls._fields_]
+
+
+def test_abi_struct_layouts_match_header_as_compiled(tmp_path):
+    """The ctypes structs of rajepy_amd/_lib.py against include/rjprt.h AS COMPILED: a C++
+    program generated from the header's own member list prints sizeof / offsetof / member
+    sizes; every member, in order, must sit where ctypes puts it (a member added to the header
+    and not to the binding -- or the reverse -- fails here, not on the GPU)."""
+    comp = _compiled_layouts(tmp_path)
+    assert comp["version"] == _lib.RJP_VERSION
+    for st, cname in _ABI_STRUCTS.items():
+        cls = getattr(_lib, cname)
+        assert comp[st]["sizeof"] == ctypes.sizeof(cls), st
+        assert comp[st]["members"] == _ctypes_layout(cls), st
+
+
+def _integration_md_binding():
+    """exec()s the ctypes stub printed in INTEGRATION.md (section B, `RaJePy/_rjprt.py`) with
+    the CDLL call replaced by a recorder; returns (namespace, recorder)."""
+    md = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    blocks = re.findall(r"```python\n(.*?)```", md, re.S)
+    stub = [b for b in blocks if "RaJePy/_rjprt.py" in b]
+    assert len(stub) == 1
+
+    class _Fn:
+        argtypes = None
+        restype = ctypes.c_int
+
+    class _Recorder:
+        def __init__(self):
+            self.fns = {}
+
+        def __getattr__(self, name):
+            if name.startswith("rjp_"):
+                return self.fns.setdefault(name, _Fn())
+            raise AttributeError(name)
+
+    rec = _Recorder()
+    rec.fns["rjp_version"] = lambda: _lib.RJP_VERSION
+    code = stub[0].replace('C.CDLL("librjprt.so")', "_RECORDER")
+    assert "_RECORDER" in code
+    ns = {"_RECORDER": rec}
+    exec(compile(code, "INTEGRATION.md", "exec"), ns)
+    return ns, rec
+
+
+def test_integration_md_binding_matches_the_abi():
+    """The reference-side stub a maintainer would paste from INTEGRATION.md is executed and
+    compared with the binding the tests run through: struct members, types, offsets, sizes,
+    the ABI version it asserts, and every prototype it declares."""
+    ns, rec = _integration_md_binding()
+    seen = 0
+    for cname in _ABI_STRUCTS.values():
+        if cname not in ns:
+            continue
+        seen += 1
+        doc, ours = ns[cname], getattr(_lib, cname)
+        assert ctypes.sizeof(doc) == ctypes.sizeof(ours), cname
+        assert _ctypes_layout(doc) == _ctypes_layout(ours), cname
+    assert seen >= 2 and "Fields" in ns and "Bursts" in ns
+    declared = {k: v for k, v in rec.fns.items() if k != "rjp_version"}
+    assert len(declared) >= 6
+
+    def norm(t):
+        # the stub's own Fields / Bursts classes are distinct Python types: compare by layout
+        if hasattr(t, "_type_") and hasattr(t._type_, "_fields_"):
+            return ("ptr", tuple(map(tuple, _ctypes_layout(t._type_))))
+        return t
+    for name, fn in declared.items():
+        res, args = _lib.SIGNATURES[name]                   # KeyError: not an entry point
+        if fn.argtypes is not None:
+            assert [norm(a) for a in fn.argtypes] == [norm(a) for a in args], name
+        assert fn.restype is res, name
 
 
 def test_workspace_queries_are_host_arithmetic():
