@@ -24,13 +24,6 @@ struct FieldPtrs {
   const T* a0;             // tau layout: em0 * T^-1.5 (or T^-1.35), sign bit = red jet
 };
 
-// which fields a scan kernel streams
-enum : int {
-  LAY_WIDE = 0,            // nd, xi, temp, pf, ts
-  LAY_CMP = 1,             // em0, temp, ts
-  LAY_TAU = 2              // a0, ts (+ em0 with emission-measure maps); no T_avg sums
-};
-
 // A NaN launch time never reaches the jet: its cell is given chi = 1 here (a launch at
 // -1e300 s is > 700 sigma from every burst) and masked when it is accumulated.
 __device__ __forceinline__ double launch_or_never(double ts) { return __builtin_fmax(ts, -1e300); }

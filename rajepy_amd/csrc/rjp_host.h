@@ -30,6 +30,13 @@ struct ScanPlan {
   std::vector<double> ext;       // host image of the overflow table (empty without overflow)
 };
 
+// which fields a scan kernel streams (scan_layout)
+enum : int {
+  LAY_WIDE = 0,            // nd, xi, temp, pf, ts
+  LAY_CMP = 1,             // em0, temp, ts
+  LAY_TAU = 2              // a0, ts (+ em0 with emission-measure maps); no T_avg sums
+};
+
 int ff_scan_vec(const rjp_fields* fl);
 int scan_layout(const rjp_fields* fl, int mode, bool want_em);
 bool tile_dma_ok(const rjp_fields* fl);

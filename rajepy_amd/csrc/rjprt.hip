@@ -325,12 +325,25 @@ int rjp_ff_scan(rjp_ctx* ctx, const rjp_fields* fields, const rjp_bursts* bursts
   if (int r = check_bursts(ctx, bursts, fields)) return r;
   if (!h_epochs_s || n_epochs < 1) return fail(ctx, RJP_ERR_ARG, "need >= 1 epoch");
   if (!d_sumA || !d_work) return fail(ctx, RJP_ERR_ARG, "d_sumA / d_work is NULL");
-  if (fields->d_a0 && fields->a0_mode == gff_mode && !fields->d_em0 && !fields->d_temp &&
-      (d_em || d_tavg))
-    return fail(ctx, RJP_ERR_ARG, "rjp_ff_scan: fields hold the tau layout only; d_em needs "
-                                  "d_em0 and d_tavg needs d_temp");
-  if (fields->d_a0 && fields->a0_mode == gff_mode && d_tavg && !fields->d_temp)
-    return fail(ctx, RJP_ERR_ARG, "rjp_ff_scan: d_tavg on the tau layout needs fields.d_temp");
+  // check_fields accepted the call on the strength of ONE complete layout; the layout the scan
+  // really takes depends on what is asked for (d_em moves a tau-only field set to the compact
+  // or wide kernels): every pointer THAT layout dereferences must be there
+  switch (rjp::scan_layout(fields, gff_mode, d_em != nullptr)) {
+    case rjp::LAY_TAU:
+      if (d_tavg && !fields->d_temp)
+        return fail(ctx, RJP_ERR_ARG, "rjp_ff_scan: d_tavg on the tau layout needs fields.d_temp");
+      break;
+    case rjp::LAY_CMP:
+      if (!fields->d_temp)
+        return fail(ctx, RJP_ERR_ARG, "rjp_ff_scan: the compact layout needs fields.d_temp");
+      break;
+    default:
+      if (!fields->d_nd || !fields->d_xi || !fields->d_temp || !fields->d_pf)
+        return fail(ctx, RJP_ERR_ARG,
+                    d_em ? "rjp_ff_scan: d_em needs fields.d_em0 or the complete wide set "
+                           "(nd, xi, temp, pf); these fields hold the tau layout only"
+                         : "rjp_ff_scan: fields nd/xi/temp/pf must be device pointers");
+  }
   if (work_bytes < rjp::ff_scan_workspace_bytes(fields->nx, fields->ny, fields->nz, n_epochs))
     return fail(ctx, RJP_ERR_WORKSPACE, "rjp_ff_scan: workspace smaller than rjp_ff_scan_workspace()");
   hipStream_t st = (hipStream_t)stream;

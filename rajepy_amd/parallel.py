@@ -80,6 +80,28 @@ def _in_group():
     return dist.is_available() and dist.is_initialized()
 
 
+def _talks(world, group=None):
+    """Does a sharding over `world` ranks issue its collective on `group`?  Only when the
+    group's size IS the sharding's world: a one-rank RCCL group still runs the collective (the
+    path an eight-rank job takes), but a caller that keeps the default rank=0 / world=1 inside
+    an N-rank job stays purely local -- its result is complete on its own, and a collective
+    there would multiply an all_reduce by N or hang a gather only some ranks entered.  Any
+    other mismatch is a planning error and raises on every rank before anything is sent."""
+    world = int(world)
+    if not _in_group():
+        if world > 1:
+            raise RuntimeError("a sharding over %d ranks needs an initialised "
+                               "torch.distributed process group" % world)
+        return False
+    size = _dist().get_world_size(group)
+    if size == world:
+        return True
+    if world == 1:
+        return False
+    raise ValueError("sharding planned for %d ranks inside a process group of %d"
+                     % (world, size))
+
+
 def all_gather_blocks(local, shards, rank, axis=0, group=None):
     """Gather per-rank blocks of unequal leading size along `axis` to every rank.
 
@@ -91,10 +113,8 @@ def all_gather_blocks(local, shards, rank, axis=0, group=None):
     if local.shape[axis] != counts[rank]:
         raise ValueError("local block has %d items on axis %d, plan says %d"
                          % (local.shape[axis], axis, counts[rank]))
-    if shards.world == 1 and not _in_group():
-        return local                         # no process group: nothing to talk to
-    # (inside an initialised group the collective is issued even for one rank, so that a
-    # one-rank RCCL group on a single GPU exercises the path an eight-rank one takes)
+    if not _talks(shards.world, group):
+        return local                         # world = 1 outside a one-rank group: local
     loc = local.movedim(axis, 0).contiguous()
     cmax = max(counts)
     if loc.shape[0] < cmax:
@@ -122,7 +142,7 @@ def gather_to_root(local, shards, rank, axis=0, root=0, group=None):
     import torch
     dist = _dist()
     counts = shards.counts()
-    if shards.world == 1 and not _in_group():
+    if not _talks(shards.world, group):
         return local
     loc = local.movedim(axis, 0).contiguous()
     cmax = max(counts)
@@ -229,7 +249,7 @@ def sweep_xslab(model, epochs_s, freqs, rank=0, world=1, gather_maps=False, grou
     Returns (ftot[E,F] host array, tau or None, flux or None)."""
     dist = _dist()
     _, tau, flux, ftot = xslab_local(model, epochs_s, freqs, rank, world, want_maps=gather_maps)
-    if world > 1 or _in_group():
+    if _talks(world, group):
         if ftot.is_cuda and dist.get_backend(group) == "gloo":
             t = ftot.cpu()
             dist.all_reduce(t, group=group)

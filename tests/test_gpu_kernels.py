@@ -305,6 +305,22 @@ def test_abi_error_reporting(eng):
     assert b"bursts" in lib.rjp_last_error(eng.ctx)
     with pytest.raises(_lib.RjprtError):
         _lib.check(-2, eng.ctx, "demo")
+    # a tau-only field set (a0, temp, ts) asked for EM maps: the scan would move to the wide
+    # kernels, whose fields are not there -- refused before anything is enqueued
+    lean = eng.synth_fields((2, 8, 8), 1, 0, 8, wide=False, tau_mode=0, with_em0=False)
+    assert lean.em0 is None and lean.nd is None and lean.a0 is not None
+    em = eng._f64(1, 16)
+    ls = lean.struct()
+    assert lib.rjp_ff_scan(eng.ctx, C.byref(ls), None, ep, 1, 0, out.data_ptr(), None, None,
+                           work.data_ptr(), work.numel(), st) == 0
+    assert lib.rjp_ff_scan(eng.ctx, C.byref(ls), None, ep, 1, 0, out.data_ptr(), em.data_ptr(),
+                           None, work.data_ptr(), work.numel(), st) == -1
+    assert b"d_em" in lib.rjp_last_error(eng.ctx)
+    with pytest.raises(_lib.RjprtError, match="d_em"):
+        eng.ff_scan(lean, None, [0.0], 0, want_em=True, want_tavg=False)
+    # ... and the other Gaunt mode (the a0 field is ignored): nothing left to scan from
+    assert lib.rjp_ff_scan(eng.ctx, C.byref(ls), None, ep, 1, 1, out.data_ptr(), None, None,
+                           work.data_ptr(), work.numel(), st) == -1
     # out-of-range device index
     ctx = C.c_void_p()
     assert lib.rjp_ctx_create(10 ** 6, C.byref(ctx)) == -1

@@ -70,6 +70,45 @@ def test_gathers_gloo(world, n_epochs):
     assert all(ret[r] for r in range(world)), dict(ret)
 
 
+def _local_in_group_worker(rank, world, port, ret):
+    """The world = 1 entry points inside a 2-rank group: purely local, no collective -- only
+    rank 0 calls them here, so a collective would hang (and an all_reduce would double the
+    fluxes); a sharding planned for 3 ranks inside the 2-rank group is refused."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        ok = True
+        if rank == 0:
+            one = par.Shards(np.arange(4), 1)
+            x = torch.arange(12, dtype=torch.float64).reshape(4, 3)
+            ok = ok and par.all_gather_blocks(x, one, 0) is x
+            ok = ok and par.gather_to_root(x, one, 0) is x
+            ok = ok and par.gather_flux_vs_time(x, one, 0) is x
+            ok = ok and par._talks(1) is False and par._talks(2) is True
+        try:
+            par._talks(3)
+            ok = False
+        except ValueError:
+            pass
+        dist.barrier()
+        ret[rank] = bool(ok)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_world1_entry_points_stay_local_inside_a_larger_group():
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_local_in_group_worker, args=(2, _free_port(), ret), nprocs=2, join=True)
+    assert ret[0] is True and ret[1] is True, dict(ret)
+    # and without any group: world = 1 is local, world > 1 cannot be served
+    assert par._talks(1) is False
+    with pytest.raises(RuntimeError):
+        par._talks(2)
+
+
 def _pipeline_worker(rank, world, port, dcy, ret):
     """Pipeline.execute under a 2-rank gloo group, dry run (no GPU here): epochs are dealt to
     the ranks, results/completion flags are gathered, rank 0 writes the state files."""
