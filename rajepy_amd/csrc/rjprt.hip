@@ -331,7 +331,8 @@ int rjp_ff_scan(rjp_ctx* ctx, const rjp_fields* fields, const rjp_bursts* bursts
   switch (rjp::scan_layout(fields, gff_mode, d_em != nullptr)) {
     case rjp::LAY_TAU:
       if (d_tavg && !fields->d_temp)
-        return fail(ctx, RJP_ERR_ARG, "rjp_ff_scan: d_tavg on the tau layout needs fields.d_temp");
+        return fail(ctx, RJP_ERR_ARG, "rjp_ff_scan: fields hold the tau layout only; d_tavg needs "
+                                      "fields.d_temp");
       break;
     case rjp::LAY_CMP:
       if (!fields->d_temp)

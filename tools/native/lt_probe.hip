@@ -1,0 +1,347 @@
+// Feasibility probe (round 4): the launch-time moment pass WITHOUT LDS atomics.
+//
+// Per model, every group of 64 z-adjacent sightlines is bucketed once by (jet, launch-time bin):
+// cells[(slot * 64 + lane)] = (|a0|, ts) pairs, the slots of one (group, bin) contiguous and padded
+// to the largest count among the group's 64 sightlines.  A wave then walks the bins of its group
+// with every lane in the SAME bin: N Chebyshev moments per lane live in registers, and at the end
+// of a bin they are contracted with the bin's coefficient rows W[bin][n][0..32) -- wave-uniform,
+// scalar loads -- into 32 epoch sums per lane.  No LDS, no moment maps in HBM.
+//   hipcc --offload-arch=gfx950 -O3 -o lt_probe lt_probe.hip ; ./lt_probe
+#include <hip/hip_runtime.h>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
+
+__host__ __device__ inline void synth(size_t i, int nz, double& a, double& t) {
+  unsigned long long x = i * 0x9E3779B97F4A7C15ull; x ^= x >> 29; x *= 0xBF58476D1CE4E5B9ull;
+  unsigned long long y = (i + 0x1234567) * 0xD1B54A32D192ED03ull; y ^= y >> 31; y *= 0x94D049BB133111EBull;
+  const double u = (double)(x >> 11) * (1.0 / 9007199254740992.0);
+  const double v = (double)(y >> 11) * (1.0 / 9007199254740992.0);
+  const bool red = (int)(i % nz) < nz / 2;
+  a = (red ? -1.0 : 1.0) * (1.0 + 100.0 * u);
+  t = 5.0 * v;
+}
+
+__global__ void fill(double* a0, double* ts, size_t n, int nz) {
+  size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  const size_t step = (size_t)gridDim.x * 256;
+  for (; i < n; i += step) synth(i, nz, a0[i], ts[i]);
+}
+
+typedef double d2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ double2 ld2(const double2* p) { d2v t = __builtin_nontemporal_load(reinterpret_cast<const d2v*>(p)); return make_double2(t.x, t.y); }
+struct Bins { double s0, inv_h; int K; };
+
+__device__ __forceinline__ int key_of(double av, double tv, const Bins& b) {
+  const double w = (tv - b.s0) * b.inv_h;
+  const double kf = fmin(fmax(floor(w), 0.0), (double)(b.K - 1));
+  return (av < 0.0 ? 0 : b.K) + (int)kf;
+}
+
+// rows[g][q] = max over the group's 64 lanes of the number of cells with key q
+__global__ __launch_bounds__(256) void lt_count(const double* __restrict__ a0, const double* __restrict__ ts,
+                                                int ny, int nz, Bins b, int* __restrict__ rows) {
+  extern __shared__ unsigned cnt[];          // [Q][64]
+  const int Q = 2 * b.K;
+  for (int i = threadIdx.x; i < Q * 64; i += 256) cnt[i] = 0;
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const size_t p = (size_t)blockIdx.x * 64 + lane;
+  const size_t x = p / nz; const int z = (int)(p - x * nz);
+  const size_t col = x * (size_t)ny * nz + z;
+  for (int y0 = wv; y0 < ny; y0 += 4 * 8) {
+    double a[8], t[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int y = y0 + 4 * u;
+      const int yc = y < ny ? y : ny - 1;
+      a[u] = __builtin_nontemporal_load(a0 + col + (size_t)yc * nz);
+      t[u] = __builtin_nontemporal_load(ts + col + (size_t)yc * nz);
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      if (y0 + 4 * u < ny && fabs(a[u]) > 0.0 && fabs(a[u]) < 1e308 && t[u] == t[u])
+        atomicAdd(&cnt[key_of(a[u], t[u], b) * 64 + lane], 1u);
+  }
+  __syncthreads();
+  for (int q = wv; q < Q; q += 4) {
+    unsigned m = cnt[q * 64 + lane];
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, d, 64));
+    if (lane == 0) rows[(size_t)blockIdx.x * Q + q] = (int)m;
+  }
+}
+
+// exclusive prefix of n ints (one block)
+__global__ __launch_bounds__(1024) void lt_scan(const int* __restrict__ rows, size_t n, int* __restrict__ off) {
+  __shared__ long long part[1024];
+  const size_t per = (n + 1023) / 1024;
+  const size_t i0 = min(n, threadIdx.x * per), i1 = min(n, i0 + per);
+  long long s = 0;
+  for (size_t i = i0; i < i1; ++i) s += rows[i];
+  part[threadIdx.x] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) { long long r = 0; for (int i = 0; i < 1024; ++i) { long long v = part[i]; part[i] = r; r += v; } }
+  __syncthreads();
+  long long r = part[threadIdx.x];
+  for (size_t i = i0; i < i1; ++i) { off[i] = (int)r; r += rows[i]; }
+  if ((i0 < n && i1 == n) || (n == 0 && threadIdx.x == 0)) off[n] = (int)r;   // the total
+}
+
+// one wave per group: cells[(rowoff[q] + r) * 64 + lane] = (|a0|, ts), padding = (0, bin centre)
+__global__ __launch_bounds__(64) void lt_fill(const double* __restrict__ a0, const double* __restrict__ ts,
+                                              int ny, int nz, Bins b, const int* __restrict__ off,
+                                              double2* __restrict__ cells) {
+  extern __shared__ unsigned short pos[];    // [Q][64]
+  const int Q = 2 * b.K;
+  const int lane = threadIdx.x;
+  for (int q = 0; q < Q; ++q) pos[q * 64 + lane] = 0;
+  const int* go = off + (size_t)blockIdx.x * Q;
+  const size_t p = (size_t)blockIdx.x * 64 + lane;
+  const size_t x = p / nz; const int z = (int)(p - x * nz);
+  const size_t col = x * (size_t)ny * nz + z;
+  for (int y0 = 0; y0 < ny; y0 += 8) {
+    double a[8], t[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int y = y0 + u;
+      const int yc = y < ny ? y : ny - 1;
+      a[u] = __builtin_nontemporal_load(a0 + col + (size_t)yc * nz);
+      t[u] = __builtin_nontemporal_load(ts + col + (size_t)yc * nz);
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      if (y0 + u < ny && fabs(a[u]) > 0.0 && fabs(a[u]) < 1e308 && t[u] == t[u]) {
+        const int q = key_of(a[u], t[u], b);
+        const unsigned r = pos[q * 64 + lane];
+        pos[q * 64 + lane] = (unsigned short)(r + 1);
+        cells[((size_t)go[q] + r) * 64 + lane] = make_double2(fabs(a[u]), t[u]);
+      }
+  }
+  for (int q = 0; q < Q; ++q) {
+    const int nrow = go[q + 1] - go[q];
+    const double mid = b.s0 + ((q % b.K) + 0.5) / b.inv_h;
+    for (int r = pos[q * 64 + lane]; r < nrow; ++r)
+      cells[((size_t)go[q] + r) * 64 + lane] = make_double2(0.0, mid);
+  }
+}
+
+// the fused moment pass: one wave per (group, split of the key range)
+template <int N, int U>
+__global__ __launch_bounds__(64) void lt_moments(const double2* __restrict__ cells, const int* __restrict__ off,
+                                                 Bins b, int nsplit, const double* __restrict__ W,
+                                                 size_t npix, double* __restrict__ part) {
+  constexpr int ET = 32;
+  const int Q = 2 * b.K;
+  const int g = blockIdx.x / nsplit, sp = blockIdx.x % nsplit;
+  const int q0 = (int)((long long)Q * sp / nsplit), q1 = (int)((long long)Q * (sp + 1) / nsplit);
+  const int lane = threadIdx.x;
+  const int* go = off + (size_t)g * Q;
+  double acc[ET];
+#pragma unroll
+  for (int e = 0; e < ET; ++e) acc[e] = 0.0;
+  const double c1 = 2.0 * b.inv_h;
+  for (int q = q0; q < q1; ++q) {
+    const int r0 = go[q], r1 = go[q + 1];
+    const int k = q >= b.K ? q - b.K : q;
+    const double c0 = -(2.0 * (b.s0 * b.inv_h + k) + 1.0);       // xi = ts * c1 + c0
+    double M[N];
+#pragma unroll
+    for (int n = 0; n < N; ++n) M[n] = 0.0;
+    const double2* src = cells + (size_t)r0 * 64 + lane;
+    int r = r0;
+    for (; r + U <= r1; r += U) {
+      double2 c[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) c[u] = ld2(src + (size_t)u * 64);
+      src += (size_t)U * 64;
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const double xi = __builtin_fma(c[u].y, c1, c0);
+        double tm = c[u].x, tc = c[u].x * xi;
+        const double x2 = xi + xi;
+        M[0] += tm;
+        M[1] += tc;
+#pragma unroll
+        for (int n = 2; n < N; ++n) {
+          const double tn = __builtin_fma(x2, tc, -tm);
+          tm = tc; tc = tn;
+          M[n] += tn;
+        }
+      }
+    }
+    for (; r < r1; ++r) {
+      const double2 c = ld2(src);
+      src += 64;
+      const double xi = __builtin_fma(c.y, c1, c0);
+      double tm = c.x, tc = c.x * xi;
+      const double x2 = xi + xi;
+      M[0] += tm;
+      M[1] += tc;
+#pragma unroll
+      for (int n = 2; n < N; ++n) {
+        const double tn = __builtin_fma(x2, tc, -tm);
+        tm = tc; tc = tn;
+        M[n] += tn;
+      }
+    }
+    const double* w = W + (size_t)q * N * ET;
+#pragma unroll
+    for (int n = 0; n < N; ++n)
+#pragma unroll
+      for (int e = 0; e < ET; ++e) acc[e] = __builtin_fma(M[n], w[n * ET + e], acc[e]);
+  }
+  const size_t p = (size_t)g * 64 + lane;
+#pragma unroll
+  for (int e = 0; e < ET; ++e) part[((size_t)sp * ET + e) * npix + p] = acc[e];
+}
+
+__global__ __launch_bounds__(256) void lt_reduce(const double* __restrict__ part, int nsplit, size_t npix,
+                                                 double* __restrict__ out) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;      // over 32 * npix
+  if (i >= 32 * npix) return;
+  double s = 0.0;
+  for (int k = 0; k < nsplit; ++k) s += part[(size_t)k * 32 * npix + i];
+  out[i] = s;
+}
+
+// plain stream of the bucketed layout (what the pass could reach at best)
+__global__ __launch_bounds__(256) void stream16(const double2* __restrict__ c, size_t n, double* out) {
+  size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  double s = 0.0;
+  for (; i + 3 * (size_t)gridDim.x * 256 < n; i += 4 * (size_t)gridDim.x * 256) {
+    double2 v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) v[u] = ld2(c + i + u * (size_t)gridDim.x * 256);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) s += v[u].x + v[u].y;
+  }
+  if (s == 1.2345) out[0] = s;
+}
+
+// ---- host: bursts, W tables ------------------------------------------------------------------
+struct Burst { double t0, amp, inv2s2; };
+static std::vector<Burst> g_b[2];
+static double burst_F(int jet, double tl) {
+  double chi = 1.0;
+  for (auto& b : g_b[jet]) { const double d = tl - b.t0; chi += b.amp * std::exp(-d * d * b.inv2s2); }
+  return chi * chi;
+}
+static double tables(int K, int N, double s0, double h, const std::vector<double>& ep, std::vector<double>& W) {
+  const int ET = 32;
+  W.assign((size_t)2 * K * N * ET, 0.0);
+  const double pi = 3.14159265358979323846;
+  std::vector<double> xn(N), cs((size_t)N * N);
+  for (int i = 0; i < N; ++i) { xn[i] = std::cos(pi * (i + 0.5) / N); for (int n = 0; n < N; ++n) cs[(size_t)n * N + i] = std::cos(pi * n * (i + 0.5) / N); }
+  double worst = 0.0;
+  for (int e = 0; e < (int)ep.size(); ++e)
+    for (int j = 0; j < 2; ++j)
+      for (int k = 0; k < K; ++k) {
+        double* col = W.data() + (size_t)((j * K + k) * N) * ET + e;
+        const double ck = s0 + (k + 0.5) * h;
+        std::vector<double> f(N), cf(N);
+        for (int i = 0; i < N; ++i) f[i] = burst_F(j, ep[e] - (ck + 0.5 * h * xn[i]));
+        for (int n = 0; n < N; ++n) { double s = 0; for (int i = 0; i < N; ++i) s += f[i] * cs[(size_t)n * N + i]; cf[n] = s * (n == 0 ? 1.0 : 2.0) / N; col[(size_t)n * ET] = cf[n]; }
+        const int NT = 2 * N + 1;
+        for (int m = 0; m < NT; ++m) {
+          const double xv = -1.0 + 2.0 * m / (NT - 1);
+          double b1 = 0, b2 = 0;
+          for (int n = N - 1; n >= 1; --n) { const double b0 = 2 * xv * b1 - b2 + cf[n]; b2 = b1; b1 = b0; }
+          const double val = xv * b1 - b2 + cf[0], ref = burst_F(j, ep[e] - (ck + 0.5 * h * xv));
+          worst = std::max(worst, std::fabs(val - ref) / ref);
+        }
+      }
+  return worst;
+}
+
+template <int N, int U>
+static void run(const double* a0, const double* ts, int nx, int ny, int nz, int K, int nsplit) {
+  const size_t npix = (size_t)nx * nz, G = npix / 64;
+  const int Q = 2 * K;
+  Bins b{0.0, K / 5.0, K};
+  int *rows, *off;
+  CK(hipMalloc(&rows, G * Q * 4)); CK(hipMalloc(&off, (G * Q + 1) * 4));
+  hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  float ms_count, ms_fill, ms;
+  CK(hipFuncSetAttribute((const void*)lt_count, hipFuncAttributeMaxDynamicSharedMemorySize, Q * 64 * 4));
+  CK(hipFuncSetAttribute((const void*)lt_fill, hipFuncAttributeMaxDynamicSharedMemorySize, Q * 64 * 2));
+  CK(hipEventRecord(e0));
+  hipLaunchKernelGGL(lt_count, dim3((unsigned)G), dim3(256), Q * 64 * 4, 0, a0, ts, ny, nz, b, rows);
+  hipLaunchKernelGGL(lt_scan, dim3(1), dim3(1024), 0, 0, rows, G * Q, off);
+  CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1)); CK(hipEventElapsedTime(&ms_count, e0, e1));
+  int total = 0;
+  CK(hipMemcpy(&total, off + G * Q, 4, hipMemcpyDeviceToHost));
+  double2* cells;
+  CK(hipMalloc(&cells, (size_t)total * 64 * 16));
+  CK(hipEventRecord(e0));
+  hipLaunchKernelGGL(lt_fill, dim3((unsigned)G), dim3(64), Q * 64 * 2, 0, a0, ts, ny, nz, b, off, cells);
+  CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1)); CK(hipEventElapsedTime(&ms_fill, e0, e1));
+  CK(hipGetLastError());
+  const double pad = (double)total * 64 / ((double)nx * ny * nz);
+  printf("K=%d N=%d U=%d split=%d: rows %d (x%.3f of the cells)  count+scan %.2f ms  fill %.2f ms\n", K, N, U, nsplit,
+         total, pad, ms_count, ms_fill);
+  // tables
+  std::vector<double> ep(32), W;
+  for (int e = 0; e < 32; ++e) ep[e] = 5.0 * e / 31;
+  const double worst = tables(K, N, 0.0, 5.0 / K, ep, W);
+  double *dW, *part, *out, *dummy;
+  CK(hipMalloc(&dW, W.size() * 8)); CK(hipMemcpy(dW, W.data(), W.size() * 8, hipMemcpyHostToDevice));
+  CK(hipMalloc(&part, (size_t)nsplit * 32 * npix * 8)); CK(hipMalloc(&out, 32 * npix * 8)); CK(hipMalloc(&dummy, 8));
+  float best = 1e30f, bestr = 1e30f, bests = 1e30f;
+  for (int rep = 0; rep < 5; ++rep) {
+    CK(hipEventRecord(e0));
+    hipLaunchKernelGGL((lt_moments<N, U>), dim3((unsigned)(G * nsplit)), dim3(64), 0, 0, cells, off, b, nsplit, dW, npix, part);
+    CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1)); CK(hipEventElapsedTime(&ms, e0, e1)); best = std::min(best, ms);
+    CK(hipEventRecord(e0));
+    hipLaunchKernelGGL(lt_reduce, dim3((unsigned)((32 * npix + 255) / 256)), dim3(256), 0, 0, part, nsplit, npix, out);
+    CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1)); CK(hipEventElapsedTime(&ms, e0, e1)); bestr = std::min(bestr, ms);
+    CK(hipEventRecord(e0));
+    hipLaunchKernelGGL(stream16, dim3(8192), dim3(256), 0, 0, cells, (size_t)total * 64, dummy);
+    CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1)); CK(hipEventElapsedTime(&ms, e0, e1)); bests = std::min(bests, ms);
+  }
+  CK(hipGetLastError());
+  const double gb_alg = (double)nx * ny * nz * 16 / 1e9, gb_pad = (double)total * 64 * 16 / 1e9;
+  printf("   table error %.2e; pass %.3f ms = %.0f GB/s algorithmic (%.0f GB/s of the padded layout)  reduce %.3f ms  plain stream of the layout %.3f ms\n",
+         worst, best, gb_alg / best * 1e3, gb_pad / best * 1e3, bestr, bests);
+  // check a few sightlines against the direct sum
+  std::vector<double> hout(32 * npix);
+  CK(hipMemcpy(hout.data(), out, hout.size() * 8, hipMemcpyDeviceToHost));
+  double werr = 0.0;
+  for (size_t p : {(size_t)0, (size_t)63, (size_t)300, npix / 2 + 17, npix - 1}) {
+    const size_t x = p / nz; const int z = (int)(p % nz);
+    for (int e : {0, 7, 19, 31}) {
+      double ref = 0.0;
+      for (int y = 0; y < ny; ++y) {
+        double a, t; synth((x * ny + y) * (size_t)nz + z, nz, a, t);
+        ref += std::fabs(a) * burst_F(a < 0 ? 0 : 1, ep[e] - t);
+      }
+      werr = std::max(werr, std::fabs(hout[(size_t)e * npix + p] - ref) / ref);
+    }
+  }
+  printf("   worst relative difference from the direct sums on 5 sightlines x 4 epochs: %.2e\n", werr);
+  CK(hipFree(rows)); CK(hipFree(off)); CK(hipFree(cells)); CK(hipFree(dW)); CK(hipFree(part)); CK(hipFree(out)); CK(hipFree(dummy));
+}
+
+int main(int argc, char** argv) {
+  int nx = 512, ny = 4096, nz = 512;
+  if (argc > 3) { nx = atoi(argv[1]); ny = atoi(argv[2]); nz = atoi(argv[3]); }
+  const size_t n = (size_t)nx * ny * nz;
+  // the example model's bursts [yr]: sigma = FWHM * 2 / (2 sqrt(2 ln 2))
+  auto add = [](int j, double t0, double hl, double chi) { const double s = hl * 2.0 / (2.0 * std::sqrt(2.0 * std::log(2.0))); g_b[j].push_back({t0, chi - 1.0, 1.0 / (2 * s * s)}); };
+  add(0, 0.5, 0.15, 5.0); add(1, 0.75, 0.15, 5.0); add(1, 1.0, 0.45, 2.5); add(0, 2.0, 0.5, 10.0); add(1, 2.0, 0.5, 10.0);
+  double *a0, *ts;
+  CK(hipMalloc(&a0, n * 8)); CK(hipMalloc(&ts, n * 8));
+  hipLaunchKernelGGL(fill, dim3(8192), dim3(256), 0, 0, a0, ts, n, nz);
+  CK(hipDeviceSynchronize());
+  run<12, 8>(a0, ts, nx, ny, nz, 53, 4);
+  run<12, 4>(a0, ts, nx, ny, nz, 53, 4);
+  run<12, 8>(a0, ts, nx, ny, nz, 53, 8);
+  run<16, 8>(a0, ts, nx, ny, nz, 40, 4);
+  run<20, 8>(a0, ts, nx, ny, nz, 32, 4);
+  run<24, 8>(a0, ts, nx, ny, nz, 26, 4);
+  run<24, 4>(a0, ts, nx, ny, nz, 26, 4);
+  return 0;
+}
