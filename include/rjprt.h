@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define RJP_VERSION 106          /* 0.1.6 */
+#define RJP_VERSION 107          /* 0.1.7 */
 #define RJP_RANGE_BLOCKS 2048    /* partial (min, max) pairs rjp_field_range writes */
 #define RJP_MAX_EPOCH_TILE 32    /* most epochs evaluated per grid pass: 32 uniformly spaced ones (with or without d_em), 16 when only 16-31 are left, else tiles of 8, 4, 2, 1 */
 
@@ -121,6 +121,22 @@ typedef struct rjp_fields {
    * keeps the tiles.  A negative value skips the cost model (tests: the moment path on grids it
    * would not pay for). */
   int64_t occupied_cells;
+  /* Optional launch-time-ordered layout of (a0, ts) for epoch sweeps, built once per model by
+   * rjp_lt_count() + rjp_lt_fill() (all three NULL / 0 = absent).  Every group of 64 consecutive
+   * sightlines is bucketed by (jet, launch-time bin): d_lt_cells holds (|a0|, ts) pairs,
+   * [(d_lt_rowoff[g * 2 lt_K + q] + r) * 64 + lane], the rows of one (group, bin) contiguous and
+   * padded to the largest count among the group's sightlines (in chunks of 4 rows).  A wave then
+   * walks the bins of its group with every lane in the SAME bin: the Chebyshev moments of a bin
+   * live in registers and are contracted with the bin's coefficient rows at its end -- no LDS
+   * atomics, no moment maps in HBM, sums in a fixed order (bit-reproducible for one layout).
+   * rjp_ff_scan takes it for tau-layout scans of RJP_MOM_MIN.. 32 epochs without EM maps when
+   * the coefficient tables pass the accuracy check at some order <= 32.  It belongs to the d_a0,
+   * d_ts, ts_lo, ts_hi it was built from: rebuild after any of them changes. */
+  const void* d_lt_cells;
+  const int32_t* d_lt_rowoff;
+  const double* d_lt_aux;
+  int32_t lt_K;             /* launch-time bins per jet the layout was built with */
+  int32_t reserved2_;       /* 0 */
 } rjp_fields;
 
 /* Ejection bursts (classes.py:399-463): mdot(t)/mdot_ss = 1 + sum_b amp_rel_b *
@@ -228,10 +244,36 @@ int rjp_ff_scan(rjp_ctx* ctx, const rjp_fields* fields, const rjp_bursts* bursts
                 void* d_work, size_t work_bytes, void* stream);
 
 /* Which path the last rjp_ff_scan of this context took: 0 = epoch tiles, 1 = launch-time moments
- * (and, if non-NULL: in *worst_rel_err the worst relative error of the moment expansion the
- * host measured for that call, in moment_shape[0..1] the (bins, order) shape it chose; zeros
- * for the tiles).  For tests and the bench line. */
+ * in LDS + contraction, 2 = launch-time moments on the launch-time-ordered layout (and, if
+ * non-NULL: in *worst_rel_err the worst relative error of the moment expansion measured for
+ * that call, in moment_shape[0..1] the (bins, order) shape it chose; zeros for the tiles).
+ * For tests and the bench line. */
 int rjp_last_scan_path(const rjp_ctx* ctx, double* worst_rel_err, int32_t* moment_shape);
+
+/* Host wall time [ms] the last table build of this context took (the coefficient tables of the
+ * moment paths are built and checked on the device when the bursts or epochs of a sweep change:
+ * one small launch and ONE stream synchronisation inside that rjp_ff_scan; a repeated request
+ * reuses them).  0 before the first build. */
+double rjp_last_table_build_ms(const rjp_ctx* ctx);
+
+/* ---- launch-time-ordered layout (rjp_fields.d_lt_*) -------------------------------------
+ * Two calls, because the size of the padded layout is known only after counting:
+ *   rjp_lt_rowoff_entries(nx, nz, K)  entries (int32) of d_rowoff: ceil(nx nz / 64) * 2 K + 1
+ *   rjp_lt_count   counts the cells of every (group, jet, bin), pads each to the group's largest
+ *                  count, writes the exclusive prefix d_rowoff and returns the total number of
+ *                  rows in *h_total_rows (synchronises the stream);
+ *   rjp_lt_fill    writes d_cells (total_rows * 64 * 16 bytes) and d_aux (3 * nx * nz doubles:
+ *                  per sightline the sums of |a0| over red / blue cells with a NaN launch time --
+ *                  added when that jet has no burst, classes.py:232-233 -- and an "infinite
+ *                  term" flag).
+ * Needs RJP_F64 fields with d_a0, d_ts and ts_lo / ts_hi; 1 <= K <= 80, n_y < 65536.  Cells with
+ * a0 == 0 or NaN are dropped (nansum).  Cost: two passes over a0 and ts plus 16-byte scattered
+ * writes (~50 ms for 1.07e9 cells): worth it for a model that is swept many times. */
+size_t rjp_lt_rowoff_entries(int32_t nx, int32_t nz, int32_t K);
+int rjp_lt_count(rjp_ctx* ctx, const rjp_fields* fields, int32_t K, int32_t* d_rowoff,
+                 int64_t* h_total_rows, void* stream);
+int rjp_lt_fill(rjp_ctx* ctx, const rjp_fields* fields, int32_t K, const int32_t* d_rowoff,
+                void* d_cells, double* d_aux, void* stream);
 
 /* ---- K2: per-channel map stage --------------------------------------------------------
  * Replaces the map-level arithmetic of optical_depth_ff / intensity_ff / flux_ff

@@ -18,7 +18,7 @@ RJP_F32, RJP_F64 = 4, 8
 RJP_GFF_SCALAR, RJP_GFF_POWERLAW = 0, 1
 RJP_MAX_EPOCH_TILE = 32
 RJP_RANGE_BLOCKS = 2048
-RJP_VERSION = 106             # include/rjprt.h; the binding below matches exactly this ABI
+RJP_VERSION = 107             # include/rjprt.h; the binding below matches exactly this ABI
 RJP_OK = 0
 RJP_ERR_ARG, RJP_ERR_HIP, RJP_ERR_NODEVICE, RJP_ERR_WORKSPACE, RJP_ERR_DEGENERATE = \
     -1, -2, -3, -4, -5
@@ -39,7 +39,9 @@ class Fields(C.Structure):
                 ("dtype", C.c_int32), ("csize_au", C.c_double),
                 ("d_ylo", C.c_void_p), ("d_yhi", C.c_void_p), ("d_em0", C.c_void_p),
                 ("d_a0", C.c_void_p), ("a0_mode", C.c_int32), ("reserved_", C.c_int32),
-                ("ts_lo", C.c_double), ("ts_hi", C.c_double), ("occupied_cells", C.c_int64)]
+                ("ts_lo", C.c_double), ("ts_hi", C.c_double), ("occupied_cells", C.c_int64),
+                ("d_lt_cells", C.c_void_p), ("d_lt_rowoff", C.c_void_p),
+                ("d_lt_aux", C.c_void_p), ("lt_K", C.c_int32), ("reserved2_", C.c_int32)]
 
 
 class Bursts(C.Structure):
@@ -93,6 +95,10 @@ SIGNATURES = {
     "rjp_ff_scan": (C.c_int, [_P, C.POINTER(Fields), C.POINTER(Bursts), _DP, C.c_int32,
                               C.c_int32, _P, _P, _P, _P, C.c_size_t, _P]),
     "rjp_last_scan_path": (C.c_int, [_P, _DP, C.POINTER(C.c_int32)]),
+    "rjp_last_table_build_ms": (C.c_double, [_P]),
+    "rjp_lt_rowoff_entries": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32]),
+    "rjp_lt_count": (C.c_int, [_P, C.POINTER(Fields), C.c_int32, _P, C.POINTER(C.c_int64), _P]),
+    "rjp_lt_fill": (C.c_int, [_P, C.POINTER(Fields), C.c_int32, _P, _P, _P, _P]),
     "rjp_ff_maps_workspace": (C.c_size_t, [C.c_int64, C.c_int32, C.c_int32]),
     "rjp_ff_maps": (C.c_int, [_P, _P, _P, C.c_int64, C.c_int32, _DP, _DP, C.c_int32,
                               _P, _P, _P, _P, C.c_size_t, _P]),

@@ -205,97 +205,111 @@ hipError_t field_range_launch(const void* d_field, int64_t n, int dtype, double*
   return hipGetLastError();
 }
 
-// ---- host side --------------------------------------------------------------------------------
-static double burst_F(const rjp_bursts* hb, int jet, double tl) {
+// ---- coefficient tables, built and checked on the device ---------------------------------------
+// One thread per (shape, jet, bin, epoch): the Chebyshev coefficients of s -> F_jet(t_e - s) on the
+// bin from N node values (DCT with the staged matrix), then the interpolant against F at 2N+1
+// equispaced points (Clenshaw) -- the worst relative error of a shape goes to err[shape] through
+// an integer atomicMax on the bits of the (non-negative) double; NaN compares above everything
+// and rejects the shape.  (Rounds 1-3 built these tables on the host: ~3e5 exp per request, more
+// than the sweep they served.)
+struct MomTabArgs {
+  int ncand, E, nb[2];
+  int K[RJP_MOM_MAX_CAND], N[RJP_MOM_MAX_CAND];
+  long long w_off[RJP_MOM_MAX_CAND], tab_off[RJP_MOM_MAX_CAND];
+  long long off_b[2], off_e;
+  double s0, span;
+};
+
+__device__ __forceinline__ double burst_F_dev(const double* __restrict__ b, int n, double tl) {
   double chi = 1.0;
-  for (int i = 0; i < hb->n[jet]; ++i) {
-    const double d = tl - hb->t0[jet][i];
-    chi += hb->amp_rel[jet][i] * std::exp(-d * d * hb->inv2s2[jet][i]);
+  for (int i = 0; i < n; ++i) {
+    const double d = tl - b[i];
+    chi += b[n + i] * exp(-d * d * b[2 * n + i]);
   }
   return chi * chi;
 }
 
+__global__ __launch_bounds__(256) void mom_tables_kernel(const double* __restrict__ tab,
+                                                         MomTabArgs a, double* __restrict__ W,
+                                                         unsigned long long* __restrict__ err) {
+  constexpr int ET = RJP_MOM_TILE, NMAX = RJP_MOM_NMAX;
+  const int c = blockIdx.y;
+  const int K = a.K[c], N = a.N[c];
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= 2 * K * a.E) return;
+  const int e = i % a.E, jk = i / a.E, j = jk / K, k = jk - j * K;
+  const int nidx = 2 * K * N;
+  double* col = W + a.w_off[c] + (size_t)(e / ET) * nidx * ET + (size_t)((j * K + k) * N) * ET + e % ET;
+  if (a.nb[j] <= 0) { col[0] = 1.0; return; }                       // F == 1 (the rest stays 0)
+  const double* xn = tab + a.tab_off[c];
+  const double* cs = xn + N;
+  const double* bj = tab + a.off_b[j];
+  const double te = tab[a.off_e + e];
+  const double h = a.span / K, ck = a.s0 + (k + 0.5) * h;
+  double f[NMAX], cf[NMAX];
+  for (int m = 0; m < N; ++m) f[m] = burst_F_dev(bj, a.nb[j], te - (ck + 0.5 * h * xn[m]));
+  for (int n = 0; n < N; ++n) {
+    double s = 0.0;
+    for (int m = 0; m < N; ++m) s += f[m] * cs[n * N + m];
+    cf[n] = s * (n == 0 ? 1.0 : 2.0) / N;
+    col[(size_t)n * ET] = cf[n];
+  }
+  const int NT = 2 * N + 1;
+  double worst = 0.0;
+  for (int m = 0; m < NT; ++m) {
+    const double xv = -1.0 + 2.0 * m / (NT - 1);
+    double b1 = 0.0, b2 = 0.0;
+    for (int n = N - 1; n >= 1; --n) { const double b0 = 2.0 * xv * b1 - b2 + cf[n]; b2 = b1; b1 = b0; }
+    const double val = xv * b1 - b2 + cf[0];
+    const double ref = burst_F_dev(bj, a.nb[j], te - (ck + 0.5 * h * xv));
+    const double er = fabs(val - ref) / ref;                         // F = chi^2 > 0; 0/0 -> NaN
+    worst = (er <= worst) ? worst : er;
+  }
+  atomicMax(err + c, (unsigned long long)__double_as_longlong(worst));
+}
+
+// ---- host side --------------------------------------------------------------------------------
 size_t moments_workspace_bytes(int64_t npix) {
   const int64_t npixp = (npix + kMomSL - 1) / kMomSL * kMomSL;
   return (size_t)RJP_MOM_MAX_IDX * (size_t)npixp * sizeof(double) + 256;
 }
 
-// W tables of one shape; false as soon as one (jet, bin, epoch) misses the tolerance
-static bool moments_tables(const rjp_bursts* hb, const double* epochs, int n_epochs, int K, int N,
-                           MomPlan& mp) {
-  constexpr int ET = RJP_MOM_TILE, NMAX = 16;
-  const int nidx = 2 * K * N;
-  const double span = mp.key_hi - mp.key_lo;
-  const double h = span > 0.0 ? span / K : 1.0;
-  mp.s0 = mp.key_lo;
-  mp.inv_h = 1.0 / h;
-  mp.K = K; mp.N = N;
-  mp.nchunk = (n_epochs + ET - 1) / ET;
-  mp.W.assign((size_t)mp.nchunk * nidx * ET, 0.0);
-  // Chebyshev nodes and the DCT matrix
-  const double pi = 3.14159265358979323846;
-  double xn[NMAX], cs[NMAX][NMAX];
-  for (int i = 0; i < N; ++i) {
-    xn[i] = std::cos(pi * (i + 0.5) / N);
-    for (int n = 0; n < N; ++n) cs[n][i] = std::cos(pi * n * (i + 0.5) / N);
-  }
-  const int NT = 2 * N + 1;                           // test points of the accuracy check
-  double worst = 0.0;
-  for (int e = 0; e < n_epochs; ++e) {
-    const int c = e / ET, el = e % ET;
-    double* Wc = mp.W.data() + (size_t)c * nidx * ET;
-    for (int j = 0; j < 2; ++j)
-      for (int k = 0; k < K; ++k) {
-        double* col = Wc + (size_t)((j * K + k) * N) * ET + el;      // stride ET between n
-        if (hb->n[j] <= 0) { col[0] = 1.0; continue; }             // F == 1
-        const double ck = mp.s0 + (k + 0.5) * h;
-        double f[NMAX], cf[NMAX];
-        for (int i = 0; i < N; ++i) f[i] = burst_F(hb, j, epochs[e] - (ck + 0.5 * h * xn[i]));
-        for (int n = 0; n < N; ++n) {
-          double s = 0.0;
-          for (int i = 0; i < N; ++i) s += f[i] * cs[n][i];
-          cf[n] = s * (n == 0 ? 1.0 : 2.0) / N;
-          col[(size_t)n * ET] = cf[n];
-        }
-        // accuracy: the interpolant against F on a finer grid (Clenshaw)
-        for (int m = 0; m < NT; ++m) {
-          const double xv = -1.0 + 2.0 * m / (NT - 1);
-          double b1 = 0.0, b2 = 0.0;
-          for (int n = N - 1; n >= 1; --n) { const double b0 = 2.0 * xv * b1 - b2 + cf[n]; b2 = b1; b1 = b0; }
-          const double val = xv * b1 - b2 + cf[0];
-          const double ref = burst_F(hb, j, epochs[e] - (ck + 0.5 * h * xv));
-          const double err = std::fabs(val - ref) / ref;           // F >= ... > 0 (chi > 0)
-          if (!(err <= worst)) worst = err;
-        }
-        if (!(worst <= RJP_MOM_TOL)) { mp.worst = worst; return false; }
-      }
-  }
-  mp.worst = worst;
-  return true;
+void moments_release(MomPlan& mp) {
+  if (mp.d_W) (void)hipFree(mp.d_W);
+  if (mp.d_err) (void)hipFree(mp.d_err);
+  if (mp.h_err) (void)hipHostFree(mp.h_err);
+  mp.d_W = nullptr; mp.capW = 0; mp.d_err = nullptr; mp.h_err = nullptr; mp.d_Wsel = nullptr;
+  mp.key_E = -1; mp.key_ok = false; mp.ok = false;
 }
 
-// Can this scan take the moment path, and if so: its shape and W tables.
-// `mp.W` = [chunk][2 K N][32].
-bool moments_plan(const rjp_fields* fl, const rjp_bursts* hb, const double* epochs, int n_epochs,
-                  int mode, bool want_em, size_t work_bytes, MomPlan& mp) {
+// Can this scan take a moment path?  Decides between the launch-time-ordered layout (when the
+// caller attached one: any order up to 32 over its bins) and the LDS moments (three shapes inside
+// the LDS budget), applies the cost model, and either recognises the previous request (1) or
+// prepares the staged table of a new one (2).
+int moments_plan(const rjp_fields* fl, const rjp_bursts* hb, const double* epochs, int n_epochs,
+                 int mode, bool want_em, size_t work_bytes, MomPlan& mp) {
   mp.ok = false;
-  if (!hb || (hb->n[0] <= 0 && hb->n[1] <= 0)) return false;
-  if (n_epochs < RJP_MOM_MIN_EPOCHS) return false;
+  if (!hb || (hb->n[0] <= 0 && hb->n[1] <= 0)) return 0;
+  if (n_epochs < RJP_MOM_MIN_EPOCHS) return 0;
   // (with EM maps: the tau layout with its em0 field attached -- a second pass weighs by em0)
-  if (scan_layout(fl, mode, want_em) != 2 /* LAY_TAU */ || !fl->d_ts) return false;
+  if (scan_layout(fl, mode, want_em) != LAY_TAU || !fl->d_ts) return 0;
   if (!(fl->ts_hi >= fl->ts_lo) || !std::isfinite(fl->ts_lo) || !std::isfinite(fl->ts_hi) ||
       (fl->ts_lo == 0.0 && fl->ts_hi == 0.0))
-    return false;                                               // range not provided
-  if (work_bytes < moments_workspace_bytes((int64_t)fl->nx * fl->nz)) return false;
+    return 0;                                                   // range not provided
+  if (work_bytes < moments_workspace_bytes((int64_t)fl->nx * fl->nz)) return 0;
   for (int e = 0; e < n_epochs; ++e)
-    if (!std::isfinite(epochs[e])) return false;
+    if (!std::isfinite(epochs[e])) return 0;
+  const bool lt = fl->d_lt_cells && fl->d_lt_rowoff && fl->d_lt_aux && fl->lt_K >= 1 &&
+                  fl->lt_K <= RJP_LT_MAX_K && !want_em && n_epochs <= RJP_LT_MAX_EPOCHS;
+  bool lds = true;                       // may the LDS moment pass run (cost model)?
   if (fl->occupied_cells >= 0) {
     // Cost model (seconds on one MI355X, from the cfg5-size measurements of round 3): the tiles
     // pay per (cell, epoch) pair -- 0.40 ps in the uniform-epoch recurrence, 0.93 ps when every
     // epoch is evaluated directly -- on the cells inside the occupied y-ranges; the moment path
     // pays 4.7 ps per such cell once (its most expensive shape), plus per SIGHTLINE 10 KiB of
     // moments written and read back (3.6 ns) and 1.1 ns per contraction pass of 32 epochs.
-    // Short or sparsely filled sightlines keep the tiles.
+    // Short or sparsely filled sightlines keep the tiles.  (A caller that attached the
+    // launch-time-ordered layout has paid for it: that path is taken whenever it is accurate.)
     const double npix = (double)fl->nx * fl->nz;
     const double cells = fl->occupied_cells > 0 ? (double)fl->occupied_cells : npix * fl->ny;
     bool uniform = n_epochs >= 4;
@@ -308,11 +322,13 @@ bool moments_plan(const rjp_fields* fl, const rjp_bursts* hb, const double* epoc
     const double t_mom = (cells * 4.7e-12 +
                           npix * (3.6e-9 + 1.1e-9 * ((n_epochs + RJP_MOM_TILE - 1) / RJP_MOM_TILE))) *
                          (want_em ? 2.0 : 1.0);
-    if (!(t_mom < 0.8 * t_tiles)) return false;
+    lds = t_mom < 0.8 * t_tiles;
   }
-  // same request as last time?
+  if (!lt && !lds) return 0;
+  const int ltK = lt ? fl->lt_K : 0;
+  // same request as last time?  (the tables are still on the device)
   if (mp.key_E == n_epochs && mp.key_lo == fl->ts_lo && mp.key_hi == fl->ts_hi &&
-      mp.key_epochs.size() == (size_t)n_epochs &&
+      mp.key_ltK == (lds ? ltK : -2 - ltK) && mp.key_epochs.size() == (size_t)n_epochs &&
       std::memcmp(mp.key_epochs.data(), epochs, sizeof(double) * n_epochs) == 0 &&
       mp.key_n[0] == hb->n[0] && mp.key_n[1] == hb->n[1]) {
     bool same = true;
@@ -321,33 +337,131 @@ bool moments_plan(const rjp_fields* fl, const rjp_bursts* hb, const double* epoc
       for (int i = 0; i < hb->n[j] && same; ++i, o += 3)
         same = mp.key_bursts[o] == hb->t0[j][i] && mp.key_bursts[o + 1] == hb->amp_rel[j][i] &&
                mp.key_bursts[o + 2] == hb->inv2s2[j][i];
-    if (same) { mp.ok = mp.key_ok; return mp.ok; }
+    if (same) { mp.ok = mp.key_ok; return mp.ok ? 1 : 0; }
   }
   mp.key_E = n_epochs; mp.key_lo = fl->ts_lo; mp.key_hi = fl->ts_hi;
+  mp.key_ltK = lds ? ltK : -2 - ltK;            // (the candidate set depends on both)
   mp.key_epochs.assign(epochs, epochs + n_epochs);
   mp.key_n[0] = hb->n[0]; mp.key_n[1] = hb->n[1];
   mp.key_bursts.clear();
+  double inv_max = 0.0;                                         // the narrowest burst
   for (int j = 0; j < 2; ++j)
     for (int i = 0; i < hb->n[j]; ++i) {
       mp.key_bursts.push_back(hb->t0[j][i]);
       mp.key_bursts.push_back(hb->amp_rel[j][i]);
       mp.key_bursts.push_back(hb->inv2s2[j][i]);
+      if (!(hb->inv2s2[j][i] <= inv_max)) inv_max = hb->inv2s2[j][i];     // (NaN propagates)
     }
   mp.key_ok = false;
   mp.has_bursts[0] = hb->n[0] > 0;
   mp.has_bursts[1] = hb->n[1] > 0;
-  // cheapest shape first (fewest atomics per cell); RJP_MOM_SHAPE=<i> pins one (debug builds'
-  // A/B switch, as the other RJP_* switches)
+  mp.nchunk = (n_epochs + RJP_MOM_TILE - 1) / RJP_MOM_TILE;
+  const double span = fl->ts_hi - fl->ts_lo;
+  const double sigma_min = std::sqrt(0.5 / inv_max);            // NaN / 0 for degenerate widths
+  // candidate shapes, cheapest first.  RJP_MOM_SHAPE=<i> pins one (debug builds' A/B switch).
+  // Deterministic guard beside the sampled accuracy check: a shape whose node spacing h / N
+  // exceeds the narrowest burst's sigma could let that burst fall between all nodes AND all
+  // test points (every table would then pass with F ~ 1): such shapes are not even tried.
   int pin = -1;
 #ifdef RJP_DEBUG_SWITCHES
   if (const char* e = getenv("RJP_MOM_SHAPE")) pin = atoi(e);
 #endif
-  for (int sh = 0; sh < kMomNShapes && !mp.key_ok; ++sh) {
-    if (pin >= 0 && sh != pin) continue;
-    mp.key_ok = moments_tables(hb, epochs, n_epochs, kMomShapes[sh].K, kMomShapes[sh].N, mp);
+  mp.cands.clear();
+  auto consider = [&](int K, int N, int path) {
+    const double h = span > 0.0 ? span / K : 0.0;
+    if (!(sigma_min >= h / N)) return;                          // also rejects NaN / inf widths
+    if ((int)mp.cands.size() < RJP_MOM_MAX_CAND) mp.cands.push_back(MomCand{K, N, path, 0, 0});
+  };
+  // the layout first (any order up to 32 over its bins), then the three LDS shapes
+  if (lt)
+    for (int N = 8; N <= RJP_MOM_NMAX; N += 4) consider(ltK, N, 2);
+  if (lds)
+    for (int sh = 0; sh < kMomNShapes; ++sh)
+      if (pin < 0 || sh == pin) consider(kMomShapes[sh].K, kMomShapes[sh].N, 1);
+  if (mp.cands.empty()) return 0;
+  // the staged table: [jet 0: t0.., amp.., inv2s2..][jet 1: ...][epochs][per shape: x[N], cs[N][N]]
+  mp.stage.clear();
+  for (int j = 0; j < 2; ++j) {
+    mp.off_bursts[j] = mp.stage.size();
+    for (int k = 0; k < 3; ++k)
+      for (int i = 0; i < hb->n[j]; ++i)
+        mp.stage.push_back(k == 0 ? hb->t0[j][i] : k == 1 ? hb->amp_rel[j][i] : hb->inv2s2[j][i]);
   }
+  mp.off_epochs = mp.stage.size();
+  mp.stage.insert(mp.stage.end(), epochs, epochs + n_epochs);
+  const double pi = 3.14159265358979323846;
+  mp.w_total = 0;
+  for (MomCand& c : mp.cands) {
+    c.tab_off = mp.stage.size();
+    for (int i = 0; i < c.N; ++i) mp.stage.push_back(std::cos(pi * (i + 0.5) / c.N));
+    for (int n = 0; n < c.N; ++n)
+      for (int i = 0; i < c.N; ++i) mp.stage.push_back(std::cos(pi * n * (i + 0.5) / c.N));
+    c.w_off = mp.w_total;
+    mp.w_total += (size_t)mp.nchunk * 2 * c.K * c.N * RJP_MOM_TILE;
+  }
+  mp.s0 = fl->ts_lo;
+  return 2;
+}
+
+hipError_t moments_build(MomPlan& mp, const double* d_stage, hipStream_t st) {
+  hipError_t e;
+  if (!mp.d_err) {
+    e = hipMalloc((void**)&mp.d_err, RJP_MOM_MAX_CAND * sizeof(unsigned long long));
+    if (e != hipSuccess) return e;
+    e = hipHostMalloc((void**)&mp.h_err, RJP_MOM_MAX_CAND * sizeof(unsigned long long), hipHostMallocDefault);
+    if (e != hipSuccess) return e;
+  }
+  if (mp.w_total > mp.capW) {
+    // (tables of an earlier request may still be read by kernels in flight on this stream)
+    e = hipStreamSynchronize(st);
+    if (e != hipSuccess) return e;
+    if (mp.d_W) (void)hipFree(mp.d_W);
+    mp.d_W = nullptr; mp.capW = 0;
+    e = hipMalloc((void**)&mp.d_W, mp.w_total * sizeof(double));
+    if (e != hipSuccess) return e;
+    mp.capW = mp.w_total;
+  }
+  e = hipMemsetAsync(mp.d_W, 0, mp.w_total * sizeof(double), st);
+  if (e != hipSuccess) return e;
+  e = hipMemsetAsync(mp.d_err, 0, RJP_MOM_MAX_CAND * sizeof(unsigned long long), st);
+  if (e != hipSuccess) return e;
+  MomTabArgs a;
+  a.ncand = (int)mp.cands.size();
+  a.E = mp.key_E;
+  a.nb[0] = mp.key_n[0]; a.nb[1] = mp.key_n[1];
+  int kmax = 1;
+  for (int c = 0; c < a.ncand; ++c) {
+    a.K[c] = mp.cands[c].K; a.N[c] = mp.cands[c].N;
+    a.w_off[c] = (long long)mp.cands[c].w_off; a.tab_off[c] = (long long)mp.cands[c].tab_off;
+    kmax = std::max(kmax, a.K[c]);
+  }
+  a.off_b[0] = (long long)mp.off_bursts[0]; a.off_b[1] = (long long)mp.off_bursts[1];
+  a.off_e = (long long)mp.off_epochs;
+  a.s0 = mp.key_lo; a.span = mp.key_hi - mp.key_lo;
+  const unsigned nbx = (unsigned)((2 * kmax * a.E + 255) / 256);
+  hipLaunchKernelGGL(mom_tables_kernel, dim3(nbx, (unsigned)a.ncand), dim3(256), 0, st, d_stage, a,
+                     mp.d_W, mp.d_err);
+  e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  e = hipMemcpyAsync(mp.h_err, mp.d_err, RJP_MOM_MAX_CAND * sizeof(unsigned long long),
+                     hipMemcpyDeviceToHost, st);
+  if (e != hipSuccess) return e;
+  e = hipStreamSynchronize(st);                                  // the one sync of a new request
+  if (e != hipSuccess) return e;
+  mp.key_ok = false;
+  for (int c = 0; c < a.ncand && !mp.key_ok; ++c) {
+    double w;
+    std::memcpy(&w, &mp.h_err[c], sizeof(double));
+    mp.worst = w;
+    mp.K = mp.cands[c].K; mp.N = mp.cands[c].N; mp.path = mp.cands[c].path;
+    mp.d_Wsel = mp.d_W + mp.cands[c].w_off;
+    mp.key_ok = w <= RJP_MOM_TOL;                                // (NaN fails)
+  }
+  const double span = mp.key_hi - mp.key_lo;
+  mp.inv_h = span > 0.0 ? mp.K / span : 1.0;
+  mp.s0 = mp.key_lo;
   mp.ok = mp.key_ok;
-  return mp.ok;
+  return hipSuccess;
 }
 
 template <int K, int N>
@@ -374,9 +488,10 @@ static hipError_t moments_pass(const rjp_fields* fl, const double* weights, cons
 // `weights` = the field whose launch-time moments are taken (a0 for the optical-depth sums,
 // em0 for the emission measure: both carry the jet flag in their sign bit), `scale` = the
 // constant factor of the result (1 for the sums of a0).
-hipError_t moments_run(const rjp_fields* fl, const MomPlan& mp, const double* d_W, int n_epochs,
+hipError_t moments_run(const rjp_fields* fl, const MomPlan& mp, int n_epochs,
                        double* sumA, double* ws, hipStream_t st, const double* weights,
                        double scale) {
+  const double* d_W = mp.d_Wsel;
   const int64_t npix = (int64_t)fl->nx * fl->nz;
   const int64_t npixp = (npix + kMomSL - 1) / kMomSL * kMomSL;
   MomDev md;

@@ -65,25 +65,60 @@ hipError_t sum_partials_launch(const double* part, int rows, int nblk, double* o
 #define RJP_MOM_TILE 32          /* epochs per pass of the contraction */
 #define RJP_MOM_MIN_EPOCHS 12    /* below: the epoch tiles are faster */
 #define RJP_MOM_TOL 1e-11        /* worst relative error of the expansion the host accepts */
+#define RJP_MOM_MAX_CAND 12     /* (bins, order) shapes tried in one table build */
+#define RJP_MOM_NMAX 32         /* highest Chebyshev order of any shape */
+struct MomCand {
+  int K, N;
+  int path;                      // 1 = LDS moments, 2 = launch-time-ordered layout
+  size_t w_off;                  // doubles: this shape's tables in MomPlan::d_W
+  size_t tab_off;                // doubles: its nodes x[N] and DCT matrix cs[N][N] in MomPlan::stage
+};
 struct MomPlan {
   bool ok = false;
+  int path = 0;                  // 1 = LDS moments + contraction, 2 = launch-time-ordered layout
   double s0 = 0.0, inv_h = 0.0, worst = 0.0;
   int has_bursts[2] = {0, 0};
   int nchunk = 0;
-  int K = 0, N = 0;              // the shape the tables were built for
-  std::vector<double> W;         // [chunk][2 * K * N][TILE]
+  int K = 0, N = 0;              // the shape in use
+  const double* d_Wsel = nullptr;   // its tables, [chunk][2 * K * N][TILE], on the device
+  // device / pinned state of the table builder (owned; moments_release frees it)
+  double* d_W = nullptr;
+  size_t capW = 0;               // doubles
+  unsigned long long* d_err = nullptr;
+  unsigned long long* h_err = nullptr;
+  // one table build: the staged host table (bursts, epochs, nodes + DCT matrices) and shapes
+  std::vector<double> stage;
+  std::vector<MomCand> cands;
+  size_t w_total = 0, off_bursts[2] = {0, 0}, off_epochs = 0;
+  double build_ms = 0.0;         // host wall time of the last table build (incl. its one sync)
   // the request the tables were built for (a sweep repeated with the same epochs reuses them)
-  int key_E = -1, key_n[2] = {0, 0};
+  int key_E = -1, key_n[2] = {0, 0}, key_ltK = -1;
   bool key_ok = false;
   double key_lo = 0.0, key_hi = 0.0;
   std::vector<double> key_epochs, key_bursts;
 };
 size_t moments_workspace_bytes(int64_t npix);
-bool moments_plan(const rjp_fields* fl, const rjp_bursts* hb, const double* epochs, int n_epochs,
-                  int mode, bool want_em, size_t work_bytes, MomPlan& mp);
-hipError_t moments_run(const rjp_fields* fl, const MomPlan& mp, const double* d_W, int n_epochs,
+// 0 = this scan keeps the epoch tiles, 1 = moment path with the tables already on the device,
+// 2 = moment path after moments_build() (mp.stage has to be staged first)
+int moments_plan(const rjp_fields* fl, const rjp_bursts* hb, const double* epochs, int n_epochs,
+                 int mode, bool want_em, size_t work_bytes, MomPlan& mp);
+// builds and checks the tables of every candidate shape on the device (one launch, one 64-byte
+// copy back, ONE stream synchronisation) and selects the cheapest shape that passes; mp.ok says
+// whether one did.  `d_stage` = device copy of mp.stage.
+hipError_t moments_build(MomPlan& mp, const double* d_stage, hipStream_t st);
+void moments_release(MomPlan& mp);
+hipError_t moments_run(const rjp_fields* fl, const MomPlan& mp, int n_epochs,
                        double* sumA, double* ws, hipStream_t st, const double* weights,
                        double scale);
+// launch-time-ordered layout (ff_lt.hip)
+#define RJP_LT_MAX_K 80
+#define RJP_LT_MAX_EPOCHS 32     /* one fused pass serves one contraction tile */
+size_t lt_rowoff_entries(int nx, int nz, int K);
+hipError_t lt_count_launch(const rjp_fields* fl, int K, int32_t* d_rowoff, hipStream_t st);
+hipError_t lt_fill_launch(const rjp_fields* fl, int K, const int32_t* d_rowoff, void* d_cells,
+                          double* d_aux, hipStream_t st);
+hipError_t lt_run(const rjp_fields* fl, const MomPlan& mp, int n_epochs, double* sumA, double* ws,
+                  hipStream_t st);
 hipError_t field_range_launch(const void* d_field, int64_t n, int dtype, double* d_part,
                               hipStream_t st);
 

@@ -3,6 +3,7 @@
 // csrc/Makefile builds them in parallel); rjp_host.h declares their launch wrappers.
 #include <hip/hip_runtime.h>
 
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -21,7 +22,7 @@ struct rjp_ctx {
   // whose tables equal a slot's content (a sweep over epochs at a fixed channel list) reuses
   // the device copy: no host-to-device copy between the scan and the map stage.
   rjp::MomPlan mom;               // last moment-path request (its tables are reused)
-  int last_path = 0;              // 0 = epoch tiles, 1 = moments
+  int last_path = 0;              // 0 = epoch tiles, 1 = LDS moments, 2 = launch-time-ordered layout
   static constexpr int kSlots = 8;
   struct Slot {
     double* h = nullptr;
@@ -220,6 +221,7 @@ int rjp_ctx_destroy(rjp_ctx* ctx) {
   }
   if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
   if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+  rjp::moments_release(ctx->mom);
   delete ctx;
   return RJP_OK;
 }
@@ -350,28 +352,42 @@ int rjp_ff_scan(rjp_ctx* ctx, const rjp_fields* fields, const rjp_bursts* bursts
   hipStream_t st = (hipStream_t)stream;
   // epoch sweeps by launch-time moments (ff_moments.hip) when the caller provided the launch-time
   // range and the host-side accuracy check of the expansion passes
-  if (rjp::moments_plan(fields, bursts, h_epochs_s, n_epochs, gff_mode, d_em != nullptr,
-                        work_bytes, ctx->mom)) {
+  const int mr = rjp::moments_plan(fields, bursts, h_epochs_s, n_epochs, gff_mode, d_em != nullptr,
+                                   work_bytes, ctx->mom);
+  if (mr == 2) {
+    // a new (bursts, epochs) request: its coefficient tables are built and checked on the device
+    const auto t0 = std::chrono::steady_clock::now();
+    const double* src[1] = {ctx->mom.stage.data()};
+    const size_t len[1] = {ctx->mom.stage.size()};
+    double* dev[1];
+    if (int r = stage_tables(ctx, st, src, len, 1, dev)) return r;
+    const hipError_t e = rjp::moments_build(ctx->mom, dev[0], st);
+    if (int r = finish_staged(ctx, st, e, "moments_build")) return r;
+    ctx->mom.build_ms =
+        std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  }
+  if (mr && ctx->mom.ok) {
     if (d_tavg) {
       if (!fields->d_temp)
         return fail(ctx, RJP_ERR_ARG, "rjp_ff_scan: d_tavg on the tau layout needs fields.d_temp");
       RJP_HIP(ctx, rjp::tavg_launch(fields, d_tavg, (double*)d_work, st));
     }
-    ctx->last_path = 1;
-    const double* src[1] = {ctx->mom.W.data()};
-    const size_t len[1] = {ctx->mom.W.size()};
-    double* dev[1];
-    if (int r = stage_tables(ctx, st, src, len, 1, dev)) return r;
-    hipError_t e = rjp::moments_run(fields, ctx->mom, dev[0], n_epochs, d_sumA, (double*)d_work,
-                                    st, (const double*)fields->d_a0, 1.0);
+    ctx->last_path = ctx->mom.path;
+    if (ctx->mom.path == 2) {
+      RJP_HIP(ctx, rjp::lt_run(fields, ctx->mom, n_epochs, d_sumA, (double*)d_work, st));
+      return RJP_OK;
+    }
+    hipError_t e = rjp::moments_run(fields, ctx->mom, n_epochs, d_sumA, (double*)d_work, st,
+                                    (const double*)fields->d_a0, 1.0);
     if (e == hipSuccess && d_em) {
       // the emission measure of every epoch: the same pass and tables with em0 as the weight
       // (em = sum (n x)^2 * csize*au/pc * pf, classes.py:1116-1118)
       const double em_scale = fields->csize_au * 149597870700.0 / 3.085677581491367e+16;
-      e = rjp::moments_run(fields, ctx->mom, dev[0], n_epochs, d_em, (double*)d_work, st,
+      e = rjp::moments_run(fields, ctx->mom, n_epochs, d_em, (double*)d_work, st,
                            (const double*)fields->d_em0, em_scale);
     }
-    return finish_staged(ctx, st, e, "moments_run");
+    if (e != hipSuccess) return fail(ctx, RJP_ERR_HIP, "moments_run", e);
+    return RJP_OK;
   }
   ctx->last_path = 0;
   rjp::ScanPlan plan;
@@ -395,12 +411,58 @@ int rjp_ff_scan(rjp_ctx* ctx, const rjp_fields* fields, const rjp_bursts* bursts
 
 int rjp_last_scan_path(const rjp_ctx* ctx, double* worst_rel_err, int32_t* moment_shape) {
   if (!ctx) return RJP_ERR_ARG;
-  if (worst_rel_err) *worst_rel_err = ctx->last_path == 1 ? ctx->mom.worst : 0.0;
+  if (worst_rel_err) *worst_rel_err = ctx->last_path ? ctx->mom.worst : 0.0;
   if (moment_shape) {
-    moment_shape[0] = ctx->last_path == 1 ? ctx->mom.K : 0;
-    moment_shape[1] = ctx->last_path == 1 ? ctx->mom.N : 0;
+    moment_shape[0] = ctx->last_path ? ctx->mom.K : 0;
+    moment_shape[1] = ctx->last_path ? ctx->mom.N : 0;
   }
   return ctx->last_path;
+}
+
+double rjp_last_table_build_ms(const rjp_ctx* ctx) { return ctx ? ctx->mom.build_ms : 0.0; }
+
+size_t rjp_lt_rowoff_entries(int32_t nx, int32_t nz, int32_t K) {
+  if (nx <= 0 || nz <= 0 || K < 1 || K > RJP_LT_MAX_K) return 0;
+  return rjp::lt_rowoff_entries(nx, nz, K);
+}
+
+static int check_lt(rjp_ctx* ctx, const rjp_fields* f, int32_t K) {
+  if (!f) return fail(ctx, RJP_ERR_ARG, "fields is NULL");
+  if (f->dtype != RJP_F64 || !f->d_a0 || !f->d_ts)
+    return fail(ctx, RJP_ERR_ARG, "launch-time-ordered layout: needs RJP_F64 fields with d_a0 and d_ts");
+  if (f->nx <= 0 || f->ny <= 0 || f->nz <= 0 || f->ny >= 65536)
+    return fail(ctx, RJP_ERR_ARG, "launch-time-ordered layout: grid dimensions must be positive, n_y < 65536");
+  if (K < 1 || K > RJP_LT_MAX_K)
+    return fail(ctx, RJP_ERR_ARG, "launch-time-ordered layout: 1 <= K <= 80");
+  if (!(f->ts_hi >= f->ts_lo) || !std::isfinite(f->ts_lo) || !std::isfinite(f->ts_hi) ||
+      (f->ts_lo == 0.0 && f->ts_hi == 0.0))
+    return fail(ctx, RJP_ERR_ARG, "launch-time-ordered layout: fields.ts_lo / ts_hi (rjp_field_range) required");
+  return RJP_OK;
+}
+
+int rjp_lt_count(rjp_ctx* ctx, const rjp_fields* fields, int32_t K, int32_t* d_rowoff,
+                 int64_t* h_total_rows, void* stream) {
+  if (int r = bind(ctx)) return r;
+  if (int r = check_lt(ctx, fields, K)) return r;
+  if (!d_rowoff || !h_total_rows) return fail(ctx, RJP_ERR_ARG, "rjp_lt_count: NULL output");
+  hipStream_t st = (hipStream_t)stream;
+  RJP_HIP(ctx, rjp::lt_count_launch(fields, K, d_rowoff, st));
+  int32_t total = 0;
+  const size_t n = rjp::lt_rowoff_entries(fields->nx, fields->nz, K);
+  RJP_HIP(ctx, hipMemcpyAsync(&total, d_rowoff + (n - 1), sizeof(int32_t), hipMemcpyDeviceToHost, st));
+  RJP_HIP(ctx, hipStreamSynchronize(st));
+  if (total < 0) return fail(ctx, RJP_ERR_ARG, "rjp_lt_count: more than 2^31 rows");
+  *h_total_rows = total;
+  return RJP_OK;
+}
+
+int rjp_lt_fill(rjp_ctx* ctx, const rjp_fields* fields, int32_t K, const int32_t* d_rowoff,
+                void* d_cells, double* d_aux, void* stream) {
+  if (int r = bind(ctx)) return r;
+  if (int r = check_lt(ctx, fields, K)) return r;
+  if (!d_rowoff || !d_cells || !d_aux) return fail(ctx, RJP_ERR_ARG, "rjp_lt_fill: NULL argument");
+  RJP_HIP(ctx, rjp::lt_fill_launch(fields, K, d_rowoff, d_cells, d_aux, (hipStream_t)stream));
+  return RJP_OK;
 }
 
 int rjp_time_ff_scan(rjp_ctx* ctx, const rjp_fields* fields, const rjp_bursts* bursts,

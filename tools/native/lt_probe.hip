@@ -71,7 +71,7 @@ __global__ __launch_bounds__(256) void lt_count(const double* __restrict__ a0, c
     unsigned m = cnt[q * 64 + lane];
 #pragma unroll
     for (int d = 32; d > 0; d >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, d, 64));
-    if (lane == 0) rows[(size_t)blockIdx.x * Q + q] = (int)m;
+    if (lane == 0) rows[(size_t)blockIdx.x * Q + q] = (int)((m + 3u) & ~3u);     // chunks of 4 rows
   }
 }
 
@@ -199,6 +199,88 @@ __global__ __launch_bounds__(64) void lt_moments(const double2* __restrict__ cel
   for (int e = 0; e < ET; ++e) part[((size_t)sp * ET + e) * npix + p] = acc[e];
 }
 
+// v2: rows of every (group, bin) come in chunks of 4; the wave streams the chunks of its whole key
+// range through three rotating register buffers (8-12 rows in flight while it computes), bin
+// boundaries fall between chunks
+template <int N>
+__global__ __launch_bounds__(64) void lt_moments2(const double2* __restrict__ cells, const int* __restrict__ off,
+                                                  Bins b, int nsplit, const double* __restrict__ W,
+                                                  size_t npix, double* __restrict__ part) {
+  constexpr int ET = 32, C = 4;
+  const int Q = 2 * b.K;
+  const int g = blockIdx.x / nsplit, sp = blockIdx.x % nsplit;
+  const int q0 = (int)((long long)Q * sp / nsplit), q1 = (int)((long long)Q * (sp + 1) / nsplit);
+  const int lane = threadIdx.x;
+  const int* go = off + (size_t)g * Q;
+  double acc[ET], M[N];
+#pragma unroll
+  for (int e = 0; e < ET; ++e) acc[e] = 0.0;
+#pragma unroll
+  for (int n = 0; n < N; ++n) M[n] = 0.0;
+  const double c1 = 2.0 * b.inv_h;
+  const int R0 = go[q0], R1 = go[q1];
+  int q = q0, rnext = go[q0 + 1];
+  double c0 = -(2.0 * (b.s0 * b.inv_h + (q >= b.K ? q - b.K : q)) + 1.0);
+  const double2* base = cells + lane;
+  auto issue = [&](double2 (&buf)[C], int r) __attribute__((always_inline)) {
+    const int rc = r < R1 ? r : R1 - C;                 // clamped: never past the range
+#pragma unroll
+    for (int u = 0; u < C; ++u) buf[u] = ld2(base + (size_t)(rc + u) * 64);
+  };
+  auto step = [&](const double2 (&buf)[C], int r) __attribute__((always_inline)) {
+    if (r >= R1) return;
+    // bins that ended before this chunk (empty ones included)
+    while (r == rnext) {
+      const double* w = W + (size_t)q * N * ET;
+#pragma unroll
+      for (int n = 0; n < N; ++n) {
+#pragma unroll
+        for (int e = 0; e < ET; ++e) acc[e] = __builtin_fma(M[n], w[n * ET + e], acc[e]);
+        M[n] = 0.0;
+      }
+      ++q;
+      rnext = go[q + 1];
+      c0 = -(2.0 * (b.s0 * b.inv_h + (q >= b.K ? q - b.K : q)) + 1.0);
+    }
+#pragma unroll
+    for (int u = 0; u < C; ++u) {
+      const double xi = __builtin_fma(buf[u].y, c1, c0);
+      double tm = buf[u].x, tc = buf[u].x * xi;
+      const double x2 = xi + xi;
+      M[0] += tm;
+      M[1] += tc;
+#pragma unroll
+      for (int n = 2; n < N; ++n) {
+        const double tn = __builtin_fma(x2, tc, -tm);
+        tm = tc; tc = tn;
+        M[n] += tn;
+      }
+    }
+  };
+  if (R0 < R1) {
+    double2 A[C], B[C], D[C];
+    issue(A, R0); issue(B, R0 + C);
+    for (int r = R0; r < R1; r += 3 * C) {
+      issue(D, r + 2 * C); step(A, r);
+      issue(A, r + 3 * C); step(B, r + C);
+      issue(B, r + 4 * C); step(D, r + 2 * C);
+    }
+  }
+  // the last bin(s)
+  for (; q < q1; ++q) {
+    const double* w = W + (size_t)q * N * ET;
+#pragma unroll
+    for (int n = 0; n < N; ++n) {
+#pragma unroll
+      for (int e = 0; e < ET; ++e) acc[e] = __builtin_fma(M[n], w[n * ET + e], acc[e]);
+      M[n] = 0.0;
+    }
+  }
+  const size_t p = (size_t)g * 64 + lane;
+#pragma unroll
+  for (int e = 0; e < ET; ++e) part[((size_t)sp * ET + e) * npix + p] = acc[e];
+}
+
 __global__ __launch_bounds__(256) void lt_reduce(const double* __restrict__ part, int nsplit, size_t npix,
                                                  double* __restrict__ out) {
   const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;      // over 32 * npix
@@ -293,7 +375,8 @@ static void run(const double* a0, const double* ts, int nx, int ny, int nz, int 
   float best = 1e30f, bestr = 1e30f, bests = 1e30f;
   for (int rep = 0; rep < 5; ++rep) {
     CK(hipEventRecord(e0));
-    hipLaunchKernelGGL((lt_moments<N, U>), dim3((unsigned)(G * nsplit)), dim3(64), 0, 0, cells, off, b, nsplit, dW, npix, part);
+    if (U == 0) hipLaunchKernelGGL((lt_moments2<N>), dim3((unsigned)(G * nsplit)), dim3(64), 0, 0, cells, off, b, nsplit, dW, npix, part);
+    else hipLaunchKernelGGL((lt_moments<N, (U ? U : 4)>), dim3((unsigned)(G * nsplit)), dim3(64), 0, 0, cells, off, b, nsplit, dW, npix, part);
     CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1)); CK(hipEventElapsedTime(&ms, e0, e1)); best = std::min(best, ms);
     CK(hipEventRecord(e0));
     hipLaunchKernelGGL(lt_reduce, dim3((unsigned)((32 * npix + 255) / 256)), dim3(256), 0, 0, part, nsplit, npix, out);
@@ -336,12 +419,14 @@ int main(int argc, char** argv) {
   CK(hipMalloc(&a0, n * 8)); CK(hipMalloc(&ts, n * 8));
   hipLaunchKernelGGL(fill, dim3(8192), dim3(256), 0, 0, a0, ts, n, nz);
   CK(hipDeviceSynchronize());
-  run<12, 8>(a0, ts, nx, ny, nz, 53, 4);
-  run<12, 4>(a0, ts, nx, ny, nz, 53, 4);
-  run<12, 8>(a0, ts, nx, ny, nz, 53, 8);
-  run<16, 8>(a0, ts, nx, ny, nz, 40, 4);
-  run<20, 8>(a0, ts, nx, ny, nz, 32, 4);
-  run<24, 8>(a0, ts, nx, ny, nz, 26, 4);
-  run<24, 4>(a0, ts, nx, ny, nz, 26, 4);
+  run<12, 0>(a0, ts, nx, ny, nz, 53, 4);
+  run<12, 0>(a0, ts, nx, ny, nz, 53, 8);
+  run<12, 4>(a0, ts, nx, ny, nz, 53, 8);
+  run<14, 0>(a0, ts, nx, ny, nz, 36, 8);
+  run<16, 0>(a0, ts, nx, ny, nz, 32, 8);
+  run<20, 0>(a0, ts, nx, ny, nz, 24, 8);
+  run<24, 0>(a0, ts, nx, ny, nz, 20, 8);
+  run<28, 0>(a0, ts, nx, ny, nz, 16, 8);
+  run<28, 0>(a0, ts, nx, ny, nz, 16, 16);
   return 0;
 }
