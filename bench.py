@@ -124,6 +124,13 @@ def parse(argv=None):
                     help="length of the back-to-back leg after the contract timing (0 = skip): "
                          "long enough that clock / power droop would show and that a monitor "
                          "sampling the GPU every few seconds sees it busy")
+    ap.add_argument("--lt", action="store_true",
+                    help="cfg5-like sweeps: build the launch-time-ordered layout of (a0, ts) before "
+                         "the timed region (per-model state like a0 itself, its build time is "
+                         "reported): 12-32-epoch sweeps then keep their moments in registers")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="N = 1, default config only: skip the `configs` object (cfg2 / cfg3 / "
+                         "cfg5 measured in the same process after the contract timing)")
     ap.add_argument("--no-api-level", action="store_true",
                     help="skip the PCIe-inclusive leg (step + copy of the cubes to pinned host)")
     return ap.parse_args(argv)
@@ -472,11 +479,12 @@ def rehearse_cpu(args, rank, world):
 # the GPU workload of one rank under one sharding
 # ---------------------------------------------------------------------------------------
 class Workload:
-    def __init__(self, eng, args, sharding, rank, world):
+    def __init__(self, eng, args, sharding, rank, world, config=None, lt=None):
         from rajepy_amd import _lib, engine as E
         from rajepy_amd.maths import physics as ph, rrls
         self.eng, self.args, self.rank, self.world = eng, args, rank, world
-        self.pl = pl = plan(args.config, sharding, rank, world)
+        config = config or args.config
+        self.pl = pl = plan(config, sharding, rank, world)
         self.rrl = pl["rrl"]
         self.dtype = E.RJP_F64 if args.storage == "f64" else E.RJP_F32
         self.plaw = args.gaunt == "powerlaw"
@@ -484,7 +492,7 @@ class Workload:
         lshape = pl["lshape"]
         self.P = lshape[0] * lshape[2]
         self.ncell_loc = lshape[0] * lshape[1] * lshape[2]
-        lean = args.config == "cfg4x8"            # generate em0, temp, ts only (24 B/cell)
+        lean = config == "cfg4x8"                 # generate em0, temp, ts only (24 B/cell)
         tau = args.layout == "tau" and self.dtype == E.RJP_F64 and not (lean and args.em)
         self.fields = eng.synth_fields(lshape, SEED, 1 if self.plaw else 0, self.dtype,
                                        csize_au=0.5, with_vy=self.rrl, cell0=pl["cell0"],
@@ -493,6 +501,13 @@ class Workload:
         self._em0 = self.fields.em0
         if args.layout == "wide":
             self.fields.em0 = None
+        # the launch-time-ordered layout (epoch sweeps): per-model state, built once
+        self.lt_info = None
+        if (args.lt if lt is None else lt) and pl["n_ep_cfg"] and self.fields.a0 is not None:
+            info = eng.build_lt(self.fields, 32)
+            self.lt_info = {k: info[k] for k in ("K", "rows", "build_ms",
+                                                 "build_with_allocation_ms", "bytes")}
+            self.lt_info["padding"] = info["rows"] * 64 / float(self.ncell_loc)
         ej = EXAMPLE_BURSTS
         red, blue = [], []
         for t0, hl, chi, which in zip(ej["t_0"], ej["hl"], ej["chi"], ej["which"]):
@@ -559,9 +574,172 @@ class Workload:
         return collect(self.local_step(), self.pl, self.rank, self.world, self.args.backend)
 
     def release(self):
+        if self.fields is not None:
+            self.fields.lt = None
         self.fields = self._em0 = self.sumA = self.em = self.tau = self.flux = None
         import torch
         torch.cuda.empty_cache()
+
+
+# ---------------------------------------------------------------------------------------
+# the other BASELINE configurations, measured in the same process (N = 1, default config)
+# ---------------------------------------------------------------------------------------
+def _latest_profile(pattern):
+    """Newest committed profiles/<round>_<pattern> (rounds sort r04 > r03e > r03 ...)."""
+    import glob
+    hits = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_" + pattern)))
+    return hits[-1] if hits else None
+
+
+def measure_other_configs(eng, args, torch):
+    """cfg2, cfg5 (warm and cold, LDS moments and launch-time-ordered layout) and cfg3 on this
+    GPU, each with freshly generated fields, after the contract timing of the default config.
+    Wall times are synchronised on both sides; kernel times come from HIP events on the launch
+    stream.  Returns the `configs` object of the line."""
+    from rajepy_amd import engine as E
+    out = {}
+
+    def wall(fn, steps, warm):
+        for _ in range(warm):
+            fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / steps * 1e3
+
+    def rate(cfg, ms, epochs):
+        shp, nch = CONFIGS[cfg][0], CONFIGS[cfg][1]
+        return shp[0] * shp[1] * shp[2] * nch * epochs / (ms * 1e-3) / 1e6
+
+    # ---- cfg2: 256x1024x256 x 32 channels, one epoch -------------------------------------
+    try:
+        w = Workload(eng, args, "none", 0, 1, config="cfg2", lt=False)
+        ms = wall(w.local_step, 300, 30)
+        k1 = eng.time_ff_scan(w.fields, w.bursts, w.my_epochs, w.gmode, reps=50, want_em=False,
+                              want_tavg=False)
+        nf = w.fields.scan_fields(w.gmode, False)
+        b = nf * w.ncell_loc * int(w.dtype) + w.P * 8
+        out["cfg2"] = {"workload": "256x1024x256 x 32 continuum channels, one epoch per step "
+                                   "(K1 scan + K2 tau/flux cubes)",
+                       "ms_per_step": ms, "value": rate("cfg2", ms, 1),
+                       "k1_ms_per_launch": k1, "k1_algorithmic_bytes": b,
+                       "k1_frac": b / (k1 * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                       "fields_streamed_per_cell": nf}
+        w.release()
+        del w
+    except Exception as exc:                                   # a leg must never void the line
+        out["cfg2"] = {"error": "%s: %s" % (type(exc).__name__, str(exc)[:300])}
+
+    # ---- cfg5: 512x4096x512 x 64 channels x 32 epochs, flux-vs-time ------------------------
+    try:
+        w = Workload(eng, args, "none", 0, 1, config="cfg5", lt=False)
+        E5 = len(w.my_epochs)
+        alg = 2 * w.ncell_loc * 8 + E5 * w.P * 8          # a0 + ts once, E base maps
+        alg_unfused = E5 * 5 * w.ncell_loc * 8 + E5 * w.P * 2 * 8
+        orig = list(w.my_epochs)
+
+        def leg():
+            """first call of a NEW (bursts, epochs) request -- the coefficient tables are built
+            and checked on the device inside it -- then the warm figure and the kernel time"""
+            w.my_epochs = [t + 1.0 for t in orig]          # same sweep, one second later
+            w.local_step()
+            torch.cuda.synchronize()
+            w.my_epochs = orig
+            t0 = time.perf_counter()
+            w.local_step()                                 # a new request again
+            torch.cuda.synchronize()
+            cold = (time.perf_counter() - t0) * 1e3
+            tab = eng.last_table_build_ms()
+            warm = wall(w.local_step, 20, 2)
+            k1 = eng.time_ff_scan(w.fields, w.bursts, w.my_epochs, w.gmode, reps=10,
+                                  want_em=False, want_tavg=False)
+            path, err = eng.last_scan_path()
+            return {"scan_path": path, "shape_bins_order": list(eng.last_moment_shape),
+                    "worst_rel_err_of_the_expansion": err,
+                    "ms_per_step": warm, "value": rate("cfg5", warm, E5),
+                    "cold_new_request_ms": cold, "cold_over_warm": cold / warm,
+                    "table_build_ms": tab, "k1_stage_ms": k1,
+                    "frac": alg / (k1 * 1e-3) / 1e9 / HBM_PEAK_GBS}
+
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        w.local_step()
+        torch.cuda.synchronize()
+        first_ever = (time.perf_counter() - t0) * 1e3
+        lds = leg()
+        lds["first_call_in_this_process_ms"] = first_ever  # + the kernels' code objects
+        info = eng.build_lt(w.fields, 32)
+        lt = leg()
+        lt.update({"layout_build_ms": info["build_ms"],
+                   "layout_build_with_allocation_ms": info["build_with_allocation_ms"],
+                   "layout_bytes": info["bytes"],
+                   "padding": info["rows"] * 64 / float(w.ncell_loc),
+                   "sweeps_to_amortise_the_build": info["build_ms"] /
+                   max(1e-9, lds["ms_per_step"] - lt["ms_per_step"])})
+        c5 = {"workload": "512x4096x512 x 64 continuum channels x 32 uniformly spaced epochs per "
+                          "step, flux-vs-time output (K1 epoch sweep + light-curve kernel)",
+              "algorithmic_bytes": alg, "algorithmic_bytes_8d_unfused": alg_unfused,
+              "frac_is": "algorithmic_bytes (a0 + ts once + 32 base maps) / k1_stage_ms / 8 TB/s",
+              "lds_moments": lds, "lt_layout": lt,
+              "ms_per_step": lt["ms_per_step"], "value": lt["value"],
+              "ms_per_step_cold_path": lds["ms_per_step"],
+              "note": "lds_moments = what a model's FIRST sweep runs (no per-model preparation "
+                      "beyond a0); lt_layout = sweeps of a model whose launch-time-ordered layout "
+                      "was built once (layout_build_ms, like a0 itself)"}
+        for tag, key in (("cfg5_f64_pmc.json", "traffic"), ("cfg5_f64_lt_pmc.json", "traffic_lt")):
+            f = _latest_profile(tag)
+            if f:
+                try:
+                    c5[key] = json.load(open(f)).get("hbm_bytes_per_launch")
+                    c5[key + "_source"] = os.path.relpath(f, ROOT) + \
+                        " (rocprofv3 --pmc passes of an earlier run, not measured in this run)"
+                except Exception:
+                    pass
+        out["cfg5"] = c5
+        w.release()
+        del w, info
+    except Exception as exc:
+        out["cfg5"] = {"error": "%s: %s" % (type(exc).__name__, str(exc)[:300])}
+    torch.cuda.empty_cache()
+
+    # ---- cfg3: 512x2048x512 x 256 H66a channels --------------------------------------------
+    try:
+        w = Workload(eng, args, "none", 0, 1, config="cfg3", lt=False)
+        ms = wall(w.local_step, 2, 1)
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
+        for _ in range(2):
+            eng.rrl_scan(w.fields, w.bursts, w.my_epochs[0], w.line, w.freqs)
+        ev1.record()
+        torch.cuda.synchronize()
+        k3 = ev0.elapsed_time(ev1) / 2
+        evals = w.ncell_loc * w.nchan / (k3 * 1e-3)
+        c3 = {"workload": "512x2048x512 x 256 H66a channels of 100 kHz (K3 RRL scan + K1/K2 "
+                          "continuum + line flux cube)",
+              "ms_per_step": ms, "value": rate("cfg3", ms, 1), "k3_ms_per_launch": k3,
+              "voigt_evals_per_s": evals,
+              "fp64_vector_peak_lane_ops_per_s": 256 * 4 * 16 * 2.4e9,
+              "hbm_frac": (6 * w.ncell_loc * 8 + w.nchan * w.P * 8) / (k3 * 1e-3) / 1e9 /
+              HBM_PEAK_GBS}
+        f = _latest_profile("cfg3_k3_sq.json")
+        if f:
+            try:
+                ipe = json.load(open(f))["derived"]["valu_lane_insts_per_work_item"]
+                c3["valu_insts_per_eval"] = ipe
+                c3["valu_insts_per_eval_source"] = os.path.relpath(f, ROOT) + \
+                    " (SQ counters of an earlier run)"
+                c3["valu_issue_frac_of_256x4x16_lanes_at_2.4GHz"] = evals * ipe / (256 * 4 * 16 * 2.4e9)
+            except Exception:
+                pass
+        out["cfg3"] = c3
+        w.release()
+        del w
+    except Exception as exc:
+        out["cfg3"] = {"error": "%s: %s" % (type(exc).__name__, str(exc)[:300])}
+    torch.cuda.empty_cache()
+    return out
 
 
 def device_identity(torch, index):
@@ -738,11 +916,12 @@ def main(argv=None):
         dma = E_loc >= 16 and long_tiles and fields.shape[2] % 2 == 0
         kname = "ff_scan_tile_kernel" if dma else "ff_scan_kernel"
         scan_path, mom_err = eng.last_scan_path()
-        if scan_path == "moments":
-            # the sweep went through the launch-time moments (ff_moments.hip): ONE pass over the
-            # grid for all epochs of the launch + a contraction over the moment maps
-            kname, npass = "moments_kernel", 1
-        if scan_path == "moments":
+        if scan_path in ("moments", "lt"):
+            # the sweep went through the launch-time moments (ff_moments.hip / ff_lt.hip): ONE pass
+            # over the grid for all epochs of the launch (+ a contraction over the moment maps
+            # on the LDS path; fused on the launch-time-ordered layout)
+            kname, npass = ("moments_kernel" if scan_path == "moments" else "lt_moments_kernel"), 1
+        if scan_path in ("moments", "lt"):
             alg_bytes = npass * nfld * ncell_loc * dsz + base_maps
             alg_8d = npass * 5 * ncell_loc * dsz + E_loc * P * 2 * 8
         roof_extra = {"grid_passes_per_launch": npass, "fields_streamed_per_cell": nfld,
@@ -752,6 +931,16 @@ def main(argv=None):
                                "what": "T_avg = nanmean_y(T > 0) is independent of frequency "
                                        "and epoch: one rjp_tavg pass per MODEL, not part of "
                                        "a step"}}
+        if scan_path == "lt":
+            roof_extra["lt"] = dict(wl.lt_info or {}, **{
+                "what": "launch-time-ordered layout (per-model state): every group of 64 "
+                        "sightlines bucketed by (jet, launch-time bin); the sweep keeps a bin's "
+                        "Chebyshev moments in registers and contracts them at the bin's end -- no "
+                        "LDS atomics, no moment maps in HBM; `frac` is priced on the ALGORITHMIC "
+                        "bytes (a0 + ts), the kernel reads `padding` x as many",
+                "shape_bins_order": list(eng.last_moment_shape),
+                "worst_rel_err_of_the_expansion": mom_err,
+                "padded_bytes_per_launch": (wl.lt_info or {}).get("bytes")})
         if scan_path == "moments":
             roof_extra["moments"] = {
                 "what": "sum_y a0 chi(t_e - ts)^2 as a convolution over launch time: one pass "
@@ -876,6 +1065,12 @@ def main(argv=None):
         except RuntimeError as exc:
             api_level = {"error": str(exc)[:200]}
 
+    # ---- the other BASELINE configs under the same clock (N = 1, default config) ---------
+    other = None
+    if world == 1 and args.config == "cfg4" and not args.no_other_configs and not rehearsal:
+        wl.release()
+        other = measure_other_configs(eng, args, torch)
+
     # ---- N > 1: the other labelled legs and the N = 1 reference --------------------------
     legs, n1 = {}, None
     if world > 1 and not args.no_extra_legs:
@@ -955,6 +1150,26 @@ def main(argv=None):
                                    "%d distinct device(s) for %d ranks" % (distinct_devices, world)
                                    if distinct_devices < world else
                                    "backend %s, not RCCL" % args.backend)
+    if not rrl and "wide_ms_per_launch" in roofline:
+        # SURVEY 8(d)'s workload literally: ONE epoch from the five model fields (nd, xi, temp,
+        # pf, ts) -- the wide kernel's scan (tau + EM + T_avg sums) + this step's map stage
+        ms_wide_step = roofline["wide_ms_per_launch"] + max(0.0, ms_step - k_ms)
+        result["value_from_model_fields"] = rate(ms_wide_step, total_epochs)
+        result["value_from_model_fields_what"] = (
+            "%.3f ms = the wide-layout scan of the five model fields (%.3f ms, frac_8d) + the map "
+            "stage of this step (%.3f ms): what one epoch costs without the per-model scan "
+            "fields a0 / em0 and the per-model T_avg map" %
+            (ms_wide_step, roofline["wide_ms_per_launch"], max(0.0, ms_step - k_ms)))
+    if not rrl and "with_em" in roofline and not n_ep_cfg:
+        # the step as rounds 1-2 defined it (EM map of the epoch and T_avg inside the step)
+        ms_r02 = roofline["with_em"]["ms_per_launch"] + wl.tavg_ms + max(0.0, ms_step - k_ms)
+        result["value_r02_workload"] = rate(ms_r02, total_epochs)
+        result["config"]["workload_version"] = (
+            "r03+: the timed step produces tau and flux cubes; the emission-measure map (--em) and "
+            "T_avg (per-model rjp_tavg) are outside it.  value_r02_workload re-prices the step "
+            "with both inside (%.3f ms), comparable with BENCH_r02" % ms_r02)
+    if other:
+        result["configs"] = other
     if sustained:
         result["sustained"] = sustained
     if api_level:

@@ -305,19 +305,24 @@ class RTEngine:
             raise ValueError("K must be 1..80")
         rowoff = torch.empty(n_off, dtype=torch.int32, device=self.device)
         total = C.c_int64()
-        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        ev0.record()
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+        ev[0].record()
         _lib.check(self.lib.rjp_lt_count(self.ctx, C.byref(fs), int(K), rowoff.data_ptr(),
                                          C.byref(total), self._stream()), self.ctx, "rjp_lt_count")
+        ev[1].record()
+        # (allocating ~1.2 x the bytes of a0 + ts is the slow part of a first build: hipMalloc)
         cells = torch.empty(max(1, total.value) * 64 * 2, dtype=torch.float64, device=self.device)
         aux = torch.empty(3 * fields.npix, dtype=torch.float64, device=self.device)
+        ev[2].record()
         _lib.check(self.lib.rjp_lt_fill(self.ctx, C.byref(fs), int(K), rowoff.data_ptr(),
                                         cells.data_ptr(), aux.data_ptr(), self._stream()),
                    self.ctx, "rjp_lt_fill")
-        ev1.record()
+        ev[3].record()
         torch.cuda.synchronize(self.device)
+        kernels_ms = ev[0].elapsed_time(ev[1]) + ev[2].elapsed_time(ev[3])
         fields.lt = {"cells": cells, "rowoff": rowoff, "aux": aux, "K": int(K),
-                     "rows": int(total.value), "build_ms": ev0.elapsed_time(ev1),
+                     "rows": int(total.value), "build_ms": kernels_ms,
+                     "build_with_allocation_ms": ev[0].elapsed_time(ev[3]),
                      "bytes": cells.numel() * 8,
                      "key": (fields.a0.data_ptr(), fields.ts.data_ptr(), fs.ts_lo, fs.ts_hi)}
         return fields.lt

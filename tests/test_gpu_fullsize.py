@@ -197,7 +197,26 @@ def test_cfg5_epoch_sweep_by_launch_time_moments_full_size(eng):
     for e in (0, 15, 31):
         jet.time = ep[e]
         np.testing.assert_allclose(ctau[0] * m_s[e], jet.optical_depth_ff(5e9)[:, 0], rtol=1e-10)
-    del mom, til
+    # round 4: the same sweep on the launch-time-ordered layout (register moments fused with the
+    # contraction): the whole [32, P] result against the LDS moments and the tiles at 5e-11, the
+    # sampled sightlines against the oracle, two sweeps of one layout bit for bit
+    import torch
+    lt = eng.build_lt(fields, 32)
+    assert lt["rows"] * 64 < 1.3 * nx * ny * nz                   # padding: 1.22 x on this grid
+    ltr = eng.ff_scan(fields, bursts, ep, E.RJP_GFF_SCALAR, want_em=False, want_tavg=False)[0].clone()
+    path, err = eng.last_scan_path()
+    assert path == "lt" and err <= 1e-11 and eng.last_moment_shape[0] == 32
+    ltr2 = eng.ff_scan(fields, bursts, ep, E.RJP_GFF_SCALAR, want_em=False, want_tavg=False)[0]
+    eng.synchronize()
+    assert torch.equal(ltr.view(torch.int64), ltr2.view(torch.int64))
+    assert ((ltr - til).abs() / til).max().item() < 5e-11
+    assert ((ltr - mom).abs() / mom).max().item() < 5e-11
+    l_s = ltr.cpu().numpy()[:, idx]
+    for e in (0, 15, 31):
+        jet.time = ep[e]
+        np.testing.assert_allclose(ctau[0] * l_s[e], jet.optical_depth_ff(5e9)[:, 0], rtol=1e-10)
+    fields.lt = None
+    del mom, til, ltr, ltr2, lt
     ep2 = sorted(float(t) for t in rng.uniform(0., 5., 40) * orc.YEAR)
     mom2 = eng.ff_scan(fields, bursts, ep2, E.RJP_GFF_SCALAR, want_em=False, want_tavg=False)[0]
     assert eng.last_scan_path()[0] == "moments"

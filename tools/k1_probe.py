@@ -20,6 +20,9 @@ fields = eng.synth_fields(shape, 20240504, 1 if os.environ.get("PROBE_POWERLAW")
                           tau_mode=MODE if (LAYOUT == "tau" and storage == "f64") else None)
 if LAYOUT == "wide":
     fields.em0 = None
+if os.environ.get("PROBE_LT"):              # launch-time-ordered layout, K bins per jet
+    info = eng.build_lt(fields, int(os.environ["PROBE_LT"]))
+    print("lt layout: K=%d rows=%d build %.1f ms" % (info["K"], info["rows"], info["build_ms"]))
 ej = bench.EXAMPLE_BURSTS
 red, blue = [], []
 for t0, hl, chi, which in zip(ej["t_0"], ej["hl"], ej["chi"], ej["which"]):
@@ -36,6 +39,7 @@ n = shape[0] * shape[1] * shape[2]
 npass = -(-nep // (32 if nep >= 32 else 16 if nep >= 16 else 8)) if nep > 1 else 1
 nf = fields.scan_fields(MODE, want_em)
 gb = npass * nf * n * int(dtype) / 1e9
+print("path", eng.last_scan_path(), eng.last_moment_shape)
 print("%s %s %s E=%d lib=%s ysplit=%s: %.3f ms  %.0f GB/s (alg)  %.3f ms/epoch" % (
     cfg, storage, "%d fields" % nf, nep, os.path.basename(os.environ.get("RJP_LIB", "default")),
     os.environ.get("RJP_YSPLIT", "auto"), ms, gb / ms * 1e3, ms / nep))
