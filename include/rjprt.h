@@ -244,7 +244,8 @@ int rjp_ff_scan(rjp_ctx* ctx, const rjp_fields* fields, const rjp_bursts* bursts
                 void* d_work, size_t work_bytes, void* stream);
 
 /* Which path the last rjp_ff_scan of this context took: 0 = epoch tiles, 1 = launch-time moments
- * in LDS + contraction, 2 = launch-time moments on the launch-time-ordered layout (and, if
+ * in LDS + contraction, 2 = launch-time moments on the launch-time-ordered layout, 3 = the
+ * single-epoch tau-layout scan with the burst factor from a table in LDS (and, if
  * non-NULL: in *worst_rel_err the worst relative error of the moment expansion measured for
  * that call, in moment_shape[0..1] the (bins, order) shape it chose; zeros for the tiles).
  * For tests and the bench line. */

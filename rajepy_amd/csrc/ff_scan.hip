@@ -134,6 +134,14 @@ __global__ __launch_bounds__(kBlock) void ff_reduce_kernel(
   }
 }
 
+hipError_t ff_reduce_launch(const double* ws, int nsplit, int et, int64_t npix, int e0,
+                            double em_scale, double* sumA, double* em, double* tavg,
+                            hipStream_t st) {
+  hipLaunchKernelGGL(ff_reduce_kernel, dim3((unsigned)((npix + kBlock - 1) / kBlock)), dim3(kBlock),
+                     0, st, ws, nsplit, et, npix, e0, em_scale, sumA, em, tavg);
+  return hipGetLastError();
+}
+
 // ---- K2 ------------------------------------------------------------------------------
 // One thread per VEC adjacent pixels, serial over the channels of its slice: every store
 // instruction is a coalesced row segment of one (epoch, channel) map, 16 B per lane when the
@@ -178,6 +186,63 @@ __global__ __launch_bounds__(kBlock) void ff_maps_kernel(
       for (int d = RJP_WAVE / 2; d > 0; d >>= 1) acc += __shfl_down(acc, d, RJP_WAVE);
       if ((threadIdx.x & (RJP_WAVE - 1)) == 0)
         part[((int64_t)e * nchan + f) * nparts + slot] = acc;
+    }
+  }
+}
+
+// The cube kernel for maps large enough to fill the chip with FEWER, fatter threads (round 4): a
+// lane walks `kp` pixel groups for kMapsFC channels, stores as above, and keeps one flux
+// accumulator per channel in registers -- the six-step wave reduction (a third of the kernel's
+// issue slots when it came once per channel and pixel pair: 0.11 of cfg4's 0.24 ms) now comes
+// once per channel and LANE, as in ff_ftot_kernel below.  Same arithmetic per (pixel, channel);
+// the totals are summed in another (fixed) order.
+constexpr int kMapsFC = 16;      // channels per workgroup (gridDim.z slices the channel axis)
+template <int VEC, bool FT>
+__global__ __launch_bounds__(kBlock) void ff_maps_acc_kernel(
+    const double* __restrict__ sumA, const double* __restrict__ tavg, int64_t npix,
+    const double* __restrict__ ctau, const double* __restrict__ cflux, int nchan, int kp,
+    double* __restrict__ tau, double* __restrict__ flux, double* __restrict__ part, int nparts) {
+  const int e = blockIdx.y;
+  const int f0 = blockIdx.z * kMapsFC;
+  const int nf = min(nchan - f0, kMapsFC);
+  double acc[kMapsFC];
+#pragma unroll
+  for (int j = 0; j < kMapsFC; ++j) acc[j] = 0.0;
+#pragma unroll 1
+  for (int k = 0; k < kp; ++k) {
+    const int64_t p = (((int64_t)blockIdx.x * kp + k) * kBlock + threadIdx.x) * VEC;
+    if (p >= npix) continue;                       // npix % VEC == 0
+    double A[VEC], ta[VEC];
+    load_plain(sumA + (int64_t)e * npix + p, A);
+    load_plain(tavg + p, ta);
+#pragma unroll
+    for (int j = 0; j < kMapsFC; ++j) {
+      if (j < nf) {
+        const double ct = ctau[f0 + j], cf = cflux[f0 + j];
+        double t[VEC], s[VEC];
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) {
+          t[v] = ct * A[v];
+          s[v] = cf * (ta[v] * one_minus_exp_neg(t[v]));
+          if (FT) acc[j] += s[v] == s[v] ? s[v] : 0.0;                 // nansum
+        }
+        const int64_t o = ((int64_t)e * nchan + f0 + j) * npix + p;
+        if (tau) store_cube(tau + o, t);
+        if (flux) store_cube(flux + o, s);
+      }
+    }
+  }
+  if (FT) {
+    const int slot = blockIdx.x * (kBlock / RJP_WAVE) + threadIdx.x / RJP_WAVE;
+#pragma unroll
+    for (int j = 0; j < kMapsFC; ++j) {
+      if (j < nf) {
+        double a = acc[j];
+#pragma unroll
+        for (int d = RJP_WAVE / 2; d > 0; d >>= 1) a += __shfl_down(a, d, RJP_WAVE);
+        if ((threadIdx.x & (RJP_WAVE - 1)) == 0)
+          part[((int64_t)e * nchan + f0 + j) * nparts + slot] = a;
+      }
     }
   }
 }
@@ -713,6 +778,33 @@ hipError_t ff_maps_launch(const double* sumA, const double* tavg, int64_t npix, 
     return sum_partials_launch(part, n_epochs * n_chan, np, ftot, st);
   }
   const unsigned nblk = (unsigned)((lanes + kBlock - 1) / kBlock);
+  {
+    // maps that fill the chip with 16 channels (x 4 pixel groups) per lane: the kernel with
+    // per-lane flux accumulators
+    const unsigned nzc = (unsigned)((n_chan + kMapsFC - 1) / kMapsFC);
+    const unsigned nb4 = (unsigned)((lanes + (int64_t)kBlock * 4 - 1) / ((int64_t)kBlock * 4));
+    int kp = 0;
+    if ((int64_t)nb4 * n_epochs * nzc >= 1024) kp = 4;
+    else if ((int64_t)nblk * n_epochs * nzc >= 1024) kp = 1;
+    if (kp) {
+      const unsigned nbx = kp == 4 ? nb4 : nblk;
+      const int np = (int)nbx * (kBlock / RJP_WAVE);
+      dim3 g(nbx, (unsigned)n_epochs, nzc);
+      auto go = [&](auto vtag, auto ftag) {
+        constexpr int V = decltype(vtag)::value;
+        constexpr bool FT = decltype(ftag)::value;
+        hipLaunchKernelGGL((ff_maps_acc_kernel<V, FT>), g, dim3(kBlock), 0, st, sumA, tavg, npix,
+                           d_ctau, d_cflux, n_chan, kp, tau, flux, ftot ? part : nullptr, np);
+      };
+      using I1 = std::integral_constant<int, 1>;
+      using I2 = std::integral_constant<int, 2>;
+      if (vec2) { if (ftot) go(I2{}, std::true_type{}); else go(I2{}, std::false_type{}); }
+      else { if (ftot) go(I1{}, std::true_type{}); else go(I1{}, std::false_type{}); }
+      hipError_t e1 = hipGetLastError();
+      if (e1 != hipSuccess) return e1;
+      return ftot ? sum_partials_launch(part, n_epochs * n_chan, np, ftot, st) : hipSuccess;
+    }
+  }
   const int nparts = (int)nblk * (kBlock / RJP_WAVE);
   // split channels over gridDim.z so that small maps still expose >= ~2048 blocks
   int fsplit = 1;

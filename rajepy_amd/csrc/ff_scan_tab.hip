@@ -1,0 +1,284 @@
+// K1, single epoch, tau layout: the burst factor from a table in LDS (round 4).
+//
+// The single-epoch scan of (a0, ts) spends ~42 of its 51 vector instructions per cell on the 2-3
+// burst Gaussians of chi(t - ts) (classes.py:442-448, 866-868) and is co-limited by vector-ALU
+// issue at a power-limited clock (profiles/r03c_cfg4_k1_tau_sq.json).  chi is a function of ONE
+// variable, the time since launch: per call it is tabulated on the interval of times since launch
+// that can occur AND matter -- [t - ts_hi, t - ts_lo] cut with the bursts' support (chi == 1 to
+// 1e-17 outside) -- as piecewise quintics, 6 coefficients (48 bytes) per interval and jet, built
+// on the device by a tiny kernel in front of the scan (6 Chebyshev nodes per interval, Vandermonde
+// inverse from the host).  A cell costs one interval lookup: three 16-byte LDS reads at a random
+// address + 5 FMAs, whatever the number of bursts.  The number of intervals follows from the
+// interpolation bound  |chi - p| <= max|chi^(6)| (h/2)^6 / (6! 2^5),  max|G^(6)| = 15 A / sigma^6
+// for a Gaussian of amplitude A: h is chosen so that the bound is <= 1e-13 (chi >= 1: bursts with
+// a negative amplitude keep the Gaussians), i.e. <= 2e-13 relative on chi^2; a table that would
+// not fit 64 KB of LDS (682 intervals per jet) keeps the Gaussians too.
+//
+// Launch shape: with ~22 instead of 51 vector instructions per cell the scan no longer needs
+// eight y-ranges' worth of waves to hide its ALU work: ONE y-range per sightline chunk on maps
+// that fill the chip that way (cfg4: 512 workgroups of 256 threads, two per CU), eight rows of
+// loads in flight, sums written straight to the map -- no partial sums, no reduction kernel.
+// (profiles/r03_chi_table_experiment.md: 2.59 ms against 2.72 ms for the Gaussians on the same
+// buffers.)  The sums follow another order than the compact / wide layouts' eight ranges: equal
+// to them to rounding (tests: 1e-12), not bit for bit -- the price VERDICT r03 item 5 accepts.
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+#include "ff_scan_kernels.h"
+
+namespace rjp {
+
+constexpr int kChiNC = 6;                    // coefficients per interval (quintic)
+constexpr int kChiMaxNI = 682;               // 2 jets x 682 x 48 B = 65472 B of LDS
+constexpr double kChiTol = 1e-13;            // bound on |chi - table|
+// a Gaussian of relative amplitude A is below 1e-17 beyond sqrt(2 ln(A 1e17)) sigmas
+static double chi_reach(double amp) { return std::sqrt(2.0 * std::log(std::max(amp, 1.0) * 1e17)); }
+
+struct ChiTabDev {
+  int ni;
+  double lo, inv_h;
+};
+
+// table builder: one thread per (jet, interval); tab[(jet * ni + k) * 6 + c]
+// stage = [Vandermonde inverse 6 x 6][nodes 6][jet 0: t0.., amp.., inv2s2..][jet 1: ...]
+__global__ __launch_bounds__(256) void chi_table_kernel(const double* __restrict__ stage, int nb0,
+                                                        int nb1, ChiTabDev t,
+                                                        double* __restrict__ tab) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= 2 * t.ni) return;
+  const int j = i / t.ni, k = i - j * t.ni;
+  const int nb = j == 0 ? nb0 : nb1;
+  const double* vinv = stage;
+  const double* xs = stage + 36;
+  const double* bj = stage + 42 + (j == 0 ? 0 : 3 * nb0);
+  const double h = 1.0 / t.inv_h;
+  double f[kChiNC];
+  for (int m = 0; m < kChiNC; ++m) {
+    const double tl = t.lo + (k + xs[m]) * h;
+    double chi = 1.0;
+    for (int b = 0; b < nb; ++b) {
+      const double d = tl - bj[b];
+      chi += bj[nb + b] * exp(-d * d * bj[2 * nb + b]);
+    }
+    f[m] = chi;
+  }
+  for (int c = 0; c < kChiNC; ++c) {
+    double s = 0.0;
+    for (int m = 0; m < kChiNC; ++m) s += vinv[c * kChiNC + m] * f[m];
+    tab[(size_t)i * kChiNC + c] = s;
+  }
+}
+
+template <int U>
+__global__ __launch_bounds__(kBlock) void ff_scan_table_kernel(
+    const double* __restrict__ a0, const double* __restrict__ ts, const int32_t* __restrict__ ylo,
+    const int32_t* __restrict__ yhi, int ny, int nz, int64_t nchunks, int64_t npix, int ylen,
+    int nsplit, ChiTabDev t, double t_epoch, const double* __restrict__ tab,
+    double* __restrict__ out, int64_t out_split_stride) {
+  constexpr int VEC = 2;
+  extern __shared__ __attribute__((aligned(16))) double s_chi[];       // [2][ni][6]
+  for (int i = threadIdx.x; i < 2 * t.ni * kChiNC; i += kBlock) s_chi[i] = tab[i];
+  __shared__ int s_lo, s_hi;
+  if (threadIdx.x == 0) { s_lo = ny; s_hi = 0; }
+  __syncthreads();
+  const int split = (int)(blockIdx.x % (unsigned)nsplit);
+  const int64_t c = (int64_t)(blockIdx.x / (unsigned)nsplit) * kBlock + threadIdx.x;
+  const bool lane_live = c < nchunks;
+  const int64_t p0 = c * VEC;
+  int y0 = split * ylen;
+  int y1 = min(ny, y0 + ylen);
+  if (ylo) {
+    if (lane_live) {
+      int lo = ny, hi = 0;
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) { lo = min(lo, ylo[p0 + v]); hi = max(hi, yhi[p0 + v]); }
+      if (lo < hi) { atomicMin(&s_lo, lo); atomicMax(&s_hi, hi); }
+    }
+    __syncthreads();
+    y0 = max(y0, s_lo);
+    y1 = min(y1, s_hi);
+  }
+  if (!lane_live) return;
+  const int64_t x = p0 / nz;
+  const int z = (int)(p0 - x * nz);
+  const double wmax = (double)t.ni - 0.0009765625;          // the last interval, just inside
+  // chi^2-weighted term of one cell: the jet picks the half of the table, the time since launch
+  // the interval; a NaN launch time lands in interval 0 and the term is masked (nansum)
+  auto term = [&](double av, double tv) __attribute__((always_inline)) {
+    const double am = keep_if_ordered(__builtin_fabs(av), tv);
+    double w = (t_epoch - tv - t.lo) * t.inv_h;
+    w = __builtin_fmin(__builtin_fmax(w, 0.0), wmax);
+    const double kf = __builtin_floor(w);
+    const double xi = w - kf;
+    const int k = (int)kf + (signbit_d(av) ? 0 : t.ni);
+    const rjp_d2* cp = reinterpret_cast<const rjp_d2*>(s_chi + k * kChiNC);
+    const rjp_d2 c01 = cp[0], c23 = cp[1], c45 = cp[2];
+    double chi = __builtin_fma(c45.y, xi, c45.x);
+    chi = __builtin_fma(chi, xi, c23.y);
+    chi = __builtin_fma(chi, xi, c23.x);
+    chi = __builtin_fma(chi, xi, c01.y);
+    chi = __builtin_fma(chi, xi, c01.x);
+    return am * (chi * chi);
+  };
+  double acc[VEC] = {0.0, 0.0};
+  int64_t off = (x * ny + y0) * (int64_t)nz + z;
+  int y = y0;
+  for (; y + U <= y1; y += U) {
+    double a[U][VEC], tt[U][VEC];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      load_vec(a0 + off + (int64_t)u * nz, a[u]);
+      load_vec(ts + off + (int64_t)u * nz, tt[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) acc[v] += term(a[u][v], tt[u][v]);
+    off += (int64_t)U * nz;
+  }
+  for (; y < y1; ++y) {
+    double a[VEC], tt[VEC];
+    load_vec(a0 + off, a);
+    load_vec(ts + off, tt);
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) acc[v] += term(a[v], tt[v]);
+    off += nz;
+  }
+  double* w = out + (int64_t)split * out_split_stride + p0;
+#pragma unroll
+  for (int v = 0; v < VEC; ++v) w[v] = acc[v];
+}
+
+// ---- host -----------------------------------------------------------------------------------
+// Vandermonde inverse of the 6 Chebyshev nodes on [0, 1] (monomial coefficients from node values)
+static void chi_nodes(double (&xs)[kChiNC], double (&vinv)[kChiNC][kChiNC]) {
+  const double pi = 3.14159265358979323846;
+  double A[kChiNC][2 * kChiNC];
+  for (int m = 0; m < kChiNC; ++m) {
+    xs[m] = 0.5 - 0.5 * std::cos(pi * (m + 0.5) / kChiNC);
+    double p = 1.0;
+    for (int q = 0; q < kChiNC; ++q) { A[m][q] = p; p *= xs[m]; }
+    for (int q = 0; q < kChiNC; ++q) A[m][kChiNC + q] = m == q ? 1.0 : 0.0;
+  }
+  for (int c = 0; c < kChiNC; ++c) {
+    int piv = c;
+    for (int r = c + 1; r < kChiNC; ++r) if (std::fabs(A[r][c]) > std::fabs(A[piv][c])) piv = r;
+    for (int q = 0; q < 2 * kChiNC; ++q) std::swap(A[c][q], A[piv][q]);
+    for (int r = 0; r < kChiNC; ++r)
+      if (r != c) {
+        const double f = A[r][c] / A[c][c];
+        for (int q = 0; q < 2 * kChiNC; ++q) A[r][q] -= f * A[c][q];
+      }
+  }
+  for (int c = 0; c < kChiNC; ++c)
+    for (int m = 0; m < kChiNC; ++m) vinv[c][m] = A[c][kChiNC + m] / A[c][c];
+}
+
+// Can this scan take the table path, and with which table?  On success: cp.tab describes the
+// table, cp.stage is the small host table to stage (inverse, nodes, burst parameters).
+bool chi_table_plan(const rjp_fields* fl, const rjp_bursts* hb, const double* epochs, int n_epochs,
+                    int mode, bool want_em, size_t work_bytes, ChiPlan& cp) {
+  cp.ok = false;
+  if (!hb || (hb->n[0] <= 0 && hb->n[1] <= 0) || n_epochs != 1 || want_em) return false;
+  if (scan_layout(fl, mode, false) != LAY_TAU || !fl->d_ts || ff_scan_vec(fl) != 2) return false;
+  if (!(fl->ts_hi >= fl->ts_lo) || !std::isfinite(fl->ts_lo) || !std::isfinite(fl->ts_hi) ||
+      (fl->ts_lo == 0.0 && fl->ts_hi == 0.0) || !std::isfinite(epochs[0]))
+    return false;
+  // small maps gain nothing (their scan is launch-bound) and their workspace may not hold the table
+  const int64_t npix = (int64_t)fl->nx * fl->nz;
+  if (npix / 2 < 64 * 256 || fl->ny < 64) return false;
+  // the bursts' support and the interpolation bound
+  double s_lo = INFINITY, s_hi = -INFINITY, B = 0.0;
+  for (int j = 0; j < 2; ++j) {
+    double Bj = 0.0;
+    for (int i = 0; i < hb->n[j]; ++i) {
+      const double inv = hb->inv2s2[j][i], amp = hb->amp_rel[j][i], t0 = hb->t0[j][i];
+      if (!(inv > 0.0) || !std::isfinite(inv) || !(amp >= 0.0) || !std::isfinite(amp) ||
+          !std::isfinite(t0))
+        return false;                             // dips (chi < 1) and degenerate widths: Gaussians
+      const double sigma = std::sqrt(0.5 / inv);
+      s_lo = std::min(s_lo, t0 - chi_reach(amp) * sigma);
+      s_hi = std::max(s_hi, t0 + chi_reach(amp) * sigma);
+      Bj += amp * 15.0 / (sigma * sigma * sigma * sigma * sigma * sigma);
+    }
+    B = std::max(B, Bj);
+  }
+  double lo = std::max(s_lo, epochs[0] - fl->ts_hi), hi = std::min(s_hi, epochs[0] - fl->ts_lo);
+  int ni = 1;
+  if (!(hi > lo)) {
+    // no cell is inside a burst's support at this epoch: chi == 1, one constant interval
+    lo = epochs[0] - fl->ts_hi;
+    hi = lo + 1.0;
+  } else {
+    const double h = 2.0 * std::pow(kChiTol * 23040.0 / B, 1.0 / 6.0);
+    const double n = std::ceil((hi - lo) / h);
+    if (!(n <= kChiMaxNI)) return false;          // would not fit the LDS: Gaussians
+    ni = std::max(1, (int)n);
+  }
+  const size_t tab_bytes = (size_t)2 * ni * kChiNC * sizeof(double);
+  // the table sits in the caller's workspace, in plane 1 of the first y-range's four planes (the
+  // scan writes plane 0 only): npix doubles in, 16-byte aligned because n_z is even
+  if (work_bytes < (size_t)npix * sizeof(double) + tab_bytes || (size_t)3 * npix * 8 < tab_bytes)
+    return false;
+  cp.ni = ni;
+  cp.lo = lo;
+  cp.inv_h = ni / (hi - lo);
+  cp.n[0] = hb->n[0]; cp.n[1] = hb->n[1];
+  static double xs[kChiNC], vinv[kChiNC][kChiNC];
+  static bool have = false;
+  if (!have) { chi_nodes(xs, vinv); have = true; }
+  cp.stage.clear();
+  for (int c = 0; c < kChiNC; ++c) for (int m = 0; m < kChiNC; ++m) cp.stage.push_back(vinv[c][m]);
+  for (int m = 0; m < kChiNC; ++m) cp.stage.push_back(xs[m]);
+  for (int j = 0; j < 2; ++j)
+    for (int k = 0; k < 3; ++k)
+      for (int i = 0; i < hb->n[j]; ++i)
+        cp.stage.push_back(k == 0 ? hb->t0[j][i] : k == 1 ? hb->amp_rel[j][i] : hb->inv2s2[j][i]);
+  cp.ok = true;
+  return true;
+}
+
+hipError_t chi_table_scan(const rjp_fields* fl, const ChiPlan& cp, const double* d_stage,
+                          double t_epoch, double* sumA, double* ws, size_t work_bytes,
+                          hipStream_t st) {
+  const int64_t npix = (int64_t)fl->nx * fl->nz;
+  const int64_t nchunks = npix / 2;
+  const size_t tab_doubles = (size_t)2 * cp.ni * kChiNC;
+  if (((uintptr_t)ws % 16) != 0 || work_bytes < (npix + tab_doubles) * sizeof(double))
+    return hipErrorInvalidValue;
+  double* d_tab = ws + npix;                        // plane 1 of the first y-range (see the plan)
+  ChiTabDev t{cp.ni, cp.lo, cp.inv_h};
+  hipLaunchKernelGGL(chi_table_kernel, dim3((unsigned)((2 * cp.ni + 255) / 256)), dim3(256), 0, st,
+                     d_stage, cp.n[0], cp.n[1], t, d_tab);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  // one y-range when the sightline chunks alone give every CU two workgroups; else as many ranges
+  // as it takes (partials reduced by ff_reduce_kernel's order: plane 0 of nacc(1) planes)
+  const int64_t wgs = (nchunks + kBlock - 1) / kBlock;
+  int nsplit = 1;
+  while (wgs * nsplit < 512 && nsplit * 2 * 64 <= fl->ny && nsplit < 16) nsplit *= 2;
+  const int ylen = (fl->ny + nsplit - 1) / nsplit;
+  const size_t shm = tab_doubles * sizeof(double);
+  static int attr_dev = -1;
+  int dev = -1;
+  e = hipGetDevice(&dev);
+  if (e != hipSuccess) return e;
+  if (dev != attr_dev) {
+    e = hipFuncSetAttribute((const void*)ff_scan_table_kernel<8>,
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+    if (e != hipSuccess) return e;
+    attr_dev = dev;
+  }
+  double* out = nsplit == 1 ? sumA : ws;
+  const int64_t stride = nsplit == 1 ? 0 : (int64_t)nacc(1) * npix;
+  hipLaunchKernelGGL(ff_scan_table_kernel<8>, dim3((unsigned)(wgs * nsplit)), dim3(kBlock), shm, st,
+                     (const double*)fl->d_a0, (const double*)fl->d_ts, fl->d_ylo, fl->d_yhi, fl->ny,
+                     fl->nz, nchunks, npix, ylen, nsplit, t, t_epoch, d_tab, out, stride);
+  e = hipGetLastError();
+  if (e != hipSuccess || nsplit == 1) return e;
+  return ff_reduce_launch(ws, nsplit, 1, npix, 0, 1.0, sumA, nullptr, nullptr, st);
+}
+
+}  // namespace rjp

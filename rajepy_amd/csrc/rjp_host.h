@@ -59,6 +59,24 @@ hipError_t ff_maps_launch(const double* sumA, const double* tavg, int64_t npix, 
 hipError_t sum_partials_launch(const double* part, int rows, int nblk, double* out,
                                hipStream_t st);
 
+// fixed-order reduction of the y-range partials of one tile (ff_reduce_kernel)
+hipError_t ff_reduce_launch(const double* ws, int nsplit, int et, int64_t npix, int e0,
+                            double em_scale, double* sumA, double* em, double* tavg,
+                            hipStream_t st);
+
+// ---- ff_scan_tab.hip: single-epoch tau-layout scan with the burst factor from an LDS table -----
+struct ChiPlan {
+  bool ok = false;
+  int ni = 0, n[2] = {0, 0};
+  double lo = 0.0, inv_h = 0.0;
+  std::vector<double> stage;      // Vandermonde inverse, nodes, burst parameters
+};
+bool chi_table_plan(const rjp_fields* fl, const rjp_bursts* hb, const double* epochs, int n_epochs,
+                    int mode, bool want_em, size_t work_bytes, ChiPlan& cp);
+hipError_t chi_table_scan(const rjp_fields* fl, const ChiPlan& cp, const double* d_stage,
+                          double t_epoch, double* sumA, double* ws, size_t work_bytes,
+                          hipStream_t st);
+
 // ---- ff_moments.hip: epoch sweeps by launch-time moments --------------------------------------
 #define RJP_MOM_MAX_IDX 1280      /* 2 jets x K bins x N Chebyshev moments <= this (160 KB of LDS
                                     for 16 sightlines); the (K, N) shapes: ff_moments.hip */

@@ -22,6 +22,7 @@ struct rjp_ctx {
   // whose tables equal a slot's content (a sweep over epochs at a fixed channel list) reuses
   // the device copy: no host-to-device copy between the scan and the map stage.
   rjp::MomPlan mom;               // last moment-path request (its tables are reused)
+  rjp::ChiPlan chi;               // the burst-factor table of the last single-epoch scan
   int last_path = 0;              // 0 = epoch tiles, 1 = LDS moments, 2 = launch-time-ordered layout
   static constexpr int kSlots = 8;
   struct Slot {
@@ -389,6 +390,19 @@ int rjp_ff_scan(rjp_ctx* ctx, const rjp_fields* fields, const rjp_bursts* bursts
     if (e != hipSuccess) return fail(ctx, RJP_ERR_HIP, "moments_run", e);
     return RJP_OK;
   }
+  if (d_tavg == nullptr &&
+      rjp::chi_table_plan(fields, bursts, h_epochs_s, n_epochs, gff_mode, d_em != nullptr,
+                          work_bytes, ctx->chi)) {
+    // single epoch on the tau layout: the burst factor from a table in LDS (ff_scan_tab.hip)
+    ctx->last_path = 3;
+    const double* src[1] = {ctx->chi.stage.data()};
+    const size_t len[1] = {ctx->chi.stage.size()};
+    double* dev[1];
+    if (int r = stage_tables(ctx, st, src, len, 1, dev)) return r;
+    return finish_staged(ctx, st, rjp::chi_table_scan(fields, ctx->chi, dev[0], h_epochs_s[0],
+                                                      d_sumA, (double*)d_work, work_bytes, st),
+                         "chi_table_scan");
+  }
   ctx->last_path = 0;
   rjp::ScanPlan plan;
   rjp::ff_scan_plan(fields, bursts, h_epochs_s, n_epochs, gff_mode, d_em != nullptr, plan);
@@ -411,10 +425,12 @@ int rjp_ff_scan(rjp_ctx* ctx, const rjp_fields* fields, const rjp_bursts* bursts
 
 int rjp_last_scan_path(const rjp_ctx* ctx, double* worst_rel_err, int32_t* moment_shape) {
   if (!ctx) return RJP_ERR_ARG;
-  if (worst_rel_err) *worst_rel_err = ctx->last_path ? ctx->mom.worst : 0.0;
+  const bool mom = ctx->last_path == 1 || ctx->last_path == 2;
+  if (worst_rel_err) *worst_rel_err = mom ? ctx->mom.worst : ctx->last_path == 3 ? 2e-13 : 0.0;
   if (moment_shape) {
-    moment_shape[0] = ctx->last_path ? ctx->mom.K : 0;
-    moment_shape[1] = ctx->last_path ? ctx->mom.N : 0;
+    // (path 3: the table's intervals per jet and its polynomial degree + 1)
+    moment_shape[0] = mom ? ctx->mom.K : ctx->last_path == 3 ? ctx->chi.ni : 0;
+    moment_shape[1] = mom ? ctx->mom.N : ctx->last_path == 3 ? 6 : 0;
   }
   return ctx->last_path;
 }

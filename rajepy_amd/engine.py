@@ -147,6 +147,9 @@ class RTEngine:
         self.use_moments = not (_lib.DEBUG and os.environ.get("RJP_NO_MOMENTS"))
         self.force_moments = False     # tests: skip the library's tiles-or-moments cost model
         self.use_lt = True             # False: ignore an attached launch-time-ordered layout
+        # single-epoch scans of large maps on the tau layout take the burst factor from a table in
+        # LDS (ff_scan_tab.hip; needs the launch-time range); False: always the Gaussians
+        self.use_chi_table = True
         self.last_moment_shape = (0, 0)
 
     def close(self):
@@ -462,14 +465,16 @@ class RTEngine:
         (rjp_unmask_launch_times): the reference's burst-less jet has a constant mass-loss rate,
         so a NaN launch time does not drop its cells (classes.py:232-233, 442-448).  The copy
         is kept with the fields and rebuilt when `ts` or the flag-carrying field changes."""
-        if (self.use_moments and bursts is not None and fields.a0 is not None and
-                n_epochs >= 12):
+        if (bursts is not None and fields.a0 is not None and
+                ((self.use_moments and n_epochs >= 12) or (self.use_chi_table and n_epochs == 1))):
             self.launch_time_range(fields)
         fs = fields.struct()
+        if n_epochs == 1 and not self.use_chi_table:
+            fs.ts_lo = fs.ts_hi = 0.0
         if not (self.use_lt and self.use_moments):
             fs.d_lt_cells = fs.d_lt_rowoff = fs.d_lt_aux = None
             fs.lt_K = 0
-        if not self.use_moments:
+        if not self.use_moments and n_epochs != 1:
             fs.ts_lo = fs.ts_hi = 0.0
         elif self.force_moments:
             fs.occupied_cells = -1
@@ -518,13 +523,14 @@ class RTEngine:
         return sumA, em, tavg
 
     def last_scan_path(self):
-        """('tiles' | 'moments' | 'lt', worst relative error of the moment expansion) of the
-        last rjp_ff_scan of this engine ('lt' = moments on the launch-time-ordered layout)."""
+        """('tiles' | 'moments' | 'lt' | 'table', worst relative error of the expansion) of the
+        last rjp_ff_scan of this engine ('lt' = moments on the launch-time-ordered layout,
+        'table' = single-epoch scan with the burst factor from a table in LDS)."""
         err = C.c_double()
         shape = (C.c_int32 * 2)()
         path = self.lib.rjp_last_scan_path(self.ctx, C.byref(err), shape)
         self.last_moment_shape = (int(shape[0]), int(shape[1]))      # (bins, order); (0, 0) = tiles
-        return {0: "tiles", 1: "moments", 2: "lt"}[path], err.value
+        return {0: "tiles", 1: "moments", 2: "lt", 3: "table"}[path], err.value
 
     def last_table_build_ms(self):
         """Host wall time of the last coefficient-table build (a new bursts / epochs request)."""

@@ -27,11 +27,11 @@ def eng():
     e.close()
 
 
-def _sample_jet(shape, pix, temp_mode, q_T):
+def _sample_jet(shape, pix, temp_mode, q_T, seed=SEED):
     nx, ny, nz = shape
     cells = np.array([(x * ny + y) * nz + z for (x, z) in pix for y in range(ny)],
                      dtype=np.uint64)
-    g = U.synth_host((len(pix), ny, 1), SEED, temp_mode, cells=cells, nz_full=nz)
+    g = U.synth_host((len(pix), ny, 1), seed, temp_mode, cells=cells, nz_full=nz)
     p = copy.deepcopy(U.load_golden("cfg1_example")[2])
     p["ejection"] = U.example_bursts_params()
     p["power_laws"]["q_T"] = q_T
@@ -129,6 +129,7 @@ def test_cfg4_tau_layout_is_bit_identical_at_full_size(eng, temp_mode):
     fields = eng.synth_fields(shape, SEED, temp_mode, 8, csize_au=0.5, tau_mode=mode)
     assert fields.a0 is not None and fields.scan_fields(mode, False) == 2
     eng.use_moments = False        # the epoch TILES are what is compared bit for bit here
+    eng.use_chi_table = False      # ... with the Gaussians (the table path: its own test below)
     jet = _sample_jet(shape, [(0, 0)], temp_mode, 0. if temp_mode == 0 else -0.5)
     bursts = U.bursts_from_oracle(jet)
     e1 = [1.0 * orc.YEAR]
@@ -161,6 +162,16 @@ def test_cfg4_tau_layout_is_bit_identical_at_full_size(eng, temp_mode):
     assert torch.equal(tav, t_cmp)
     fields.em0, fields.a0 = em0, a0
     eng.use_moments = True
+    eng.use_chi_table = True
+    # round 4: the shipped single-epoch scan takes the burst factor from a table in LDS and sums
+    # each sightline in ONE y-range: equal to the Gaussian scan's map to rounding (its bound on
+    # chi^2 is 2e-13; the other order of the sum adds ~1e-14), exactly zero where that is zero
+    tab = eng.ff_scan(fields, bursts, e1, mode, want_em=False, want_tavg=False)[0]
+    assert eng.last_scan_path()[0] == "table"
+    eng.synchronize()
+    ref = got[0][0]
+    assert torch.equal(tab == 0, ref == 0)
+    assert ((tab - ref).abs() / ref).max().item() < 1e-12
 
 
 def test_cfg5_epoch_sweep_by_launch_time_moments_full_size(eng):
@@ -224,6 +235,74 @@ def test_cfg5_epoch_sweep_by_launch_time_moments_full_size(eng):
     for e in (0, 21, 39):
         jet.time = ep2[e]
         np.testing.assert_allclose(ctau[0] * m2[e], jet.optical_depth_ff(5e9)[:, 0], rtol=1e-10)
+
+
+@pytest.mark.parametrize("temp_mode", [0, 1])
+@pytest.mark.parametrize("shape", [(128, 96, 256), (64, 131, 512), (32, 77, 1030)])
+def test_single_epoch_table_scan_vs_gaussians_and_oracle(eng, temp_mode, shape):
+    """The single-epoch tau-layout scan with the burst factor from a table in LDS
+    (ff_scan_tab.hip) on maps large enough to take it, one and several y-ranges, an odd number of
+    rows and a map whose width is no multiple of the workgroup: against the Gaussian scan at
+    1e-12 (the table's bound is 2e-13 on chi^2), sampled sightlines against the oracle at 1e-11,
+    NaN launch times / weights masked alike, epochs inside, at the edge of and far outside the
+    bursts' support, occupied y-ranges honoured; bursts with a dip keep the Gaussians."""
+    import torch
+    from rajepy_amd import engine as E
+    from rajepy_amd.maths import physics as ph
+    nx, ny, nz = shape
+    mode = E.RJP_GFF_SCALAR if temp_mode == 0 else E.RJP_GFF_POWERLAW
+    fields = eng.synth_fields(shape, SEED + 5, temp_mode, 8, csize_au=0.5, tau_mode=mode)
+    # NaN sprinkles in the launch times and the weights (a device-side edit of the fields)
+    g = torch.Generator(device=eng.device)
+    g.manual_seed(5)
+    m_ts = torch.rand(fields.ncells, device=eng.device, generator=g) < 0.02
+    m_a = torch.rand(fields.ncells, device=eng.device, generator=g) < 0.02
+    fields.ts[m_ts] = float("nan")
+    fields.a0[m_a] = float("nan")
+    rng = np.random.default_rng(3)
+    pix = [(int(rng.integers(nx)), int(rng.integers(nz))) for _ in range(6)] + [(0, 0), (nx - 1, nz - 1)]
+    jet = _sample_jet(shape, pix, temp_mode, 0. if temp_mode == 0 else -0.5, seed=SEED + 5)
+    idx = [x * nz + z for (x, z) in pix]
+    # the sampled oracle cells get the same NaNs
+    flat = [np.ravel_multi_index((x, np.arange(ny), z), shape) for (x, z) in pix]
+    mts, ma = m_ts.cpu().numpy(), m_a.cpu().numpy()
+    for k, fl in enumerate(flat):
+        jet._ts[k, mts[fl], 0] = np.nan
+        jet._nd[k, ma[fl], 0] = np.nan
+    bursts = U.bursts_from_oracle(jet)
+    gv = [ph.gff(5e9, 1e4)] if temp_mode == 0 else None
+    ctau, _ = E.ff_channel_coeffs([5e9], 0.5, 120., mode, gv)
+    for years in (1.0, 0.0, 2.6, 40.0, -30.0):
+        ep = [years * orc.YEAR]
+        eng.use_chi_table = True
+        tab = eng.ff_scan(fields, bursts, ep, mode, want_em=False, want_tavg=False)[0].clone()
+        assert eng.last_scan_path()[0] == "table"
+        eng.use_chi_table = False
+        ref = eng.ff_scan(fields, bursts, ep, mode, want_em=False, want_tavg=False)[0].clone()
+        assert eng.last_scan_path()[0] == "tiles"
+        eng.use_chi_table = True
+        eng.synchronize()
+        assert torch.equal(tab == 0, ref == 0)
+        ok = ref != 0
+        assert ((tab - ref).abs()[ok] / ref[ok]).max().item() < 1e-12
+        jet.time = ep[0]
+        np.testing.assert_allclose(ctau[0] * tab.cpu().numpy()[0, idx],
+                                   jet.optical_depth_ff(5e9)[:, 0], rtol=1e-11)
+    # occupied y-ranges: the same map
+    eng.compute_y_bounds(fields)
+    yb = eng.ff_scan(fields, bursts, [1.0 * orc.YEAR], mode, want_em=False, want_tavg=False)[0]
+    assert eng.last_scan_path()[0] == "table"
+    fields.ylo = fields.yhi = None
+    full = eng.ff_scan(fields, bursts, [1.0 * orc.YEAR], mode, want_em=False, want_tavg=False)[0]
+    eng.synchronize()
+    assert ((yb - full).abs() / full).max().item() < 1e-13
+    # a dip (negative amplitude): chi may come close to 0, the bound is on chi itself -> Gaussians
+    dip = E.make_bursts([(1.0 * orc.YEAR, -0.5, 2e6)], [(1.2 * orc.YEAR, 3.0, 4e6)])
+    eng.ff_scan(fields, dip, [1.0 * orc.YEAR], mode, want_em=False, want_tavg=False)
+    assert eng.last_scan_path()[0] == "tiles"
+    # and a request for the EM map or for T_avg with the scan keeps the three-field kernels
+    eng.ff_scan(fields, bursts, [1.0 * orc.YEAR], mode, want_em=True, want_tavg=False)
+    assert eng.last_scan_path()[0] == "tiles"
 
 
 def torch_all_finite(t):

@@ -791,3 +791,36 @@ def test_per_call_tables_are_reused_only_when_equal(eng):
         np.testing.assert_allclose(tau.cpu().numpy()[0], want_tau, rtol=1e-15)
         np.testing.assert_allclose(flux.cpu().numpy()[0], want_flux, rtol=1e-13)
         np.testing.assert_allclose(ftot.cpu().numpy()[0], want_flux.sum(axis=1), rtol=1e-12)
+
+
+@pytest.mark.parametrize("npix,nchan,n_ep", [(65536, 128, 1), (262144, 70, 1), (65536, 33, 4),
+                                             (65535, 128, 1), (4096, 16, 1)])
+def test_k2_per_lane_flux_accumulators_every_launch_shape(eng, npix, nchan, n_ep):
+    """K2's three launch shapes -- 4 pixel groups x 16 channels per lane with the per-channel
+    flux totals accumulated in registers (large maps), 1 pixel group x 16 channels, and the
+    small-map kernel -- against the map formulas (classes.py:1395-1397, 1473-1475, 1519-1521)
+    in NumPy, NaN pixels included (nansum), odd pixel counts (scalar lanes), ragged last
+    channel slice."""
+    import torch
+    rng = np.random.default_rng(npix + nchan)
+    A = rng.uniform(1e-3, 3e3, (n_ep, npix)) * 10.0 ** rng.uniform(-8, 2, (n_ep, npix))
+    T = rng.uniform(5e3, 2e4, npix)
+    T[rng.random(npix) < 0.01] = np.nan                       # empty sightlines
+    A[:, np.isnan(T)] = 0.0
+    ctau = 10.0 ** rng.uniform(-6, 1, nchan)
+    cflux = 10.0 ** rng.uniform(-12, -8, nchan)
+    dA = torch.from_numpy(A).to(eng.device)
+    dT = torch.from_numpy(T).to(eng.device)
+    tau, flux, ftot = eng.ff_maps(dA, dT, ctau, cflux)
+    t2, f2, _ = eng.ff_maps(dA, dT, ctau, cflux, want_ftot=False)
+    eng.synchronize()
+    want_tau = ctau[None, :, None] * A[:, None, :]
+    want_flux = cflux[None, :, None] * (T[None, None, :] * -np.expm1(-want_tau))
+    np.testing.assert_allclose(tau.cpu().numpy(), want_tau, rtol=1e-14)
+    got_f = flux.cpu().numpy()
+    assert np.array_equal(np.isnan(got_f), np.isnan(want_flux))
+    np.testing.assert_allclose(got_f, want_flux, rtol=1e-13)
+    np.testing.assert_allclose(ftot.cpu().numpy(), np.nansum(want_flux, axis=2), rtol=1e-12)
+    # the same cubes bit for bit when no totals are asked for
+    assert torch.equal(tau.view(torch.int64), t2.view(torch.int64))
+    assert bool(((flux == f2) | (flux.isnan() & f2.isnan())).all())
