@@ -5,21 +5,26 @@
 // issue at a power-limited clock (profiles/r03c_cfg4_k1_tau_sq.json).  chi is a function of ONE
 // variable, the time since launch: per call it is tabulated on the interval of times since launch
 // that can occur AND matter -- [t - ts_hi, t - ts_lo] cut with the bursts' support (chi == 1 to
-// 1e-17 outside) -- as piecewise quintics, 6 coefficients (48 bytes) per interval and jet, built
-// on the device by a tiny kernel in front of the scan (6 Chebyshev nodes per interval, Vandermonde
-// inverse from the host).  A cell costs one interval lookup: three 16-byte LDS reads at a random
-// address + 5 FMAs, whatever the number of bursts.  The number of intervals follows from the
-// interpolation bound  |chi - p| <= max|chi^(6)| (h/2)^6 / (6! 2^5),  max|G^(6)| = 15 A / sigma^6
+// 1e-17 outside) -- as piecewise polynomials of degree 7 in the interval's own coordinate
+// xi in [-1, 1), 8 coefficients per interval and jet at a stride of 80 bytes (an odd multiple of
+// 16: the four 16-byte reads of a lookup then spread over all LDS bank groups; at 64 bytes they
+// fall on a quarter of them), built on the device by a tiny kernel in front of the scan (8
+// Chebyshev nodes per interval, inverse Vandermonde matrix on [-1, 1] from the host).  A cell
+// costs one interval lookup: four 16-byte LDS reads at a random address + 7 FMAs, whatever the
+// number of bursts.  The number of intervals follows from the interpolation bound
+//   |chi - p| <= max|chi^(8)| (h/2)^8 / (8! 2^7),   max|G^(8)| = 105 A / sigma^8
 // for a Gaussian of amplitude A: h is chosen so that the bound is <= 1e-13 (chi >= 1: bursts with
 // a negative amplitude keep the Gaussians), i.e. <= 2e-13 relative on chi^2; a table that would
-// not fit 64 KB of LDS (682 intervals per jet) keeps the Gaussians too.
+// not fit 72 KB of LDS (460 intervals per jet; two workgroups per CU) keeps the Gaussians too.
+// (Quintics at 48 bytes, the round-3 experiment, need 4.2 x the intervals: the example's bursts
+// then fit for few epochs only.)
 //
 // Launch shape: with ~22 instead of 51 vector instructions per cell the scan no longer needs
 // eight y-ranges' worth of waves to hide its ALU work: ONE y-range per sightline chunk on maps
-// that fill the chip that way (cfg4: 512 workgroups of 256 threads, two per CU), eight rows of
+// that fill the chip that way (cfg4: 512 workgroups of 256 threads, two per CU), six rows of
 // loads in flight, sums written straight to the map -- no partial sums, no reduction kernel.
-// (profiles/r03_chi_table_experiment.md: 2.59 ms against 2.72 ms for the Gaussians on the same
-// buffers.)  The sums follow another order than the compact / wide layouts' eight ranges: equal
+// Same-buffer A/B at cfg4 (profiles/r04_k1_table_variants.log): 2.48 ms against 2.64-2.69 ms for
+// the Gaussians = 0.865 of the 8 TB/s peak on the 17.18 GB the scan needs.  The sums follow another order than the compact / wide layouts' eight ranges: equal
 // to them to rounding (tests: 1e-12), not bit for bit -- the price VERDICT r03 item 5 accepts.
 #include <algorithm>
 #include <cmath>
@@ -30,8 +35,15 @@
 
 namespace rjp {
 
-constexpr int kChiNC = 6;                    // coefficients per interval (quintic)
-constexpr int kChiMaxNI = 682;               // 2 jets x 682 x 48 B = 65472 B of LDS
+#ifndef RJP_TAB_U
+#define RJP_TAB_U 6              /* rows of loads in flight per lane (same-buffer A/B at cfg4, profiles/r04_k1_table_variants.log: 6: 2.483 ms, 8: 2.513, 12: 2.516, 16: 2.529) */
+#endif
+#ifndef RJP_TAB_WGS
+#define RJP_TAB_WGS 512          /* y-ranges are added until this many workgroups exist (1024 / 2048 at cfg4: 2.518 / 2.524 ms) */
+#endif
+constexpr int kChiNC = 8;                    // coefficients per interval (degree 7)
+constexpr int kChiStride = 10;               // doubles between intervals (80 B)
+constexpr int kChiMaxNI = 460;               // 2 jets x 460 x 80 B = 73600 B of LDS
 constexpr double kChiTol = 1e-13;            // bound on |chi - table|
 // a Gaussian of relative amplitude A is below 1e-17 beyond sqrt(2 ln(A 1e17)) sigmas
 static double chi_reach(double amp) { return std::sqrt(2.0 * std::log(std::max(amp, 1.0) * 1e17)); }
@@ -39,10 +51,12 @@ static double chi_reach(double amp) { return std::sqrt(2.0 * std::log(std::max(a
 struct ChiTabDev {
   int ni;
   double lo, inv_h;
+  double wmax;     // the largest double below ni: a cell launched exactly at ts_lo (w == ni)
+                   // belongs to the last interval, xi -> 1
 };
 
-// table builder: one thread per (jet, interval); tab[(jet * ni + k) * 6 + c]
-// stage = [Vandermonde inverse 6 x 6][nodes 6][jet 0: t0.., amp.., inv2s2..][jet 1: ...]
+// table builder: one thread per (jet, interval); tab[(jet * ni + k) * kChiStride + c]
+// stage = [Vandermonde inverse 8 x 8][nodes 8][jet 0: t0.., amp.., inv2s2..][jet 1: ...]
 __global__ __launch_bounds__(256) void chi_table_kernel(const double* __restrict__ stage, int nb0,
                                                         int nb1, ChiTabDev t,
                                                         double* __restrict__ tab) {
@@ -51,12 +65,12 @@ __global__ __launch_bounds__(256) void chi_table_kernel(const double* __restrict
   const int j = i / t.ni, k = i - j * t.ni;
   const int nb = j == 0 ? nb0 : nb1;
   const double* vinv = stage;
-  const double* xs = stage + 36;
-  const double* bj = stage + 42 + (j == 0 ? 0 : 3 * nb0);
+  const double* xs = stage + kChiNC * kChiNC;
+  const double* bj = stage + kChiNC * kChiNC + kChiNC + (j == 0 ? 0 : 3 * nb0);
   const double h = 1.0 / t.inv_h;
   double f[kChiNC];
   for (int m = 0; m < kChiNC; ++m) {
-    const double tl = t.lo + (k + xs[m]) * h;
+    const double tl = t.lo + (k + 0.5 * (xs[m] + 1.0)) * h;
     double chi = 1.0;
     for (int b = 0; b < nb; ++b) {
       const double d = tl - bj[b];
@@ -67,8 +81,9 @@ __global__ __launch_bounds__(256) void chi_table_kernel(const double* __restrict
   for (int c = 0; c < kChiNC; ++c) {
     double s = 0.0;
     for (int m = 0; m < kChiNC; ++m) s += vinv[c * kChiNC + m] * f[m];
-    tab[(size_t)i * kChiNC + c] = s;
+    tab[(size_t)i * kChiStride + c] = s;
   }
+  tab[(size_t)i * kChiStride + 8] = tab[(size_t)i * kChiStride + 9] = 0.0;
 }
 
 template <int U>
@@ -78,8 +93,8 @@ __global__ __launch_bounds__(kBlock) void ff_scan_table_kernel(
     int nsplit, ChiTabDev t, double t_epoch, const double* __restrict__ tab,
     double* __restrict__ out, int64_t out_split_stride) {
   constexpr int VEC = 2;
-  extern __shared__ __attribute__((aligned(16))) double s_chi[];       // [2][ni][6]
-  for (int i = threadIdx.x; i < 2 * t.ni * kChiNC; i += kBlock) s_chi[i] = tab[i];
+  extern __shared__ __attribute__((aligned(16))) double s_chi[];       // [2][ni][10]
+  for (int i = threadIdx.x; i < 2 * t.ni * kChiStride; i += kBlock) s_chi[i] = tab[i];
   __shared__ int s_lo, s_hi;
   if (threadIdx.x == 0) { s_lo = ny; s_hi = 0; }
   __syncthreads();
@@ -103,7 +118,7 @@ __global__ __launch_bounds__(kBlock) void ff_scan_table_kernel(
   if (!lane_live) return;
   const int64_t x = p0 / nz;
   const int z = (int)(p0 - x * nz);
-  const double wmax = (double)t.ni - 0.0009765625;          // the last interval, just inside
+  const double wmax = t.wmax;
   // chi^2-weighted term of one cell: the jet picks the half of the table, the time since launch
   // the interval; a NaN launch time lands in interval 0 and the term is masked (nansum)
   auto term = [&](double av, double tv) __attribute__((always_inline)) {
@@ -111,11 +126,13 @@ __global__ __launch_bounds__(kBlock) void ff_scan_table_kernel(
     double w = (t_epoch - tv - t.lo) * t.inv_h;
     w = __builtin_fmin(__builtin_fmax(w, 0.0), wmax);
     const double kf = __builtin_floor(w);
-    const double xi = w - kf;
+    const double xi = __builtin_fma(2.0, w - kf, -1.0);
     const int k = (int)kf + (signbit_d(av) ? 0 : t.ni);
-    const rjp_d2* cp = reinterpret_cast<const rjp_d2*>(s_chi + k * kChiNC);
-    const rjp_d2 c01 = cp[0], c23 = cp[1], c45 = cp[2];
-    double chi = __builtin_fma(c45.y, xi, c45.x);
+    const rjp_d2* cp = reinterpret_cast<const rjp_d2*>(s_chi + k * kChiStride);
+    const rjp_d2 c01 = cp[0], c23 = cp[1], c45 = cp[2], c67 = cp[3];
+    double chi = __builtin_fma(c67.y, xi, c67.x);
+    chi = __builtin_fma(chi, xi, c45.y);
+    chi = __builtin_fma(chi, xi, c45.x);
     chi = __builtin_fma(chi, xi, c23.y);
     chi = __builtin_fma(chi, xi, c23.x);
     chi = __builtin_fma(chi, xi, c01.y);
@@ -152,12 +169,13 @@ __global__ __launch_bounds__(kBlock) void ff_scan_table_kernel(
 }
 
 // ---- host -----------------------------------------------------------------------------------
-// Vandermonde inverse of the 6 Chebyshev nodes on [0, 1] (monomial coefficients from node values)
+// Vandermonde inverse of the 8 Chebyshev nodes on [-1, 1] (monomial coefficients in the interval's
+// own coordinate from node values; on [-1, 1] the matrix is well conditioned)
 static void chi_nodes(double (&xs)[kChiNC], double (&vinv)[kChiNC][kChiNC]) {
   const double pi = 3.14159265358979323846;
   double A[kChiNC][2 * kChiNC];
   for (int m = 0; m < kChiNC; ++m) {
-    xs[m] = 0.5 - 0.5 * std::cos(pi * (m + 0.5) / kChiNC);
+    xs[m] = -std::cos(pi * (m + 0.5) / kChiNC);
     double p = 1.0;
     for (int q = 0; q < kChiNC; ++q) { A[m][q] = p; p *= xs[m]; }
     for (int q = 0; q < kChiNC; ++q) A[m][kChiNC + q] = m == q ? 1.0 : 0.0;
@@ -201,7 +219,8 @@ bool chi_table_plan(const rjp_fields* fl, const rjp_bursts* hb, const double* ep
       const double sigma = std::sqrt(0.5 / inv);
       s_lo = std::min(s_lo, t0 - chi_reach(amp) * sigma);
       s_hi = std::max(s_hi, t0 + chi_reach(amp) * sigma);
-      Bj += amp * 15.0 / (sigma * sigma * sigma * sigma * sigma * sigma);
+      const double s2 = sigma * sigma;
+      Bj += amp * 105.0 / (s2 * s2 * s2 * s2);
     }
     B = std::max(B, Bj);
   }
@@ -212,12 +231,12 @@ bool chi_table_plan(const rjp_fields* fl, const rjp_bursts* hb, const double* ep
     lo = epochs[0] - fl->ts_hi;
     hi = lo + 1.0;
   } else {
-    const double h = 2.0 * std::pow(kChiTol * 23040.0 / B, 1.0 / 6.0);
+    const double h = 2.0 * std::pow(kChiTol * 5160960.0 / B, 1.0 / 8.0);      // 8! 2^7
     const double n = std::ceil((hi - lo) / h);
     if (!(n <= kChiMaxNI)) return false;          // would not fit the LDS: Gaussians
     ni = std::max(1, (int)n);
   }
-  const size_t tab_bytes = (size_t)2 * ni * kChiNC * sizeof(double);
+  const size_t tab_bytes = (size_t)2 * ni * kChiStride * sizeof(double);
   // the table sits in the caller's workspace, in plane 1 of the first y-range's four planes (the
   // scan writes plane 0 only): npix doubles in, 16-byte aligned because n_z is even
   if (work_bytes < (size_t)npix * sizeof(double) + tab_bytes || (size_t)3 * npix * 8 < tab_bytes)
@@ -245,11 +264,11 @@ hipError_t chi_table_scan(const rjp_fields* fl, const ChiPlan& cp, const double*
                           hipStream_t st) {
   const int64_t npix = (int64_t)fl->nx * fl->nz;
   const int64_t nchunks = npix / 2;
-  const size_t tab_doubles = (size_t)2 * cp.ni * kChiNC;
+  const size_t tab_doubles = (size_t)2 * cp.ni * kChiStride;
   if (((uintptr_t)ws % 16) != 0 || work_bytes < (npix + tab_doubles) * sizeof(double))
     return hipErrorInvalidValue;
   double* d_tab = ws + npix;                        // plane 1 of the first y-range (see the plan)
-  ChiTabDev t{cp.ni, cp.lo, cp.inv_h};
+  ChiTabDev t{cp.ni, cp.lo, cp.inv_h, std::nextafter((double)cp.ni, 0.0)};
   hipLaunchKernelGGL(chi_table_kernel, dim3((unsigned)((2 * cp.ni + 255) / 256)), dim3(256), 0, st,
                      d_stage, cp.n[0], cp.n[1], t, d_tab);
   hipError_t e = hipGetLastError();
@@ -258,7 +277,7 @@ hipError_t chi_table_scan(const rjp_fields* fl, const ChiPlan& cp, const double*
   // as it takes (partials reduced by ff_reduce_kernel's order: plane 0 of nacc(1) planes)
   const int64_t wgs = (nchunks + kBlock - 1) / kBlock;
   int nsplit = 1;
-  while (wgs * nsplit < 512 && nsplit * 2 * 64 <= fl->ny && nsplit < 16) nsplit *= 2;
+  while (wgs * nsplit < RJP_TAB_WGS && nsplit * 2 * 64 <= fl->ny && nsplit < 16) nsplit *= 2;
   const int ylen = (fl->ny + nsplit - 1) / nsplit;
   const size_t shm = tab_doubles * sizeof(double);
   static int attr_dev = -1;
@@ -266,14 +285,15 @@ hipError_t chi_table_scan(const rjp_fields* fl, const ChiPlan& cp, const double*
   e = hipGetDevice(&dev);
   if (e != hipSuccess) return e;
   if (dev != attr_dev) {
-    e = hipFuncSetAttribute((const void*)ff_scan_table_kernel<8>,
-                            hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+    e = hipFuncSetAttribute((const void*)ff_scan_table_kernel<RJP_TAB_U>,
+                            hipFuncAttributeMaxDynamicSharedMemorySize,
+                            2 * kChiMaxNI * kChiStride * (int)sizeof(double));
     if (e != hipSuccess) return e;
     attr_dev = dev;
   }
   double* out = nsplit == 1 ? sumA : ws;
   const int64_t stride = nsplit == 1 ? 0 : (int64_t)nacc(1) * npix;
-  hipLaunchKernelGGL(ff_scan_table_kernel<8>, dim3((unsigned)(wgs * nsplit)), dim3(kBlock), shm, st,
+  hipLaunchKernelGGL(ff_scan_table_kernel<RJP_TAB_U>, dim3((unsigned)(wgs * nsplit)), dim3(kBlock), shm, st,
                      (const double*)fl->d_a0, (const double*)fl->d_ts, fl->d_ylo, fl->d_yhi, fl->ny,
                      fl->nz, nchunks, npix, ylen, nsplit, t, t_epoch, d_tab, out, stride);
   e = hipGetLastError();

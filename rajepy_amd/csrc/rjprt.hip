@@ -430,7 +430,7 @@ int rjp_last_scan_path(const rjp_ctx* ctx, double* worst_rel_err, int32_t* momen
   if (moment_shape) {
     // (path 3: the table's intervals per jet and its polynomial degree + 1)
     moment_shape[0] = mom ? ctx->mom.K : ctx->last_path == 3 ? ctx->chi.ni : 0;
-    moment_shape[1] = mom ? ctx->mom.N : ctx->last_path == 3 ? 6 : 0;
+    moment_shape[1] = mom ? ctx->mom.N : ctx->last_path == 3 ? 8 : 0;
   }
   return ctx->last_path;
 }

@@ -171,7 +171,7 @@ def test_cfg4_tau_layout_is_bit_identical_at_full_size(eng, temp_mode):
     eng.synchronize()
     ref = got[0][0]
     assert torch.equal(tab == 0, ref == 0)
-    assert ((tab - ref).abs() / ref).max().item() < 1e-12
+    assert ((tab - ref).abs() / ref).max().item() < 3e-12
 
 
 def test_cfg5_epoch_sweep_by_launch_time_moments_full_size(eng):
@@ -243,7 +243,7 @@ def test_single_epoch_table_scan_vs_gaussians_and_oracle(eng, temp_mode, shape):
     """The single-epoch tau-layout scan with the burst factor from a table in LDS
     (ff_scan_tab.hip) on maps large enough to take it, one and several y-ranges, an odd number of
     rows and a map whose width is no multiple of the workgroup: against the Gaussian scan at
-    1e-12 (the table's bound is 2e-13 on chi^2), sampled sightlines against the oracle at 1e-11,
+    3e-12 (the table's bound is 2e-13 on chi^2), sampled sightlines against the oracle at 1e-11,
     NaN launch times / weights masked alike, epochs inside, at the edge of and far outside the
     bursts' support, occupied y-ranges honoured; bursts with a dip keep the Gaussians."""
     import torch
@@ -284,7 +284,9 @@ def test_single_epoch_table_scan_vs_gaussians_and_oracle(eng, temp_mode, shape):
         eng.synchronize()
         assert torch.equal(tab == 0, ref == 0)
         ok = ref != 0
-        assert ((tab - ref).abs()[ok] / ref[ok]).max().item() < 1e-12
+        # (the Gaussians' own 2^f polynomial is good to 1.1e-12 on chi, rjp_device.h exp2_gauss:
+        # the two scans may differ by 2.2e-12 + the table's 2e-13)
+        assert ((tab - ref).abs()[ok] / ref[ok]).max().item() < 3e-12
         jet.time = ep[0]
         np.testing.assert_allclose(ctau[0] * tab.cpu().numpy()[0, idx],
                                    jet.optical_depth_ff(5e9)[:, 0], rtol=1e-11)
