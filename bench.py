@@ -916,6 +916,13 @@ def main(argv=None):
         dma = E_loc >= 16 and long_tiles and fields.shape[2] % 2 == 0
         kname = "ff_scan_tile_kernel" if dma else "ff_scan_kernel"
         scan_path, mom_err = eng.last_scan_path()
+        if scan_path == "table":
+            # single epoch, tau layout: burst factor from a table in LDS, ONE y-range, the sums
+            # written straight to the map (ff_scan_tab.hip)
+            kname = "ff_scan_table_kernel"
+            roof_extra_table = {"intervals_per_jet": eng.last_moment_shape[0],
+                                "degree": eng.last_moment_shape[1] - 1,
+                                "bound_on_chi2_rel_err": mom_err}
         if scan_path in ("moments", "lt"):
             # the sweep went through the launch-time moments (ff_moments.hip / ff_lt.hip): ONE pass
             # over the grid for all epochs of the launch (+ a contraction over the moment maps
@@ -931,6 +938,8 @@ def main(argv=None):
                                "what": "T_avg = nanmean_y(T > 0) is independent of frequency "
                                        "and epoch: one rjp_tavg pass per MODEL, not part of "
                                        "a step"}}
+        if scan_path == "table":
+            roof_extra["chi_table"] = roof_extra_table
         if scan_path == "lt":
             roof_extra["lt"] = dict(wl.lt_info or {}, **{
                 "what": "launch-time-ordered layout (per-model state): every group of 64 "

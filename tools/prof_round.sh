@@ -17,7 +17,7 @@ for variant in tau2 tau3 wide5; do
   case $variant in
     # (the kernel of the timed step, by its full template arguments: <T, VEC, ET, MODE, BURSTS,
     # UNIF, LAY, EM> -- the run also launches the other layouts' kernels for its side figures)
-    tau2) flags=(); kern="ff_scan_kernel<double, 2, 1, 0, true, false, 2, false>" ;;
+    tau2) flags=(); kern="ff_scan_table_kernel" ;;
     tau3) flags=(--em); kern="ff_scan_kernel<double, 2, 1, 0, true, false, 2, true>" ;;
     wide5) flags=(--layout wide --em); kern="ff_scan_kernel<double, 2, 1, 0, true, false, 0, true>" ;;
   esac
