@@ -38,6 +38,9 @@ namespace rjp {
 #ifndef RJP_TAB_U
 #define RJP_TAB_U 6              /* rows of loads in flight per lane (same-buffer A/B at cfg4, profiles/r04_k1_table_variants.log: 6: 2.483 ms, 8: 2.513, 12: 2.516, 16: 2.529) */
 #endif
+#ifndef RJP_TAB_U_EM
+#define RJP_TAB_U_EM 4           /* ... with the EM map (three streams) */
+#endif
 #ifndef RJP_TAB_WGS
 #define RJP_TAB_WGS 512          /* y-ranges are added until this many workgroups exist (1024 / 2048 at cfg4: 2.518 / 2.524 ms) */
 #endif
@@ -86,12 +89,15 @@ __global__ __launch_bounds__(256) void chi_table_kernel(const double* __restrict
   tab[(size_t)i * kChiStride + 8] = tab[(size_t)i * kChiStride + 9] = 0.0;
 }
 
-template <int U>
+// EM: the emission measure of the epoch as well (a third stream, em0: classes.py:1116-1118 with
+// number_density = _nd chi); `em_scale` is applied when the sums go straight to the map
+template <int U, bool EM>
 __global__ __launch_bounds__(kBlock) void ff_scan_table_kernel(
-    const double* __restrict__ a0, const double* __restrict__ ts, const int32_t* __restrict__ ylo,
-    const int32_t* __restrict__ yhi, int ny, int nz, int64_t nchunks, int64_t npix, int ylen,
-    int nsplit, ChiTabDev t, double t_epoch, const double* __restrict__ tab,
-    double* __restrict__ out, int64_t out_split_stride) {
+    const double* __restrict__ a0, const double* __restrict__ em0, const double* __restrict__ ts,
+    const int32_t* __restrict__ ylo, const int32_t* __restrict__ yhi, int ny, int nz,
+    int64_t nchunks, int64_t npix, int ylen, int nsplit, ChiTabDev t, double t_epoch,
+    const double* __restrict__ tab, double* __restrict__ out, int64_t out_split_stride,
+    double* __restrict__ out_em, double em_scale) {
   constexpr int VEC = 2;
   extern __shared__ __attribute__((aligned(16))) double s_chi[];       // [2][ni][10]
   for (int i = threadIdx.x; i < 2 * t.ni * kChiStride; i += kBlock) s_chi[i] = tab[i];
@@ -121,8 +127,7 @@ __global__ __launch_bounds__(kBlock) void ff_scan_table_kernel(
   const double wmax = t.wmax;
   // chi^2-weighted term of one cell: the jet picks the half of the table, the time since launch
   // the interval; a NaN launch time lands in interval 0 and the term is masked (nansum)
-  auto term = [&](double av, double tv) __attribute__((always_inline)) {
-    const double am = keep_if_ordered(__builtin_fabs(av), tv);
+  auto chi2 = [&](double av, double tv) __attribute__((always_inline)) {
     double w = (t_epoch - tv - t.lo) * t.inv_h;
     w = __builtin_fmin(__builtin_fmax(w, 0.0), wmax);
     const double kf = __builtin_floor(w);
@@ -137,35 +142,51 @@ __global__ __launch_bounds__(kBlock) void ff_scan_table_kernel(
     chi = __builtin_fma(chi, xi, c23.x);
     chi = __builtin_fma(chi, xi, c01.y);
     chi = __builtin_fma(chi, xi, c01.x);
-    return am * (chi * chi);
+    return chi * chi;
   };
-  double acc[VEC] = {0.0, 0.0};
+  double acc[VEC] = {0.0, 0.0}, accE[VEC] = {0.0, 0.0};
   int64_t off = (x * ny + y0) * (int64_t)nz + z;
   int y = y0;
   for (; y + U <= y1; y += U) {
-    double a[U][VEC], tt[U][VEC];
+    double a[U][VEC], g[U][VEC], tt[U][VEC];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       load_vec(a0 + off + (int64_t)u * nz, a[u]);
+      if (EM) load_vec(em0 + off + (int64_t)u * nz, g[u]);
       load_vec(ts + off + (int64_t)u * nz, tt[u]);
     }
 #pragma unroll
     for (int u = 0; u < U; ++u)
 #pragma unroll
-      for (int v = 0; v < VEC; ++v) acc[v] += term(a[u][v], tt[u][v]);
+      for (int v = 0; v < VEC; ++v) {
+        const double c2 = chi2(a[u][v], tt[u][v]);
+        acc[v] = __builtin_fma(keep_if_ordered(__builtin_fabs(a[u][v]), tt[u][v]), c2, acc[v]);
+        if (EM) accE[v] = __builtin_fma(keep_if_ordered(__builtin_fabs(g[u][v]), tt[u][v]), c2, accE[v]);
+      }
     off += (int64_t)U * nz;
   }
   for (; y < y1; ++y) {
-    double a[VEC], tt[VEC];
+    double a[VEC], g[VEC], tt[VEC];
     load_vec(a0 + off, a);
+    if (EM) load_vec(em0 + off, g);
     load_vec(ts + off, tt);
 #pragma unroll
-    for (int v = 0; v < VEC; ++v) acc[v] += term(a[v], tt[v]);
+    for (int v = 0; v < VEC; ++v) {
+      const double c2 = chi2(a[v], tt[v]);
+      acc[v] = __builtin_fma(keep_if_ordered(__builtin_fabs(a[v]), tt[v]), c2, acc[v]);
+      if (EM) accE[v] = __builtin_fma(keep_if_ordered(__builtin_fabs(g[v]), tt[v]), c2, accE[v]);
+    }
     off += nz;
   }
   double* w = out + (int64_t)split * out_split_stride + p0;
 #pragma unroll
   for (int v = 0; v < VEC; ++v) w[v] = acc[v];
+  if (EM) {
+    // straight to the map (scaled) with one y-range, else plane 1 of this range's partial sums
+    double* we = nsplit == 1 ? out_em + p0 : out + (int64_t)split * out_split_stride + npix + p0;
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) we[v] = nsplit == 1 ? accE[v] * em_scale : accE[v];
+  }
 }
 
 // ---- host -----------------------------------------------------------------------------------
@@ -199,8 +220,8 @@ static void chi_nodes(double (&xs)[kChiNC], double (&vinv)[kChiNC][kChiNC]) {
 bool chi_table_plan(const rjp_fields* fl, const rjp_bursts* hb, const double* epochs, int n_epochs,
                     int mode, bool want_em, size_t work_bytes, ChiPlan& cp) {
   cp.ok = false;
-  if (!hb || (hb->n[0] <= 0 && hb->n[1] <= 0) || n_epochs != 1 || want_em) return false;
-  if (scan_layout(fl, mode, false) != LAY_TAU || !fl->d_ts || ff_scan_vec(fl) != 2) return false;
+  if (!hb || (hb->n[0] <= 0 && hb->n[1] <= 0) || n_epochs != 1) return false;
+  if (scan_layout(fl, mode, want_em) != LAY_TAU || !fl->d_ts || ff_scan_vec(fl) != 2) return false;
   if (!(fl->ts_hi >= fl->ts_lo) || !std::isfinite(fl->ts_lo) || !std::isfinite(fl->ts_hi) ||
       (fl->ts_lo == 0.0 && fl->ts_hi == 0.0) || !std::isfinite(epochs[0]))
     return false;
@@ -237,9 +258,10 @@ bool chi_table_plan(const rjp_fields* fl, const rjp_bursts* hb, const double* ep
     ni = std::max(1, (int)n);
   }
   const size_t tab_bytes = (size_t)2 * ni * kChiStride * sizeof(double);
-  // the table sits in the caller's workspace, in plane 1 of the first y-range's four planes (the
-  // scan writes plane 0 only): npix doubles in, 16-byte aligned because n_z is even
-  if (work_bytes < (size_t)npix * sizeof(double) + tab_bytes || (size_t)3 * npix * 8 < tab_bytes)
+  // the table sits in the caller's workspace, in planes 2-3 of the first y-range's four planes
+  // (the temperature sums of the other layouts: the scan writes planes 0 and 1 only): 2 npix
+  // doubles in, 16-byte aligned because n_z is even
+  if (work_bytes < (size_t)2 * npix * sizeof(double) + tab_bytes || (size_t)2 * npix * 8 < tab_bytes)
     return false;
   cp.ni = ni;
   cp.lo = lo;
@@ -260,14 +282,14 @@ bool chi_table_plan(const rjp_fields* fl, const rjp_bursts* hb, const double* ep
 }
 
 hipError_t chi_table_scan(const rjp_fields* fl, const ChiPlan& cp, const double* d_stage,
-                          double t_epoch, double* sumA, double* ws, size_t work_bytes,
+                          double t_epoch, double* sumA, double* em, double* ws, size_t work_bytes,
                           hipStream_t st) {
   const int64_t npix = (int64_t)fl->nx * fl->nz;
   const int64_t nchunks = npix / 2;
   const size_t tab_doubles = (size_t)2 * cp.ni * kChiStride;
-  if (((uintptr_t)ws % 16) != 0 || work_bytes < (npix + tab_doubles) * sizeof(double))
+  if (((uintptr_t)ws % 16) != 0 || work_bytes < (2 * npix + tab_doubles) * sizeof(double))
     return hipErrorInvalidValue;
-  double* d_tab = ws + npix;                        // plane 1 of the first y-range (see the plan)
+  double* d_tab = ws + 2 * npix;                    // plane 2 of the first y-range (see the plan)
   ChiTabDev t{cp.ni, cp.lo, cp.inv_h, std::nextafter((double)cp.ni, 0.0)};
   hipLaunchKernelGGL(chi_table_kernel, dim3((unsigned)((2 * cp.ni + 255) / 256)), dim3(256), 0, st,
                      d_stage, cp.n[0], cp.n[1], t, d_tab);
@@ -280,25 +302,38 @@ hipError_t chi_table_scan(const rjp_fields* fl, const ChiPlan& cp, const double*
   while (wgs * nsplit < RJP_TAB_WGS && nsplit * 2 * 64 <= fl->ny && nsplit < 16) nsplit *= 2;
   const int ylen = (fl->ny + nsplit - 1) / nsplit;
   const size_t shm = tab_doubles * sizeof(double);
+  // em = sum (n x)^2 * csize*au/pc * pf  (classes.py:1116-1118)
+  const double em_scale = fl->csize_au * 149597870700.0 / 3.085677581491367e+16;
   static int attr_dev = -1;
   int dev = -1;
   e = hipGetDevice(&dev);
   if (e != hipSuccess) return e;
+  constexpr int kMaxShm = 2 * kChiMaxNI * kChiStride * (int)sizeof(double);
   if (dev != attr_dev) {
-    e = hipFuncSetAttribute((const void*)ff_scan_table_kernel<RJP_TAB_U>,
-                            hipFuncAttributeMaxDynamicSharedMemorySize,
-                            2 * kChiMaxNI * kChiStride * (int)sizeof(double));
+    e = hipFuncSetAttribute((const void*)ff_scan_table_kernel<RJP_TAB_U, false>,
+                            hipFuncAttributeMaxDynamicSharedMemorySize, kMaxShm);
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute((const void*)ff_scan_table_kernel<RJP_TAB_U_EM, true>,
+                            hipFuncAttributeMaxDynamicSharedMemorySize, kMaxShm);
     if (e != hipSuccess) return e;
     attr_dev = dev;
   }
   double* out = nsplit == 1 ? sumA : ws;
   const int64_t stride = nsplit == 1 ? 0 : (int64_t)nacc(1) * npix;
-  hipLaunchKernelGGL(ff_scan_table_kernel<RJP_TAB_U>, dim3((unsigned)(wgs * nsplit)), dim3(kBlock), shm, st,
-                     (const double*)fl->d_a0, (const double*)fl->d_ts, fl->d_ylo, fl->d_yhi, fl->ny,
-                     fl->nz, nchunks, npix, ylen, nsplit, t, t_epoch, d_tab, out, stride);
+  const dim3 grid((unsigned)(wgs * nsplit));
+  if (em)
+    hipLaunchKernelGGL((ff_scan_table_kernel<RJP_TAB_U_EM, true>), grid, dim3(kBlock), shm, st,
+                       (const double*)fl->d_a0, (const double*)fl->d_em0, (const double*)fl->d_ts,
+                       fl->d_ylo, fl->d_yhi, fl->ny, fl->nz, nchunks, npix, ylen, nsplit, t,
+                       t_epoch, d_tab, out, stride, em, em_scale);
+  else
+    hipLaunchKernelGGL((ff_scan_table_kernel<RJP_TAB_U, false>), grid, dim3(kBlock), shm, st,
+                       (const double*)fl->d_a0, (const double*)nullptr, (const double*)fl->d_ts,
+                       fl->d_ylo, fl->d_yhi, fl->ny, fl->nz, nchunks, npix, ylen, nsplit, t,
+                       t_epoch, d_tab, out, stride, (double*)nullptr, em_scale);
   e = hipGetLastError();
   if (e != hipSuccess || nsplit == 1) return e;
-  return ff_reduce_launch(ws, nsplit, 1, npix, 0, 1.0, sumA, nullptr, nullptr, st);
+  return ff_reduce_launch(ws, nsplit, 1, npix, 0, em_scale, sumA, em, nullptr, st);
 }
 
 }  // namespace rjp

@@ -74,7 +74,7 @@ struct ChiPlan {
 bool chi_table_plan(const rjp_fields* fl, const rjp_bursts* hb, const double* epochs, int n_epochs,
                     int mode, bool want_em, size_t work_bytes, ChiPlan& cp);
 hipError_t chi_table_scan(const rjp_fields* fl, const ChiPlan& cp, const double* d_stage,
-                          double t_epoch, double* sumA, double* ws, size_t work_bytes,
+                          double t_epoch, double* sumA, double* em, double* ws, size_t work_bytes,
                           hipStream_t st);
 
 // ---- ff_moments.hip: epoch sweeps by launch-time moments --------------------------------------

@@ -400,7 +400,7 @@ int rjp_ff_scan(rjp_ctx* ctx, const rjp_fields* fields, const rjp_bursts* bursts
     double* dev[1];
     if (int r = stage_tables(ctx, st, src, len, 1, dev)) return r;
     return finish_staged(ctx, st, rjp::chi_table_scan(fields, ctx->chi, dev[0], h_epochs_s[0],
-                                                      d_sumA, (double*)d_work, work_bytes, st),
+                                                      d_sumA, d_em, (double*)d_work, work_bytes, st),
                          "chi_table_scan");
   }
   ctx->last_path = 0;

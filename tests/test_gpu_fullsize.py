@@ -302,10 +302,25 @@ def test_single_epoch_table_scan_vs_gaussians_and_oracle(eng, temp_mode, shape):
     dip = E.make_bursts([(1.0 * orc.YEAR, -0.5, 2e6)], [(1.2 * orc.YEAR, 3.0, 4e6)])
     eng.ff_scan(fields, dip, [1.0 * orc.YEAR], mode, want_em=False, want_tavg=False)
     assert eng.last_scan_path()[0] == "tiles"
-    # and a request for the EM map or for T_avg with the scan keeps the three-field kernels
-    eng.ff_scan(fields, bursts, [1.0 * orc.YEAR], mode, want_em=True, want_tavg=False)
+    # with the emission-measure map of the epoch (a third stream, em0): table path as well
+    ep = [1.3 * orc.YEAR]
+    a_t, e_t, _ = eng.ff_scan(fields, bursts, ep, mode, want_em=True, want_tavg=False)
+    assert eng.last_scan_path()[0] == "table"
+    a_t, e_t = a_t.clone(), e_t.clone()
+    eng.use_chi_table = False
+    a_g, e_g, _ = eng.ff_scan(fields, bursts, ep, mode, want_em=True, want_tavg=False)
     assert eng.last_scan_path()[0] == "tiles"
-
+    eng.use_chi_table = True
+    eng.synchronize()
+    for got, ref in ((a_t, a_g), (e_t, e_g)):
+        assert torch.equal(got == 0, ref == 0)
+        ok = ref != 0
+        assert ((got - ref).abs()[ok] / ref[ok]).max().item() < 3e-12
+    jet.time = ep[0]
+    np.testing.assert_allclose(e_t.cpu().numpy()[0, idx], jet.emission_measure()[:, 0], rtol=1e-11)
+    # T_avg asked for WITH the scan: the caller is served by the ordinary kernels
+    eng.ff_scan(fields, bursts, [1.0 * orc.YEAR], mode, want_em=False, want_tavg=True)
+    assert eng.last_scan_path()[0] == "tiles"
 
 def torch_all_finite(t):
     import torch
