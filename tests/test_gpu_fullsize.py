@@ -259,6 +259,7 @@ def test_single_epoch_table_scan_vs_gaussians_and_oracle(eng, temp_mode, shape):
     m_a = torch.rand(fields.ncells, device=eng.device, generator=g) < 0.02
     fields.ts[m_ts] = float("nan")
     fields.a0[m_a] = float("nan")
+    fields.em0[m_a] = float("nan")           # (the oracle's cells lose their density there)
     rng = np.random.default_rng(3)
     pix = [(int(rng.integers(nx)), int(rng.integers(nz))) for _ in range(6)] + [(0, 0), (nx - 1, nz - 1)]
     jet = _sample_jet(shape, pix, temp_mode, 0. if temp_mode == 0 else -0.5, seed=SEED + 5)
