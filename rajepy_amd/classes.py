@@ -639,6 +639,15 @@ class JetModel:
         return parallel.sweep_flux_vs_time(self, np.atleast_1d(np.asarray(times_s, float)),
                                            freq, rank=rank, world=world)
 
+    def prepare_epoch_sweeps(self, bins=32):
+        """Optional, for a model whose light curves are computed MANY times (e.g. while fitting
+        burst parameters): bucket the cells of every sightline by (jet, launch-time bin) once
+        (`RTEngine.build_lt`, ~50 ms and ~1.2 x the bytes of two fields for 1e9 cells).  Sweeps of
+        12-32 epochs (`flux_vs_time`) then keep their launch-time moments in registers: about a
+        quarter faster than the first-sweep path on dense grids.  Returns the layout record; a
+        setter that changes the fields (`ts`, `ion_fraction`, `temperature`) invalidates it."""
+        return self.engine.build_lt(self.device_fields, int(bins))
+
     # ------------------------------------------------------------------ RT methods ----
     def emission_measure(self, savefits=False):
         """Emission measure along y [pc cm^-6] (classes.py:1101-1128)."""

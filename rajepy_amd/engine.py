@@ -361,6 +361,8 @@ class RTEngine:
                                            self._stream()), self.ctx, "rjp_pack_field")
         self.synchronize()
         setattr(fields, name, dst)
+        if name in ("ts", "xi", "temp"):
+            fields.lt = None                    # the launch-time-ordered layout holds (a0, ts)
         if name == "ts":
             # what was measured on / derived from the old launch times (the new tensor may well
             # sit at the old one's address: never key these on the pointer alone)

@@ -249,3 +249,33 @@ def test_lt_abi_refusals(eng):
     with pytest.raises(ValueError):
         eng.build_lt(eng.synth_fields((2, 16, 64), 1, 0, 4), 8)       # f32 storage
     eng.synchronize()
+
+
+def test_jetmodel_light_curves_on_the_prepared_layout(eng, tmp_path):
+    """JetModel.prepare_epoch_sweeps + flux_vs_time on the example jet (K4-built fields with
+    occupied y-ranges, most sightlines empty): 30 epochs through the layout reproduce the
+    reference's anchors (total flux at 5 GHz at t = 0 / 0.5 / 1 / 2 / 3 yr) and
+    the tiles' light curve; replacing the launch times drops the layout."""
+    from rajepy_amd import classes, logger
+    from tests.test_host_logic import example_params
+    jm = classes.JetModel(example_params(), log=logger.Log(str(tmp_path / "a.log"), verbose=False),
+                          engine=eng)
+    info = jm.prepare_epoch_sweeps(24)
+    assert info["K"] == 24 and info["rows"] > 0
+    times = np.array(sorted(set(np.linspace(0., 3., 28)) | {0.5, 1.0, 2.0})) * orc.YEAR
+    assert 12 <= len(times) <= 32
+    lc = jm.flux_vs_time(times, [5e9])[:, 0]
+    assert eng.last_scan_path()[0] == "lt"
+    ref = {0.0: 1.158223515e-3, 0.5: 1.279591671e-3, 1.0: 1.379008153e-3, 2.0: 1.429076011e-3,
+           3.0: 1.418864143e-3}
+    for yr, want in ref.items():
+        k = int(np.argmin(np.abs(times - yr * orc.YEAR)))
+        assert abs(times[k] - yr * orc.YEAR) < 1.0
+        assert abs(lc[k] - want) <= 2e-9 * want
+    eng.use_moments = False
+    jm2 = classes.JetModel(example_params(), log=jm.log, engine=eng)
+    lc2 = jm2.flux_vs_time(times, [5e9])[:, 0]
+    eng.use_moments = True
+    np.testing.assert_allclose(lc, lc2, rtol=RTOL)
+    jm.ts = jm.ts * 1.0 + 0.0                      # the setter: a new launch-time tensor
+    assert jm.device_fields.struct().d_lt_cells is None
