@@ -17,8 +17,9 @@ for variant in tau2 tau3 wide5; do
   case $variant in
     # (the kernel of the timed step, by its full template arguments: <T, VEC, ET, MODE, BURSTS,
     # UNIF, LAY, EM> -- the run also launches the other layouts' kernels for its side figures)
-    tau2) flags=(); kern="ff_scan_table_kernel" ;;
-    tau3) flags=(--em); kern="ff_scan_kernel<double, 2, 1, 0, true, false, 2, true>" ;;
+    # (round 4: single-epoch scans of the tau layout take the burst factor from an LDS table)
+    tau2) flags=(); kern="ff_scan_table_kernel<6, false>" ;;
+    tau3) flags=(--em); kern="ff_scan_table_kernel<4, true>" ;;
     wide5) flags=(--layout wide --em); kern="ff_scan_kernel<double, 2, 1, 0, true, false, 0, true>" ;;
   esac
   sfx="_${variant}"
@@ -26,13 +27,15 @@ for variant in tau2 tau3 wide5; do
   if [[ $variant == tau2 ]]; then
     "${B[@]}" > "$out/${tag}_cfg4_f64${sfx}_bench.json" 2> "$out/${tag}_cfg4_f64${sfx}_bench.err"
   else
-    "${B[@]}" --no-cpu-baseline > "$out/${tag}_cfg4_f64${sfx}_bench.json" 2> "$out/${tag}_cfg4_f64${sfx}_bench.err"
+    "${B[@]}" --no-cpu-baseline --no-other-configs > "$out/${tag}_cfg4_f64${sfx}_bench.json" 2> "$out/${tag}_cfg4_f64${sfx}_bench.err"
   fi
   echo "bench $variant done"
+  # (--no-other-configs: the `configs` object of the default line would add cfg2-size launches
+  # of the same kernels to the per-kernel averages)
   rocprofv3 --kernel-trace --stats -d "$out/${tag}_cfg4${sfx}_stats" -o run --output-format csv -- \
-    "${B[@]}" --no-cpu-baseline > "$out/${tag}_cfg4_f64${sfx}_bench_under_rocprof.json" 2> "$out/${tag}_cfg4${sfx}_stats.log"
+    "${B[@]}" --no-cpu-baseline --no-other-configs > "$out/${tag}_cfg4_f64${sfx}_bench_under_rocprof.json" 2> "$out/${tag}_cfg4${sfx}_stats.log"
   echo "stats $variant done"
-  S=("${B[@]}" --steps 8 --warmup 2 --no-cpu-baseline --no-api-level --sustained-seconds 0)
+  S=("${B[@]}" --steps 8 --warmup 2 --no-cpu-baseline --no-api-level --sustained-seconds 0 --no-other-configs)
   rocprofv3 --kernel-trace --pmc FETCH_SIZE -d "$out/${tag}_cfg4${sfx}_fetch" -o run --output-format csv -- "${S[@]}" > "$out/${tag}_cfg4${sfx}_fetch.log" 2>&1
   rocprofv3 --kernel-trace --pmc WRITE_SIZE -d "$out/${tag}_cfg4${sfx}_write" -o run --output-format csv -- "${S[@]}" > "$out/${tag}_cfg4${sfx}_write.log" 2>&1
   echo "pmc $variant done"
