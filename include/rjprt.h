@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define RJP_VERSION 107          /* 0.1.7 */
+#define RJP_VERSION 108          /* 0.1.8 */
 #define RJP_RANGE_BLOCKS 2048    /* partial (min, max) pairs rjp_field_range writes */
 #define RJP_MAX_EPOCH_TILE 32    /* most epochs evaluated per grid pass: 32 uniformly spaced ones (with or without d_em), 16 when only 16-31 are left, else tiles of 8, 4, 2, 1 */
 
@@ -137,6 +137,18 @@ typedef struct rjp_fields {
   const double* d_lt_aux;
   int32_t lt_K;             /* launch-time bins per jet the layout was built with */
   int32_t reserved2_;       /* 0 */
+  /* Optional cache of the launch-time moment maps of a0 (NULL = none): rjp_moment_cache_bytes()
+   * bytes of device memory the CALLER keeps with the model.  The moments depend on the fields,
+   * on ts_lo / ts_hi, on the (bins, order) shape and on WHICH jets have bursts -- not on the
+   * epochs, not on the burst parameters -- so every further sweep of the model (other epochs,
+   * other bursts, e.g. a fit of burst parameters) needs only the contraction.  A sweep that
+   * takes the LDS moment path without EM maps writes its moment maps here instead of into the
+   * workspace; when mom_cache_K / mom_cache_N equal the shape that sweep selects, the pass over
+   * the grid is SKIPPED (rjp_last_scan_path returns 4).  The caller sets mom_cache_K / _N to the
+   * shape rjp_last_scan_path reported after a call that filled the buffer, and back to 0
+   * whenever d_a0, d_ts, the range or the set of jets with bursts changes. */
+  double* d_mom_cache;
+  int32_t mom_cache_K, mom_cache_N;
 } rjp_fields;
 
 /* Ejection bursts (classes.py:399-463): mdot(t)/mdot_ss = 1 + sum_b amp_rel_b *
@@ -245,7 +257,8 @@ int rjp_ff_scan(rjp_ctx* ctx, const rjp_fields* fields, const rjp_bursts* bursts
 
 /* Which path the last rjp_ff_scan of this context took: 0 = epoch tiles, 1 = launch-time moments
  * in LDS + contraction, 2 = launch-time moments on the launch-time-ordered layout, 3 = the
- * single-epoch tau-layout scan with the burst factor from a table in LDS (and, if
+ * single-epoch tau-layout scan with the burst factor from a table in LDS, 4 = contraction of the
+ * caller's cached moment maps (rjp_fields.d_mom_cache: no pass over the grid) (and, if
  * non-NULL: in *worst_rel_err the worst relative error of the moment expansion measured for
  * that call, in moment_shape[0..1] the (bins, order) shape it chose; zeros for the tiles).
  * For tests and the bench line. */
@@ -256,6 +269,9 @@ int rjp_last_scan_path(const rjp_ctx* ctx, double* worst_rel_err, int32_t* momen
  * one small launch and ONE stream synchronisation inside that rjp_ff_scan; a repeated request
  * reuses them).  0 before the first build. */
 double rjp_last_table_build_ms(const rjp_ctx* ctx);
+
+/* Bytes of rjp_fields.d_mom_cache for an n_x x n_z map (1280 doubles per sightline). */
+size_t rjp_moment_cache_bytes(int32_t nx, int32_t nz);
 
 /* ---- launch-time-ordered layout (rjp_fields.d_lt_*) -------------------------------------
  * Two calls, because the size of the padded layout is known only after counting:

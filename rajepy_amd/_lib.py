@@ -18,7 +18,7 @@ RJP_F32, RJP_F64 = 4, 8
 RJP_GFF_SCALAR, RJP_GFF_POWERLAW = 0, 1
 RJP_MAX_EPOCH_TILE = 32
 RJP_RANGE_BLOCKS = 2048
-RJP_VERSION = 107             # include/rjprt.h; the binding below matches exactly this ABI
+RJP_VERSION = 108             # include/rjprt.h; the binding below matches exactly this ABI
 RJP_OK = 0
 RJP_ERR_ARG, RJP_ERR_HIP, RJP_ERR_NODEVICE, RJP_ERR_WORKSPACE, RJP_ERR_DEGENERATE = \
     -1, -2, -3, -4, -5
@@ -41,7 +41,9 @@ class Fields(C.Structure):
                 ("d_a0", C.c_void_p), ("a0_mode", C.c_int32), ("reserved_", C.c_int32),
                 ("ts_lo", C.c_double), ("ts_hi", C.c_double), ("occupied_cells", C.c_int64),
                 ("d_lt_cells", C.c_void_p), ("d_lt_rowoff", C.c_void_p),
-                ("d_lt_aux", C.c_void_p), ("lt_K", C.c_int32), ("reserved2_", C.c_int32)]
+                ("d_lt_aux", C.c_void_p), ("lt_K", C.c_int32), ("reserved2_", C.c_int32),
+                ("d_mom_cache", C.c_void_p), ("mom_cache_K", C.c_int32),
+                ("mom_cache_N", C.c_int32)]
 
 
 class Bursts(C.Structure):
@@ -96,6 +98,7 @@ SIGNATURES = {
                               C.c_int32, _P, _P, _P, _P, C.c_size_t, _P]),
     "rjp_last_scan_path": (C.c_int, [_P, _DP, C.POINTER(C.c_int32)]),
     "rjp_last_table_build_ms": (C.c_double, [_P]),
+    "rjp_moment_cache_bytes": (C.c_size_t, [C.c_int32, C.c_int32]),
     "rjp_lt_rowoff_entries": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32]),
     "rjp_lt_count": (C.c_int, [_P, C.POINTER(Fields), C.c_int32, _P, C.POINTER(C.c_int64), _P]),
     "rjp_lt_fill": (C.c_int, [_P, C.POINTER(Fields), C.c_int32, _P, _P, _P, _P]),

@@ -326,11 +326,18 @@ int moments_plan(const rjp_fields* fl, const rjp_bursts* hb, const double* epoch
                          (want_em ? 2.0 : 1.0);
     lds = t_mom < 0.8 * t_tiles;
   }
+  // a caller-kept cache of the moment maps of one of the LDS shapes (rjp_fields.d_mom_cache):
+  // that shape is tried first -- its sweep is a contraction only, cheaper than every other path
+  int cache_shape = -1;
+  if (fl->d_mom_cache && !want_em)
+    for (int sh = 0; sh < kMomNShapes; ++sh)
+      if (kMomShapes[sh].K == fl->mom_cache_K && kMomShapes[sh].N == fl->mom_cache_N) cache_shape = sh;
+  if (cache_shape >= 0) lds = true;
   if (!lt && !lds) return 0;
   const int ltK = lt ? fl->lt_K : 0;
   // same request as last time?  (the tables are still on the device)
   if (mp.key_E == n_epochs && mp.key_lo == fl->ts_lo && mp.key_hi == fl->ts_hi &&
-      mp.key_ltK == (lds ? ltK : -2 - ltK) && mp.key_epochs.size() == (size_t)n_epochs &&
+      mp.key_ltK == (lds ? ltK : -2 - ltK) + 1000 * (cache_shape + 1) && mp.key_epochs.size() == (size_t)n_epochs &&
       std::memcmp(mp.key_epochs.data(), epochs, sizeof(double) * n_epochs) == 0 &&
       mp.key_n[0] == hb->n[0] && mp.key_n[1] == hb->n[1]) {
     bool same = true;
@@ -342,7 +349,7 @@ int moments_plan(const rjp_fields* fl, const rjp_bursts* hb, const double* epoch
     if (same) { mp.ok = mp.key_ok; return mp.ok ? 1 : 0; }
   }
   mp.key_E = n_epochs; mp.key_lo = fl->ts_lo; mp.key_hi = fl->ts_hi;
-  mp.key_ltK = lds ? ltK : -2 - ltK;            // (the candidate set depends on both)
+  mp.key_ltK = (lds ? ltK : -2 - ltK) + 1000 * (cache_shape + 1);   // (the candidate set depends on all three)
   mp.key_epochs.assign(epochs, epochs + n_epochs);
   mp.key_n[0] = hb->n[0]; mp.key_n[1] = hb->n[1];
   mp.key_bursts.clear();
@@ -374,7 +381,9 @@ int moments_plan(const rjp_fields* fl, const rjp_bursts* hb, const double* epoch
     if (!(sigma_min >= h / N)) return;                          // also rejects NaN / inf widths
     if ((int)mp.cands.size() < RJP_MOM_MAX_CAND) mp.cands.push_back(MomCand{K, N, path, 0, 0});
   };
-  // the layout first (any order up to 32 over its bins), then the three LDS shapes
+  // the cached shape first, then the layout (any order up to 32 over its bins), then the three
+  // LDS shapes
+  if (cache_shape >= 0) consider(kMomShapes[cache_shape].K, kMomShapes[cache_shape].N, 1);
   if (lt)
     for (int N = 8; N <= RJP_MOM_NMAX; N += 4) consider(ltK, N, 2);
   if (lds)
@@ -492,15 +501,17 @@ static hipError_t moments_pass(const rjp_fields* fl, const double* weights, cons
 // constant factor of the result (1 for the sums of a0).
 hipError_t moments_run(const rjp_fields* fl, const MomPlan& mp, int n_epochs,
                        double* sumA, double* ws, hipStream_t st, const double* weights,
-                       double scale) {
+                       double scale, bool skip_pass) {
   const double* d_W = mp.d_Wsel;
   const int64_t npix = (int64_t)fl->nx * fl->nz;
   const int64_t npixp = (npix + kMomSL - 1) / kMomSL * kMomSL;
   MomDev md;
   md.s0 = mp.s0; md.inv_h = mp.inv_h;
   md.has_bursts[0] = mp.has_bursts[0]; md.has_bursts[1] = mp.has_bursts[1];
-  hipError_t err = hipErrorInvalidValue;
-  if (mp.K == 80 && mp.N == 8) err = moments_pass<80, 8>(fl, weights, md, npix, npixp, ws, st);
+  // `skip_pass`: `ws` already holds this model's moment maps of this shape (a caller-kept cache)
+  hipError_t err = skip_pass ? hipSuccess : hipErrorInvalidValue;
+  if (skip_pass) {}
+  else if (mp.K == 80 && mp.N == 8) err = moments_pass<80, 8>(fl, weights, md, npix, npixp, ws, st);
   else if (mp.K == 53 && mp.N == 12) err = moments_pass<53, 12>(fl, weights, md, npix, npixp, ws, st);
   else if (mp.K == 39 && mp.N == 16) err = moments_pass<39, 16>(fl, weights, md, npix, npixp, ws, st);
   if (err != hipSuccess) return err;

@@ -127,7 +127,7 @@ hipError_t moments_build(MomPlan& mp, const double* d_stage, hipStream_t st);
 void moments_release(MomPlan& mp);
 hipError_t moments_run(const rjp_fields* fl, const MomPlan& mp, int n_epochs,
                        double* sumA, double* ws, hipStream_t st, const double* weights,
-                       double scale);
+                       double scale, bool skip_pass = false);
 // launch-time-ordered layout (ff_lt.hip)
 #define RJP_LT_MAX_K 80
 #define RJP_LT_MAX_EPOCHS 32     /* one fused pass serves one contraction tile */

@@ -378,8 +378,19 @@ int rjp_ff_scan(rjp_ctx* ctx, const rjp_fields* fields, const rjp_bursts* bursts
       RJP_HIP(ctx, rjp::lt_run(fields, ctx->mom, n_epochs, d_sumA, (double*)d_work, st));
       return RJP_OK;
     }
-    hipError_t e = rjp::moments_run(fields, ctx->mom, n_epochs, d_sumA, (double*)d_work, st,
-                                    (const double*)fields->d_a0, 1.0);
+    // the moment maps of a0 are model state (they depend on the launch-time bins and on which
+    // jets have bursts, not on the epochs or the burst parameters): a caller-kept cache of the
+    // selected shape replaces the pass over the grid; an empty or differently shaped one is
+    // filled by this call
+    double* mbuf = (double*)d_work;
+    bool cached = false;
+    if (fields->d_mom_cache && !d_em) {
+      mbuf = fields->d_mom_cache;
+      cached = fields->mom_cache_K == ctx->mom.K && fields->mom_cache_N == ctx->mom.N;
+    }
+    if (cached) ctx->last_path = 4;
+    hipError_t e = rjp::moments_run(fields, ctx->mom, n_epochs, d_sumA, mbuf, st,
+                                    (const double*)fields->d_a0, 1.0, cached);
     if (e == hipSuccess && d_em) {
       // the emission measure of every epoch: the same pass and tables with em0 as the weight
       // (em = sum (n x)^2 * csize*au/pc * pf, classes.py:1116-1118)
@@ -425,7 +436,7 @@ int rjp_ff_scan(rjp_ctx* ctx, const rjp_fields* fields, const rjp_bursts* bursts
 
 int rjp_last_scan_path(const rjp_ctx* ctx, double* worst_rel_err, int32_t* moment_shape) {
   if (!ctx) return RJP_ERR_ARG;
-  const bool mom = ctx->last_path == 1 || ctx->last_path == 2;
+  const bool mom = ctx->last_path == 1 || ctx->last_path == 2 || ctx->last_path == 4;
   if (worst_rel_err) *worst_rel_err = mom ? ctx->mom.worst : ctx->last_path == 3 ? 2e-13 : 0.0;
   if (moment_shape) {
     // (path 3: the table's intervals per jet and its polynomial degree + 1)
@@ -436,6 +447,11 @@ int rjp_last_scan_path(const rjp_ctx* ctx, double* worst_rel_err, int32_t* momen
 }
 
 double rjp_last_table_build_ms(const rjp_ctx* ctx) { return ctx ? ctx->mom.build_ms : 0.0; }
+
+size_t rjp_moment_cache_bytes(int32_t nx, int32_t nz) {
+  if (nx <= 0 || nz <= 0) return 0;
+  return rjp::moments_workspace_bytes((int64_t)nx * nz);
+}
 
 size_t rjp_lt_rowoff_entries(int32_t nx, int32_t nz, int32_t K) {
   if (nx <= 0 || nz <= 0 || K < 1 || K > RJP_LT_MAX_K) return 0;

@@ -37,6 +37,7 @@ class DeviceFields:
         self.ts_range = None                # optional (ts_lo, ts_hi) of the finite launch times
         self._ts_range_of = None            # ... and the `ts` tensor it was measured on
         self.lt = None                      # optional launch-time-ordered layout (RTEngine.build_lt)
+        self.mom_cache = None               # optional cache of the launch-time moment maps of a0
 
     @property
     def ncells(self):
@@ -150,6 +151,9 @@ class RTEngine:
         # single-epoch scans of large maps on the tau layout take the burst factor from a table in
         # LDS (ff_scan_tab.hip; needs the launch-time range); False: always the Gaussians
         self.use_chi_table = True
+        # keep the launch-time moment maps of a model that is swept repeatedly (2.7 GB at
+        # 512 x 512 sightlines): from the third long sweep on only the contraction runs
+        self.cache_moments = True
         self.last_moment_shape = (0, 0)
 
     def close(self):
@@ -363,6 +367,7 @@ class RTEngine:
         setattr(fields, name, dst)
         if name in ("ts", "xi", "temp"):
             fields.lt = None                    # the launch-time-ordered layout holds (a0, ts)
+            fields.mom_cache = None             # ... and the moment maps are sums over them
         if name == "ts":
             # what was measured on / derived from the old launch times (the new tensor may well
             # sit at the old one's address: never key these on the pointer alone)
@@ -516,13 +521,53 @@ class RTEngine:
         wb = self.lib.rjp_ff_scan_workspace(nx, ny, nz, E)
         work = self._workspace(wb)
         fs = self._scan_struct(fields, bursts, E)
+        mkey = self._attach_moment_cache(fields, bursts, fs, E, em is not None)
         ep = _lib.dbl_array(epochs_s)
         _lib.check(self.lib.rjp_ff_scan(
             self.ctx, C.byref(fs), C.byref(bursts) if bursts is not None else None, ep, E,
             int(gff_mode), sumA.data_ptr(), em.data_ptr() if em is not None else None,
             tavg.data_ptr() if tavg is not None else None, work.data_ptr(), work.numel(),
             self._stream()), self.ctx, "rjp_ff_scan")
+        if mkey is not None:
+            self._note_moment_sweep(fields, mkey)
         return sumA, em, tavg
+
+    def _attach_moment_cache(self, fields, bursts, fs, n_epochs, want_em):
+        """The caller-kept moment maps of include/rjprt.h `rjp_fields.d_mom_cache`.  A model's
+        first long sweep runs as before; once a sweep HAS taken the LDS moment path the buffer is
+        allocated, the next sweep's pass fills it, and every later sweep of the same fields (same
+        launch times, same set of jets with bursts) is the contraction alone.  Returns the key
+        the cache would be valid for (None: this scan cannot use one)."""
+        if not (self.cache_moments and self.use_moments and n_epochs >= 12 and not want_em and
+                bursts is not None and fields.a0 is not None and fields.ts is not None and
+                fs.ts_lo != fs.ts_hi):
+            return None
+        key = (fields.a0.data_ptr(), fs.d_ts, fs.ts_lo, fs.ts_hi, int(bursts.n[0]) > 0,
+               int(bursts.n[1]) > 0)
+        mc = fields.mom_cache
+        if mc is not None and mc.get("buf") is not None:
+            if mc["key"] != key:
+                mc["K"] = mc["N"] = 0
+                mc["key"] = key
+            fs.d_mom_cache = mc["buf"].data_ptr()
+            fs.mom_cache_K, fs.mom_cache_N = mc["K"], mc["N"]
+        return key
+
+    def _note_moment_sweep(self, fields, key):
+        path = self.last_scan_path()[0]
+        mc = fields.mom_cache
+        if path in ("moments", "cached"):
+            if mc is None or mc.get("buf") is None:
+                # the first sweep on this path: reserve the buffer, the next one fills it
+                nx, _, nz = fields.shape
+                nbytes = self.lib.rjp_moment_cache_bytes(nx, nz)
+                buf = _torch().empty(nbytes // 8, dtype=_torch().float64, device=self.device)
+                fields.mom_cache = {"buf": buf, "K": 0, "N": 0, "key": key}
+            else:
+                mc["K"], mc["N"] = self.last_moment_shape
+                mc["key"] = key
+        elif mc is not None:
+            mc["K"] = mc["N"] = 0                 # (another path ran: the buffer was not refreshed)
 
     def last_scan_path(self):
         """('tiles' | 'moments' | 'lt' | 'table', worst relative error of the expansion) of the
@@ -532,7 +577,7 @@ class RTEngine:
         shape = (C.c_int32 * 2)()
         path = self.lib.rjp_last_scan_path(self.ctx, C.byref(err), shape)
         self.last_moment_shape = (int(shape[0]), int(shape[1]))      # (bins, order); (0, 0) = tiles
-        return {0: "tiles", 1: "moments", 2: "lt", 3: "table"}[path], err.value
+        return {0: "tiles", 1: "moments", 2: "lt", 3: "table", 4: "cached"}[path], err.value
 
     def last_table_build_ms(self):
         """Host wall time of the last coefficient-table build (a new bursts / epochs request)."""

@@ -23,6 +23,7 @@ SEED = 20240504
 def eng():
     from rajepy_amd.engine import RTEngine
     e = RTEngine(0)
+    e.cache_moments = False        # (paths are asserted sweep by sweep; the cache: test_gpu_moments)
     yield e
     e.close()
 

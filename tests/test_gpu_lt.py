@@ -23,7 +23,8 @@ RTOL = 5e-11
 def eng():
     from rajepy_amd.engine import RTEngine
     e = RTEngine(0)
-    e.force_moments = True          # (the fallbacks below: the LDS moments, not the cost model)
+    e.force_moments = True
+    e.cache_moments = False        # (paths are asserted sweep by sweep; the cache has its own test)          # (the fallbacks below: the LDS moments, not the cost model)
     yield e
     e.close()
 

@@ -27,6 +27,7 @@ def eng():
     from rajepy_amd.engine import RTEngine
     e = RTEngine(0)
     e.force_moments = True
+    e.cache_moments = False        # (paths are asserted sweep by sweep; the cache has its own test)
     yield e
     e.close()
 
@@ -276,3 +277,68 @@ def test_replacing_the_launch_times_remeasures_their_range(eng):
     assert path2 == "moments" and f.ts_range == (2.0 * lo0, 2.0 * hi0)
     np.testing.assert_allclose(mom2, til2, rtol=RTOL)
     assert not np.allclose(mom2, mom, rtol=1e-3)
+
+
+def test_cached_moment_maps_serve_further_sweeps_without_a_pass_over_the_grid(eng):
+    """rjp_fields.d_mom_cache: the moment maps of a0 depend on the fields, the launch-time range,
+    the shape and on which jets have bursts -- not on epochs or burst parameters.  The first long
+    sweep of a model runs as before, the second fills the caller-kept buffer, every later one --
+    other epochs, other burst parameters -- is the contraction alone and equals the uncached
+    result to rounding (same maps, same tables); a different SET of jets with bursts, replaced
+    launch times or a sweep that needs another shape refill it."""
+    from rajepy_amd import engine as E
+    shape = (4, 180, 48)
+    g, p, jet = _jet(shape, 777)
+    f = eng.upload_fields(g["nd"], g["xi"], g["temp"], g["ff"], g["areas"], g["ts"],
+                          g["rr"] < 0, csize_au=jet.csize, dtype=8)
+    eng.tau_layout(f, E.RJP_GFF_SCALAR)
+    bursts = U.bursts_from_oracle(jet)
+    yr = orc.YEAR
+    sweep = lambda b, ep: eng.ff_scan(f, b, ep, 0, want_em=False, want_tavg=False)[0].clone()
+    ep1 = [y * yr for y in np.linspace(0., 5., 32)]
+    ep2 = [y * yr for y in np.linspace(0.2, 4.4, 17)]
+    eng.cache_moments = True
+    try:
+        a1 = sweep(bursts, ep1)
+        assert eng.last_scan_path()[0] == "moments" and f.mom_cache["K"] == 0
+        a2 = sweep(bursts, ep1)                                   # fills the buffer
+        assert eng.last_scan_path()[0] == "moments" and (f.mom_cache["K"], f.mom_cache["N"]) == (53, 12)
+        a3 = sweep(bursts, ep1)
+        assert eng.last_scan_path()[0] == "cached"
+        b3 = sweep(bursts, ep2)                                   # other epochs: still cached
+        assert eng.last_scan_path()[0] == "cached"
+        # other burst parameters (same jets): cached as well
+        other = E.make_bursts([(0.6 * yr, 3.0, 0.2 * yr), (2.2 * yr, 6.0, 0.5 * yr)],
+                              [(1.1 * yr, 2.0, 0.4 * yr)])
+        c3 = sweep(other, ep2)
+        assert eng.last_scan_path()[0] == "cached"
+        eng.cache_moments = False
+        b0, c0 = sweep(bursts, ep2), sweep(other, ep2)
+        assert eng.last_scan_path()[0] == "moments"
+        eng.cache_moments = True
+        eng.synchronize()
+        for got, ref in ((a2, a1), (a3, a1), (b3, b0), (c3, c0)):
+            np.testing.assert_allclose(got.cpu().numpy(), ref.cpu().numpy(), rtol=1e-12)
+        # bursts in ONE jet only: the other jet's NaN launch times count now -> refilled
+        one = E.make_bursts([(0.6 * yr, 3.0, 0.3 * yr)], [])
+        sweep(one, ep2)
+        assert eng.last_scan_path()[0] == "moments"
+        sweep(one, ep2)
+        assert eng.last_scan_path()[0] == "cached"
+        # narrower bursts need another shape: the pass runs again into the buffer
+        ej = U.example_bursts_params()
+        ej["hl"] = np.asarray(ej["hl"], float) * 0.8
+        g2, p2, jet2 = _jet(shape, 777, ejection=ej)
+        nb = U.bursts_from_oracle(jet2)
+        n1 = sweep(nb, ep1)
+        assert eng.last_scan_path()[0] == "moments" and eng.last_moment_shape == (39, 16)
+        n2 = sweep(nb, ep1)
+        assert eng.last_scan_path()[0] == "cached"
+        np.testing.assert_allclose(n2.cpu().numpy(), n1.cpu().numpy(), rtol=1e-12)
+        # replaced launch times drop the cache
+        eng.replace_field(f, "ts", np.where(np.isnan(g["ts"]), np.nan, 0.9 * g["ts"]))
+        assert f.mom_cache is None
+        sweep(bursts, ep1)
+        assert eng.last_scan_path()[0] == "moments"
+    finally:
+        eng.cache_moments = False
