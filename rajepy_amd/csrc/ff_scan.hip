@@ -197,10 +197,10 @@ __global__ __launch_bounds__(kBlock) void ff_maps_kernel(
 // once per channel and LANE, as in ff_ftot_kernel below.  Same arithmetic per (pixel, channel);
 // the totals are summed in another (fixed) order.
 constexpr int kMapsFC = 16;      // channels per workgroup (gridDim.z slices the channel axis)
-template <int VEC, bool FT>
+template <int VEC, bool FT, int KP>
 __global__ __launch_bounds__(kBlock) void ff_maps_acc_kernel(
     const double* __restrict__ sumA, const double* __restrict__ tavg, int64_t npix,
-    const double* __restrict__ ctau, const double* __restrict__ cflux, int nchan, int kp,
+    const double* __restrict__ ctau, const double* __restrict__ cflux, int nchan,
     double* __restrict__ tau, double* __restrict__ flux, double* __restrict__ part, int nparts) {
   const int e = blockIdx.y;
   const int f0 = blockIdx.z * kMapsFC;
@@ -208,13 +208,20 @@ __global__ __launch_bounds__(kBlock) void ff_maps_acc_kernel(
   double acc[kMapsFC];
 #pragma unroll
   for (int j = 0; j < kMapsFC; ++j) acc[j] = 0.0;
-#pragma unroll 1
-  for (int k = 0; k < kp; ++k) {
-    const int64_t p = (((int64_t)blockIdx.x * kp + k) * kBlock + threadIdx.x) * VEC;
-    if (p >= npix) continue;                       // npix % VEC == 0
-    double A[VEC], ta[VEC];
-    load_plain(sumA + (int64_t)e * npix + p, A);
-    load_plain(tavg + p, ta);
+  // the base maps of all KP pixel groups first (their loads are in flight together), then the
+  // stores of group after group
+  double A[KP][VEC], ta[KP][VEC];
+  int64_t pk[KP];
+#pragma unroll
+  for (int k = 0; k < KP; ++k) {
+    pk[k] = (((int64_t)blockIdx.x * KP + k) * kBlock + threadIdx.x) * VEC;
+    const int64_t pc = pk[k] < npix ? pk[k] : 0;               // npix % VEC == 0
+    load_plain(sumA + (int64_t)e * npix + pc, A[k]);
+    load_plain(tavg + pc, ta[k]);
+  }
+#pragma unroll
+  for (int k = 0; k < KP; ++k) {
+    if (pk[k] >= npix) continue;
 #pragma unroll
     for (int j = 0; j < kMapsFC; ++j) {
       if (j < nf) {
@@ -222,11 +229,11 @@ __global__ __launch_bounds__(kBlock) void ff_maps_acc_kernel(
         double t[VEC], s[VEC];
 #pragma unroll
         for (int v = 0; v < VEC; ++v) {
-          t[v] = ct * A[v];
-          s[v] = cf * (ta[v] * one_minus_exp_neg(t[v]));
+          t[v] = ct * A[k][v];
+          s[v] = cf * (ta[k][v] * one_minus_exp_neg(t[v]));
           if (FT) acc[j] += s[v] == s[v] ? s[v] : 0.0;                 // nansum
         }
-        const int64_t o = ((int64_t)e * nchan + f0 + j) * npix + p;
+        const int64_t o = ((int64_t)e * nchan + f0 + j) * npix + pk[k];
         if (tau) store_cube(tau + o, t);
         if (flux) store_cube(flux + o, s);
       }
@@ -793,8 +800,12 @@ hipError_t ff_maps_launch(const double* sumA, const double* tavg, int64_t npix, 
       auto go = [&](auto vtag, auto ftag) {
         constexpr int V = decltype(vtag)::value;
         constexpr bool FT = decltype(ftag)::value;
-        hipLaunchKernelGGL((ff_maps_acc_kernel<V, FT>), g, dim3(kBlock), 0, st, sumA, tavg, npix,
-                           d_ctau, d_cflux, n_chan, kp, tau, flux, ftot ? part : nullptr, np);
+        if (kp == 4)
+          hipLaunchKernelGGL((ff_maps_acc_kernel<V, FT, 4>), g, dim3(kBlock), 0, st, sumA, tavg, npix,
+                             d_ctau, d_cflux, n_chan, tau, flux, ftot ? part : nullptr, np);
+        else
+          hipLaunchKernelGGL((ff_maps_acc_kernel<V, FT, 1>), g, dim3(kBlock), 0, st, sumA, tavg, npix,
+                             d_ctau, d_cflux, n_chan, tau, flux, ftot ? part : nullptr, np);
       };
       using I1 = std::integral_constant<int, 1>;
       using I2 = std::integral_constant<int, 2>;
