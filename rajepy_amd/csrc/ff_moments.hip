@@ -10,12 +10,14 @@
 //     M[p][jet][k][n] = sum_{y in bin k, jet} a0_y T_n(xi_y),    xi = position inside the bin,
 // after which ANY number of epochs, uniformly spaced or not, is the small contraction
 //     sumA_e[p] = sum_{jet,k,n} M[p][jet][k][n] * W[jet][k][n][e],
-// W = Chebyshev coefficients of s -> F_jet(t_e - s) on bin k, computed on the host for the
-// call's bursts and epochs.  F is entire (a polynomial in Gaussians): the expansion converges
-// faster than geometrically, and the host CHECKS it -- the interpolant is compared with F at
-// 2N+1 points of every (jet, bin, epoch) and the path is used only when the worst relative
-// error stays below 1e-11 (the agreement the recurrence tiles have with the direct ones); a
-// launch-time range too wide for the narrowest burst simply keeps the tiles.
+// W = Chebyshev coefficients of s -> F_jet(t_e - s) on bin k, computed for the call's bursts and
+// epochs (since round 4 on the device: mom_tables_kernel below).  F is entire (a polynomial in
+// Gaussians): the expansion converges faster than geometrically, and it is CHECKED -- the
+// interpolant is compared with F at 2N+1 points of every (jet, bin, epoch) and the path is used
+// only when the worst relative error stays below 1e-11 (the agreement the recurrence tiles have
+// with the direct ones); a launch-time range too wide for the narrowest burst simply keeps the
+// tiles.  The moment maps themselves depend on neither epochs nor burst parameters: a caller may
+// keep them (rjp_fields.d_mom_cache) and later sweeps of the model are contractions only.
 //
 // Moment pass: launch times are uncorrelated along y in general (and in the synthetic set), so
 // a cell's (jet, bin) is random and the accumulators cannot live in registers: a workgroup owns
