@@ -41,6 +41,9 @@ namespace rjp {
 #ifndef RJP_TAB_U_EM
 #define RJP_TAB_U_EM 4           /* ... with the EM map (three streams) */
 #endif
+#ifndef RJP_TAB_U_WIDE
+#define RJP_TAB_U_WIDE 3         /* ... from the five model fields (five streams) */
+#endif
 #ifndef RJP_TAB_WGS
 #define RJP_TAB_WGS 512          /* y-ranges are added until this many workgroups exist (1024 / 2048 at cfg4: 2.518 / 2.524 ms) */
 #endif
@@ -189,6 +192,125 @@ __global__ __launch_bounds__(kBlock) void ff_scan_table_kernel(
   }
 }
 
+// The same scan from the five MODEL fields (nd, xi, temp, pf, ts: SURVEY 8(d)'s byte model, what
+// a model without the derived scan fields a0 / em0 streams): optical-depth sums, emission measure
+// and T_avg of the epoch in one pass, the burst factor from the table.  Per-product NaN semantics
+// as ff_scan_kernel's wide layout (nansum of (n chi x)^2 pf T^p and of (n chi x)^2 pf; T_avg =
+// nanmean_y(T > 0), classes.py:1116-1118, 1395-1397, 1471-1472).
+template <int U, int MODE>
+__global__ __launch_bounds__(kBlock) void ff_scan_table_wide_kernel(
+    FieldPtrs<double> f, int ny, int nz, int64_t nchunks, int64_t npix, int ylen, int nsplit,
+    ChiTabDev t, double t_epoch, const double* __restrict__ tab, double* __restrict__ ws,
+    double* __restrict__ sumA, double* __restrict__ em, double* __restrict__ tavg,
+    double em_scale) {
+  constexpr int VEC = 2;
+  extern __shared__ __attribute__((aligned(16))) double s_chi[];       // [2][ni][10]
+  for (int i = threadIdx.x; i < 2 * t.ni * kChiStride; i += kBlock) s_chi[i] = tab[i];
+  __shared__ int s_lo, s_hi;
+  if (threadIdx.x == 0) { s_lo = ny; s_hi = 0; }
+  __syncthreads();
+  const int split = (int)(blockIdx.x % (unsigned)nsplit);
+  const int64_t c = (int64_t)(blockIdx.x / (unsigned)nsplit) * kBlock + threadIdx.x;
+  const bool lane_live = c < nchunks;
+  const int64_t p0 = c * VEC;
+  int y0 = split * ylen;
+  int y1 = min(ny, y0 + ylen);
+  if (f.ylo) {
+    if (lane_live) {
+      int lo = ny, hi = 0;
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) { lo = min(lo, f.ylo[p0 + v]); hi = max(hi, f.yhi[p0 + v]); }
+      if (lo < hi) { atomicMin(&s_lo, lo); atomicMax(&s_hi, hi); }
+    }
+    __syncthreads();
+    y0 = max(y0, s_lo);
+    y1 = min(y1, s_hi);
+  }
+  if (!lane_live) return;
+  const int64_t x = p0 / nz;
+  const int z = (int)(p0 - x * nz);
+  const double wmax = t.wmax;
+  auto chi2 = [&](bool red, double tv) __attribute__((always_inline)) {
+    double w = (t_epoch - tv - t.lo) * t.inv_h;
+    w = __builtin_fmin(__builtin_fmax(w, 0.0), wmax);
+    const double kf = __builtin_floor(w);
+    const double xi = __builtin_fma(2.0, w - kf, -1.0);
+    const int k = (int)kf + (red ? 0 : t.ni);
+    const rjp_d2* cp = reinterpret_cast<const rjp_d2*>(s_chi + k * kChiStride);
+    const rjp_d2 c01 = cp[0], c23 = cp[1], c45 = cp[2], c67 = cp[3];
+    double chi = __builtin_fma(c67.y, xi, c67.x);
+    chi = __builtin_fma(chi, xi, c45.y);
+    chi = __builtin_fma(chi, xi, c45.x);
+    chi = __builtin_fma(chi, xi, c23.y);
+    chi = __builtin_fma(chi, xi, c23.x);
+    chi = __builtin_fma(chi, xi, c01.y);
+    chi = __builtin_fma(chi, xi, c01.x);
+    return chi * chi;
+  };
+  double accA[VEC] = {0.0, 0.0}, accE[VEC] = {0.0, 0.0}, accT[VEC] = {0.0, 0.0};
+  int cnt[VEC] = {0, 0};
+  auto rows = [&](auto utag, int64_t off) __attribute__((always_inline)) {
+    constexpr int UU = decltype(utag)::value;
+    double nd[UU][VEC], xi[UU][VEC], tp[UU][VEC], pf[UU][VEC], tt[UU][VEC];
+#pragma unroll
+    for (int u = 0; u < UU; ++u) {
+      const int64_t o = off + (int64_t)u * nz;
+      load_vec(f.nd + o, nd[u]);
+      load_vec(f.xi + o, xi[u]);
+      load_vec(f.temp + o, tp[u]);
+      load_vec(f.pf + o, pf[u]);
+      load_vec(f.ts + o, tt[u]);
+    }
+    double tpw[UU][VEC];
+    if (MODE == RJP_GFF_POWERLAW)
+      pow_m1p35_batch<UU * VEC>(reinterpret_cast<const double (&)[UU * VEC]>(tp),
+                                reinterpret_cast<double (&)[UU * VEC]>(tpw));
+    else
+      pow_m1p5_batch<UU * VEC>(reinterpret_cast<const double (&)[UU * VEC]>(tp),
+                               reinterpret_cast<double (&)[UU * VEC]>(tpw));
+#pragma unroll
+    for (int u = 0; u < UU; ++u)
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) {
+        const double Tk = tp[u][v];
+        accT[v] += __builtin_fmax(Tk, 0.0);
+        cnt[v] += Tk > 0.0 ? 1 : 0;
+        const double n0 = __builtin_fabs(nd[u][v]) * xi[u][v];
+        const double g = poison_unless(n0 * n0 * pf[u][v], tt[u][v] == tt[u][v]);
+        const double c2 = chi2(signbit_d(nd[u][v]), tt[u][v]);
+        accE[v] = __builtin_fma(nan_to_zero<false>(g), c2, accE[v]);
+        accA[v] = __builtin_fma(nan_to_zero<false>(g * tpw[u][v]), c2, accA[v]);
+      }
+  };
+  int64_t off = (x * ny + y0) * (int64_t)nz + z;
+  int y = y0;
+  for (; y + U <= y1; y += U) {
+    rows(std::integral_constant<int, U>{}, off);
+    off += (int64_t)U * nz;
+  }
+  for (; y < y1; ++y) {
+    rows(std::integral_constant<int, 1>{}, off);
+    off += nz;
+  }
+  if (nsplit == 1) {
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) {
+      sumA[p0 + v] = accA[v];
+      if (em) em[p0 + v] = accE[v] * em_scale;
+      if (tavg) tavg[p0 + v] = accT[v] / (double)cnt[v];      // 0/0 = NaN on empty sightlines
+    }
+  } else {
+    double* w = ws + (int64_t)split * nacc(1) * npix + p0;
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) {
+      w[v] = accA[v];
+      w[npix + v] = accE[v];
+      w[2 * npix + v] = accT[v];
+      w[3 * npix + v] = (double)cnt[v];
+    }
+  }
+}
+
 // ---- host -----------------------------------------------------------------------------------
 // Vandermonde inverse of the 8 Chebyshev nodes on [-1, 1] (monomial coefficients in the interval's
 // own coordinate from node values; on [-1, 1] the matrix is well conditioned)
@@ -221,7 +343,13 @@ bool chi_table_plan(const rjp_fields* fl, const rjp_bursts* hb, const double* ep
                     int mode, bool want_em, size_t work_bytes, ChiPlan& cp) {
   cp.ok = false;
   if (!hb || (hb->n[0] <= 0 && hb->n[1] <= 0) || n_epochs != 1) return false;
-  if (scan_layout(fl, mode, want_em) != LAY_TAU || !fl->d_ts || ff_scan_vec(fl) != 2) return false;
+  // the tau layout (a0, ts [, em0]) or the five model fields (f64): the compact layout -- no
+  // default of any producer -- keeps the Gaussians
+  const int lay = scan_layout(fl, mode, want_em);
+  if ((lay != LAY_TAU && !(lay == LAY_WIDE && fl->dtype == RJP_F64)) || !fl->d_ts ||
+      ff_scan_vec(fl) != 2)
+    return false;
+  cp.wide = lay == LAY_WIDE;
   if (!(fl->ts_hi >= fl->ts_lo) || !std::isfinite(fl->ts_lo) || !std::isfinite(fl->ts_hi) ||
       (fl->ts_lo == 0.0 && fl->ts_hi == 0.0) || !std::isfinite(epochs[0]))
     return false;
@@ -263,6 +391,8 @@ bool chi_table_plan(const rjp_fields* fl, const rjp_bursts* hb, const double* ep
   // doubles in, 16-byte aligned because n_z is even
   if (work_bytes < (size_t)2 * npix * sizeof(double) + tab_bytes || (size_t)2 * npix * 8 < tab_bytes)
     return false;
+  // (the wide scan fills all four planes of its <= 8 y-ranges: its table sits behind them)
+  if (cp.wide && work_bytes < (size_t)32 * npix * sizeof(double) + tab_bytes) return false;
   cp.ni = ni;
   cp.lo = lo;
   cp.inv_h = ni / (hi - lo);
@@ -282,14 +412,15 @@ bool chi_table_plan(const rjp_fields* fl, const rjp_bursts* hb, const double* ep
 }
 
 hipError_t chi_table_scan(const rjp_fields* fl, const ChiPlan& cp, const double* d_stage,
-                          double t_epoch, double* sumA, double* em, double* ws, size_t work_bytes,
-                          hipStream_t st) {
+                          double t_epoch, int mode, double* sumA, double* em, double* tavg,
+                          double* ws, size_t work_bytes, hipStream_t st) {
   const int64_t npix = (int64_t)fl->nx * fl->nz;
   const int64_t nchunks = npix / 2;
   const size_t tab_doubles = (size_t)2 * cp.ni * kChiStride;
   if (((uintptr_t)ws % 16) != 0 || work_bytes < (2 * npix + tab_doubles) * sizeof(double))
     return hipErrorInvalidValue;
-  double* d_tab = ws + 2 * npix;                    // plane 2 of the first y-range (see the plan)
+  // plane 2 of the first y-range (see the plan); behind the 8 x 4 planes of the wide scan
+  double* d_tab = ws + (cp.wide ? 32 : 2) * npix;
   ChiTabDev t{cp.ni, cp.lo, cp.inv_h, std::nextafter((double)cp.ni, 0.0)};
   hipLaunchKernelGGL(chi_table_kernel, dim3((unsigned)((2 * cp.ni + 255) / 256)), dim3(256), 0, st,
                      d_stage, cp.n[0], cp.n[1], t, d_tab);
@@ -299,7 +430,8 @@ hipError_t chi_table_scan(const rjp_fields* fl, const ChiPlan& cp, const double*
   // as it takes (partials reduced by ff_reduce_kernel's order: plane 0 of nacc(1) planes)
   const int64_t wgs = (nchunks + kBlock - 1) / kBlock;
   int nsplit = 1;
-  while (wgs * nsplit < RJP_TAB_WGS && nsplit * 2 * 64 <= fl->ny && nsplit < 16) nsplit *= 2;
+  while (wgs * nsplit < RJP_TAB_WGS && nsplit * 2 * 64 <= fl->ny && nsplit < (cp.wide ? 8 : 16))
+    nsplit *= 2;
   const int ylen = (fl->ny + nsplit - 1) / nsplit;
   const size_t shm = tab_doubles * sizeof(double);
   // em = sum (n x)^2 * csize*au/pc * pf  (classes.py:1116-1118)
@@ -310,6 +442,12 @@ hipError_t chi_table_scan(const rjp_fields* fl, const ChiPlan& cp, const double*
   if (e != hipSuccess) return e;
   constexpr int kMaxShm = 2 * kChiMaxNI * kChiStride * (int)sizeof(double);
   if (dev != attr_dev) {
+    e = hipFuncSetAttribute((const void*)ff_scan_table_wide_kernel<RJP_TAB_U_WIDE, 0>,
+                            hipFuncAttributeMaxDynamicSharedMemorySize, kMaxShm);
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute((const void*)ff_scan_table_wide_kernel<RJP_TAB_U_WIDE, 1>,
+                            hipFuncAttributeMaxDynamicSharedMemorySize, kMaxShm);
+    if (e != hipSuccess) return e;
     e = hipFuncSetAttribute((const void*)ff_scan_table_kernel<RJP_TAB_U, false>,
                             hipFuncAttributeMaxDynamicSharedMemorySize, kMaxShm);
     if (e != hipSuccess) return e;
@@ -318,9 +456,25 @@ hipError_t chi_table_scan(const rjp_fields* fl, const ChiPlan& cp, const double*
     if (e != hipSuccess) return e;
     attr_dev = dev;
   }
+  const dim3 grid((unsigned)(wgs * nsplit));
+  if (cp.wide) {
+    FieldPtrs<double> f{(const double*)fl->d_nd, (const double*)fl->d_xi, (const double*)fl->d_temp,
+                        (const double*)fl->d_pf, (const double*)fl->d_ts, fl->d_ylo, fl->d_yhi,
+                        nullptr, nullptr};
+    if (mode == RJP_GFF_POWERLAW)
+      hipLaunchKernelGGL((ff_scan_table_wide_kernel<RJP_TAB_U_WIDE, 1>), grid, dim3(kBlock), shm, st,
+                         f, fl->ny, fl->nz, nchunks, npix, ylen, nsplit, t, t_epoch, d_tab, ws, sumA,
+                         em, tavg, em_scale);
+    else
+      hipLaunchKernelGGL((ff_scan_table_wide_kernel<RJP_TAB_U_WIDE, 0>), grid, dim3(kBlock), shm, st,
+                         f, fl->ny, fl->nz, nchunks, npix, ylen, nsplit, t, t_epoch, d_tab, ws, sumA,
+                         em, tavg, em_scale);
+    e = hipGetLastError();
+    if (e != hipSuccess || nsplit == 1) return e;
+    return ff_reduce_launch(ws, nsplit, 1, npix, 0, em_scale, sumA, em, tavg, st);
+  }
   double* out = nsplit == 1 ? sumA : ws;
   const int64_t stride = nsplit == 1 ? 0 : (int64_t)nacc(1) * npix;
-  const dim3 grid((unsigned)(wgs * nsplit));
   if (em)
     hipLaunchKernelGGL((ff_scan_table_kernel<RJP_TAB_U_EM, true>), grid, dim3(kBlock), shm, st,
                        (const double*)fl->d_a0, (const double*)fl->d_em0, (const double*)fl->d_ts,

@@ -67,6 +67,7 @@ hipError_t ff_reduce_launch(const double* ws, int nsplit, int et, int64_t npix, 
 // ---- ff_scan_tab.hip: single-epoch tau-layout scan with the burst factor from an LDS table -----
 struct ChiPlan {
   bool ok = false;
+  bool wide = false;              // the scan reads the five model fields, not the tau layout
   int ni = 0, n[2] = {0, 0};
   double lo = 0.0, inv_h = 0.0;
   std::vector<double> stage;      // Vandermonde inverse, nodes, burst parameters
@@ -74,8 +75,8 @@ struct ChiPlan {
 bool chi_table_plan(const rjp_fields* fl, const rjp_bursts* hb, const double* epochs, int n_epochs,
                     int mode, bool want_em, size_t work_bytes, ChiPlan& cp);
 hipError_t chi_table_scan(const rjp_fields* fl, const ChiPlan& cp, const double* d_stage,
-                          double t_epoch, double* sumA, double* em, double* ws, size_t work_bytes,
-                          hipStream_t st);
+                          double t_epoch, int mode, double* sumA, double* em, double* tavg,
+                          double* ws, size_t work_bytes, hipStream_t st);
 
 // ---- ff_moments.hip: epoch sweeps by launch-time moments --------------------------------------
 #define RJP_MOM_MAX_IDX 1280      /* 2 jets x K bins x N Chebyshev moments <= this (160 KB of LDS

@@ -401,9 +401,9 @@ int rjp_ff_scan(rjp_ctx* ctx, const rjp_fields* fields, const rjp_bursts* bursts
     if (e != hipSuccess) return fail(ctx, RJP_ERR_HIP, "moments_run", e);
     return RJP_OK;
   }
-  if (d_tavg == nullptr &&
-      rjp::chi_table_plan(fields, bursts, h_epochs_s, n_epochs, gff_mode, d_em != nullptr,
-                          work_bytes, ctx->chi)) {
+  if (rjp::chi_table_plan(fields, bursts, h_epochs_s, n_epochs, gff_mode, d_em != nullptr,
+                          work_bytes, ctx->chi) &&
+      (d_tavg == nullptr || ctx->chi.wide)) {      // (T_avg with the scan: the wide kernel only)
     // single epoch on the tau layout: the burst factor from a table in LDS (ff_scan_tab.hip)
     ctx->last_path = 3;
     const double* src[1] = {ctx->chi.stage.data()};
@@ -411,7 +411,8 @@ int rjp_ff_scan(rjp_ctx* ctx, const rjp_fields* fields, const rjp_bursts* bursts
     double* dev[1];
     if (int r = stage_tables(ctx, st, src, len, 1, dev)) return r;
     return finish_staged(ctx, st, rjp::chi_table_scan(fields, ctx->chi, dev[0], h_epochs_s[0],
-                                                      d_sumA, d_em, (double*)d_work, work_bytes, st),
+                                                      gff_mode, d_sumA, d_em, d_tavg,
+                                                      (double*)d_work, work_bytes, st),
                          "chi_table_scan");
   }
   ctx->last_path = 0;

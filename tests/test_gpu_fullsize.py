@@ -323,6 +323,29 @@ def test_single_epoch_table_scan_vs_gaussians_and_oracle(eng, temp_mode, shape):
     # T_avg asked for WITH the scan: the caller is served by the ordinary kernels
     eng.ff_scan(fields, bursts, [1.0 * orc.YEAR], mode, want_em=False, want_tavg=True)
     assert eng.last_scan_path()[0] == "tiles"
+    # the five MODEL fields alone (no a0 / em0: SURVEY 8(d)'s byte model): the wide table scan
+    # gives the optical-depth sums, the EM and T_avg of the epoch in one pass
+    a0, em0 = fields.a0, fields.em0
+    fields.a0 = fields.em0 = None
+    fields.nd[m_a] = float("nan")                # (the weights' NaNs, on the wide fields)
+    w_t = [t.clone() for t in eng.ff_scan(fields, bursts, ep, mode, want_em=True, want_tavg=True)]
+    assert eng.last_scan_path()[0] == "table"
+    eng.use_chi_table = False
+    w_g = [t.clone() for t in eng.ff_scan(fields, bursts, ep, mode, want_em=True, want_tavg=True)]
+    assert eng.last_scan_path()[0] == "tiles"
+    eng.use_chi_table = True
+    eng.synchronize()
+    for got, ref in zip(w_t[:2], w_g[:2]):
+        assert torch.equal(got == 0, ref == 0)
+        ok = ref != 0
+        assert ((got - ref).abs()[ok] / ref[ok]).max().item() < 3e-12
+    assert torch.equal(torch.isnan(w_t[2]), torch.isnan(w_g[2]))
+    okt = ~torch.isnan(w_g[2])
+    assert ((w_t[2] - w_g[2]).abs()[okt] / w_g[2][okt]).max().item() < 1e-13
+    np.testing.assert_allclose(ctau[0] * w_t[0].cpu().numpy()[0, idx],
+                               jet.optical_depth_ff(5e9)[:, 0], rtol=1e-11)
+    np.testing.assert_allclose(w_t[1].cpu().numpy()[0, idx], jet.emission_measure()[:, 0], rtol=1e-11)
+    fields.a0, fields.em0 = a0, em0
 
 def torch_all_finite(t):
     import torch
