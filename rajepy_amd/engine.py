@@ -472,8 +472,10 @@ class RTEngine:
         (rjp_unmask_launch_times): the reference's burst-less jet has a constant mass-loss rate,
         so a NaN launch time does not drop its cells (classes.py:232-233, 442-448).  The copy
         is kept with the fields and rebuilt when `ts` or the flag-carrying field changes."""
-        if (bursts is not None and fields.a0 is not None and
-                ((self.use_moments and n_epochs >= 12) or (self.use_chi_table and n_epochs == 1))):
+        if bursts is not None and (
+                (self.use_moments and n_epochs >= 12 and fields.a0 is not None) or
+                (self.use_chi_table and n_epochs == 1 and fields.dtype == RJP_F64 and
+                 fields.ts is not None)):
             self.launch_time_range(fields)
         fs = fields.struct()
         if n_epochs == 1 and not self.use_chi_table:
