@@ -939,7 +939,7 @@ def main(argv=None):
         if scan_path == "table":
             # single epoch, tau layout: burst factor from a table in LDS, ONE y-range, the sums
             # written straight to the map (ff_scan_tab.hip)
-            kname = "ff_scan_table_kernel"
+            kname = "ff_scan_table_wide_kernel" if nfld == 5 else "ff_scan_table_kernel"
             roof_extra_table = {"intervals_per_jet": eng.last_moment_shape[0],
                                 "degree": eng.last_moment_shape[1] - 1,
                                 "bound_on_chi2_rel_err": mom_err}
@@ -1031,8 +1031,9 @@ def main(argv=None):
             roof_extra.update({
                 "wide_ms_per_launch": wide_ms, "layout_build_ms": build_ms,
                 "frac_8d": alg_8d / (wide_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                "frac_8d_kernel": "the wide-layout ff_scan_kernel (5 fields/cell, tau + EM + "
-                                  "T_avg sums), timed live on the same fields",
+                "frac_8d_kernel": "the wide-layout scan (5 fields/cell, tau + EM + T_avg sums; "
+                                  "path: %s), timed live on the same fields"
+                                  % eng.last_scan_path()[0],
                 "first_epoch_from_wide_fields_ms": {"scan_layout": build_ms + wl.tavg_ms + k_ms,
                                                     "wide": wide_ms}})
         elif nfld == 5:

@@ -20,7 +20,7 @@ for variant in tau2 tau3 wide5; do
     # (round 4: single-epoch scans of the tau layout take the burst factor from an LDS table)
     tau2) flags=(); kern="ff_scan_table_kernel<6, false>" ;;
     tau3) flags=(--em); kern="ff_scan_table_kernel<4, true>" ;;
-    wide5) flags=(--layout wide --em); kern="ff_scan_kernel<double, 2, 1, 0, true, false, 0, true>" ;;
+    wide5) flags=(--layout wide --em); kern="ff_scan_table_wide_kernel" ;;
   esac
   sfx="_${variant}"
   B=(python3 "$root/bench.py" "${flags[@]}")
