@@ -186,6 +186,14 @@ class RTEngine:
             self._work = torch.empty(int(nbytes), dtype=torch.uint8, device=self.device)
         return self._work
 
+    def _workspace_maps(self, nbytes):
+        """The map stages' own scratch (per-wave flux partials): a scan and a map stage of two
+        consecutive epochs may then run side by side on two streams."""
+        torch = _torch()
+        if getattr(self, "_work_m", None) is None or self._work_m.numel() < nbytes:
+            self._work_m = torch.empty(int(nbytes), dtype=torch.uint8, device=self.device)
+        return self._work_m
+
     def synchronize(self):
         _torch().cuda.synchronize(self.device)
 
@@ -617,7 +625,7 @@ class RTEngine:
         else:
             tau, flux, ftot = out
         wb = self.lib.rjp_ff_maps_workspace(P, E, F)
-        work = self._workspace(wb) if ftot is not None else None
+        work = self._workspace_maps(wb) if ftot is not None else None
         a, b = _lib.dbl_array(ctau), _lib.dbl_array(cflux)
         ptr = lambda t: t.data_ptr() if t is not None else None
         _lib.check(self.lib.rjp_ff_maps(
@@ -667,7 +675,7 @@ class RTEngine:
         flux = self._f64(F, P)
         ftot = self._f64(F) if want_ftot else None
         wb = self.lib.rjp_ff_maps_workspace(P, 1, F)
-        work = self._workspace(wb) if want_ftot else None
+        work = self._workspace_maps(wb) if want_ftot else None
         a, b = _lib.dbl_array(cflux_rrl), _lib.dbl_array(hnu_k)
         ptr = lambda t: t.data_ptr() if t is not None else None
         _lib.check(self.lib.rjp_rrl_maps(
