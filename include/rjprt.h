@@ -107,12 +107,18 @@ typedef struct rjp_fields {
    * distribution with chi^2, so ONE pass over the grid accumulates per-sightline Chebyshev
    * moments of a0 over K launch-time bins of order N -- (K, N) one of (80, 8), (53, 12), (39, 16),
    * the cheapest the host's accuracy check accepts -- and any number of epochs, uniformly spaced or
-   * not, becomes a small contraction.  The host checks the expansion against chi^2 for the call's
-   * bursts and epochs and uses the path only when every coefficient table is good to 1e-11
+   * not, becomes a small contraction.  The expansion is checked against chi^2 for the call's bursts and
+   * epochs (on the device) and the path is used only when every coefficient table is good to 1e-11
    * relative AND a cost model says it is the faster one (long, densely filled sightlines; else
    * the epoch tiles run, as before); sums are reproducible to rounding, not bit
    * for bit (LDS atomics).  A range that does not contain every finite launch time gives wrong
-   * maps: pass what rjp_field_range returned for d_ts, or zeros. */
+   * maps: pass what rjp_field_range returned for d_ts, or zeros.
+   * The same range lets SINGLE-epoch scans of large f64 maps (>= 32768 sightlines, >= 64 rows; the
+   * tau layout or the five model fields) take the burst factor chi(t - ts) from a table in LDS
+   * instead of evaluating the Gaussians per cell: piecewise polynomials of degree 7 over the
+   * times since launch that can occur, built on the device in front of the scan, bound 2e-13 on
+   * chi^2 (bursts with a negative amplitude or a table that would not fit 72 KB keep the
+   * Gaussians); maps equal to the Gaussian scan's to rounding (rjp_last_scan_path = 3). */
   double ts_lo, ts_hi;
   /* Optional hint for the choice between the epoch tiles and the moment path: the number of
    * cells inside the occupied y-ranges, sum_p max(0, d_yhi[p] - d_ylo[p]) (0 = unknown: all
