@@ -159,35 +159,61 @@ def r_tau1(r_0, w_0, n_0, chi_0, T_0, freq, inc, epsilon, q_n, q_x, q_T, opang, 
     return r / cm / dist
 
 
+class _R86Lobe:
+    """Base quantities of one lobe in cgs for the Reynolds (1986) closed forms below: jet width
+    and base distances [cm], distance to the source [cm], sin(inclination), the power-law
+    indices, and the base electron density n_0 x_0 [cm^-3].  The density carries the two
+    adjustments the reference applies -- the red lobe's mass-loss ratio and, for a disc wind
+    (q^d_n != 0), the density implied by the mass-loss rate -- in the ORDER the calling formula
+    uses in the reference (the two formulas differ there, physics.py:263-273 vs 340-345; with a
+    disc wind the second adjustment overrides the first or is scaled by it accordingly)."""
+
+    ERG_TO_JY = 1e-7 * 1e2 ** 2. / 1e-26        # erg cm^-2 s^-1 Hz^-1 -> Jy
+
+    def __init__(self, jm, which, wind_density_first):
+        par = jm.params
+        geo, laws, props = par['geometry'], par['power_laws'], par['properties']
+        cm = con.au * 1e2
+        self.width = geo['w_0'] * cm
+        self.mod_r0 = geo['mod_r_0'] * cm
+        self.r0 = geo['r_0'] * cm
+        self.dist = par['target']['dist'] * con.parsec * 1e2
+        self.sin_i = np.sin(np.radians(geo['inc']))
+        self.eps, self.q_T, self.q_tau = geo['epsilon'], laws['q_T'], laws['q_tau']
+        self.T0, self.x0 = props['T_0'], props['x_0']
+        lobe_ratio = (jm.ss_jml('R') / jm.ss_jml('B')) if which == 'R' else 1.
+
+        def wind_density():
+            mdot = props["mlr"] * 1.989e30 / con.year
+            return mdot / (np.pi * props['mu'] * atomic_mass("H") * self.width ** 2. *
+                           props["v_0"] * 1e5)
+        disc_wind = laws["q^d_n"] != 0.
+        if wind_density_first:
+            self.n0 = (wind_density() if disc_wind else props['n_0']) * lobe_ratio
+        else:
+            self.n0 = wind_density() if disc_wind else props['n_0'] * lobe_ratio
+
+    def tau_base(self, freq):
+        """Optical depth through the jet base (equation 4 of Reynolds 1986 at rho = 1)."""
+        return (2. * A_K * self.width * (self.n0 * self.x0) ** 2. * self.T0 ** -1.35 *
+                freq ** -2.1 / self.sin_i)
+
+
 def approx_flux_expected_r86(jm, freq, which):
     """Approximate total flux [Jy] of one lobe, equation 16 of Reynolds (1986)
     (physics.py:239-297); `freq` scalar, list or array [Hz]; which = 'R' or 'B'."""
-    if type(freq) == list:
-        freq = np.array(freq)
-    p = jm.params
-    g, pl, pr = p['geometry'], p['power_laws'], p['properties']
-    cm = con.au * 1e2
-    w_0 = g['w_0'] * cm
-    # physics.py:263-273: the disc-wind override comes FIRST there, the red-jet scaling after
-    if pl["q^d_n"] != 0.:
-        mlr = pr["mlr"] * 1.989e30 / con.year
-        n_0 = mlr / (np.pi * pr['mu'] * atomic_mass("H") * w_0 ** 2. * pr["v_0"] * 1e5)
-    else:
-        n_0 = pr['n_0']
-    if which == 'R':
-        n_0 = n_0 * (jm.ss_jml('R') / jm.ss_jml('B'))
-    c = (1. + g['epsilon'] + pl['q_T']) / pl['q_tau']
-    flux = 2 ** (1. - c) * (p['target']['dist'] * con.parsec * 1e2) ** -2.
-    flux *= A_J * A_K ** (-1. - c) * pr['T_0'] ** (1. + 1.35 * c)
-    flux *= g['mod_r_0'] * cm
-    flux *= w_0 ** (1. - c)
-    flux *= (n_0 * pr['x_0']) ** (-(2. * c))
-    flux *= np.sin(np.radians(g['inc'])) ** (1. + c) / \
-        (c * (1. + g['epsilon'] + pl['q_T'] + pl['q_tau']))
-    alpha = 2. + (2.1 / pl['q_tau']) * (1 + g['epsilon'] + pl['q_T'])
-    flux = flux * freq ** alpha          # erg cm^-2 s^-1 Hz^-1
-    flux = flux * (1e-7 * 1e2 ** 2.)     # W m^-2 Hz^-1
-    return flux / 1e-26
+    freq = np.asarray(freq, dtype=float) if isinstance(freq, (list, tuple)) else freq
+    lobe = _R86Lobe(jm, which, wind_density_first=True)
+    s = 1. + lobe.eps + lobe.q_T
+    c = s / lobe.q_tau
+    alpha = 2. + 2.1 * c                                  # spectral index
+    factors = (2 ** (1. - c), lobe.dist ** -2., A_J, A_K ** (-1. - c), lobe.T0 ** (1. + 1.35 * c),
+               lobe.mod_r0, lobe.width ** (1. - c), (lobe.n0 * lobe.x0) ** (-2. * c),
+               lobe.sin_i ** (1. + c) / (c * (s + lobe.q_tau)))
+    flux = 1.
+    for fac in factors:
+        flux = flux * fac
+    return flux * freq ** alpha * _R86Lobe.ERG_TO_JY
 
 
 def flux_expected_r86(jm, freq, which, y_max, y_min=None):
@@ -195,42 +221,24 @@ def flux_expected_r86(jm, freq, which, y_max, y_min=None):
     [arcsec] from the jet base, equation 8 of Reynolds (1986) (physics.py:300-374).  The
     incomplete gamma function of negative order is mpmath's, as in the reference."""
     from mpmath import gammainc
-    p = jm.params
-    g, pl, pr = p['geometry'], p['power_laws'], p['properties']
-    cm = con.au * 1e2
-    inc = g['inc']
-    w_0 = g['w_0'] * cm
-    T_0 = pr['T_0']
-    n_0 = pr['n_0']
-    if which == 'R':
-        n_0 = n_0 * (jm.ss_jml('R') / jm.ss_jml('B'))
-    x_0 = pr['x_0']
-    q_tau_, q_T, eps = pl["q_tau"], pl["q_T"], g["epsilon"]
-    mod_r_0 = g['mod_r_0'] * cm
-    mod_y_0 = mod_r_0 * np.sin(np.radians(inc))
-    y_0 = g['r_0'] * cm * np.sin(np.radians(inc))
-    d = p['target']['dist'] * con.parsec * 1e2
-    # physics.py:340-345: here the disc-wind override comes AFTER the red-jet scaling
-    if pl["q^d_n"] != 0.:
-        mlr = pr["mlr"] * 1.989e30 / con.year
-        n_0 = mlr / (np.pi * pr['mu'] * atomic_mass("H") * w_0 ** 2. * pr["v_0"] * 1e5)
-    y_max = np.tan(y_max * ARCSEC) * d + mod_y_0 - y_0
-    if y_min is not None:
-        y_min = np.tan(y_min * ARCSEC) * d + mod_y_0 - y_0
-    else:
-        y_min = mod_y_0
-    tau_0 = 2. * A_K * w_0 * (n_0 * x_0) ** 2. * T_0 ** -1.35 * freq ** -2.1 * \
-        np.sin(np.radians(inc)) ** -1.
-    c = 1. + eps + q_T
+    lobe = _R86Lobe(jm, which, wind_density_first=False)
+    y_base = lobe.mod_r0 * lobe.sin_i                     # projected |r_0|
+    shift = y_base - lobe.r0 * lobe.sin_i
 
-    def indef_integral(yval):
-        const = 2. * w_0 * d ** -2. * A_J * A_K ** -1. * T_0 * freq ** 2.
-        rho = yval / mod_y_0
-        tau = tau_0 * rho ** q_tau_
-        p1 = yval / (q_tau_ * c) * rho ** (c - 1.) * tau ** (-c / q_tau_)
-        p2 = q_tau_ * tau ** (c / q_tau_) + c * gammainc(c / q_tau_, tau)
-        return const * (float(p1) * float(p2))
+    def projected(arcsec):
+        return np.tan(arcsec * ARCSEC) * lobe.dist + shift
+    upper = projected(y_max)
+    lower = y_base if y_min is None else projected(y_min)
+    tau0 = lobe.tau_base(freq)
+    s = 1. + lobe.eps + lobe.q_T
+    k = s / lobe.q_tau
+    scale = 2. * lobe.width * lobe.dist ** -2. * A_J / A_K * lobe.T0 * freq ** 2.
 
-    flux = indef_integral(y_max) - indef_integral(y_min)
-    flux *= 1e-7 * 1e2 ** 2.
-    return flux / 1e-26
+    def primitive(y):
+        """Antiderivative of the brightness integral at projected distance y."""
+        rho = y / y_base
+        tau = tau0 * rho ** lobe.q_tau
+        head = y / (lobe.q_tau * s) * rho ** (s - 1.) * tau ** (-k)
+        tail = lobe.q_tau * tau ** k + s * gammainc(k, tau)
+        return scale * (float(head) * float(tail))
+    return (primitive(upper) - primitive(lower)) * _R86Lobe.ERG_TO_JY
