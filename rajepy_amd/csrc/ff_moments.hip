@@ -147,12 +147,15 @@ __global__ __launch_bounds__(kMomBS) void moments_kernel(const double* __restric
 
 // sumA[e][p] = sum_idx M_T[idx][p] * W[idx][e], e < ne <= 32; four moment rows in flight per
 // lane (one at a time left the loop latency-bound: 0.66 -> 0.47 ms at 512x512 sightlines x 1024)
+#ifndef RJP_EVAL_UI
+#define RJP_EVAL_UI 4
+#endif
 __global__ __launch_bounds__(256) void moments_eval_kernel(const double* __restrict__ MT,
                                                            int64_t npix, int64_t npixp, int nidx,
                                                            const double* __restrict__ W, int ne,
                                                            double scale,
                                                            double* __restrict__ sumA) {
-  constexpr int ET = RJP_MOM_TILE, UI = 4;
+  constexpr int ET = RJP_MOM_TILE, UI = RJP_EVAL_UI;
   const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (p >= npix) return;
   double acc[ET];
