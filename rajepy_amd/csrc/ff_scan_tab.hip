@@ -39,10 +39,10 @@ namespace rjp {
 #define RJP_TAB_U 6              /* rows of loads in flight per lane (same-buffer A/B at cfg4, profiles/r04_k1_table_variants.log: 6: 2.483 ms, 8: 2.513, 12: 2.516, 16: 2.529) */
 #endif
 #ifndef RJP_TAB_U_EM
-#define RJP_TAB_U_EM 4           /* ... with the EM map (three streams) */
+#define RJP_TAB_U_EM 4           /* ... with the EM map (three streams; 3 / 4 / 6 rows: 3.83 / 3.86 / 3.86 ms -- noise) */
 #endif
 #ifndef RJP_TAB_U_WIDE
-#define RJP_TAB_U_WIDE 3         /* ... from the five model fields (five streams) */
+#define RJP_TAB_U_WIDE 4         /* ... from the five model fields (five streams; 2 / 3 / 4 rows: 6.229 / 6.230 / 6.187 ms) */
 #endif
 #ifndef RJP_TAB_WGS
 #define RJP_TAB_WGS 512          /* y-ranges are added until this many workgroups exist (1024 / 2048 at cfg4: 2.518 / 2.524 ms) */

@@ -14,6 +14,7 @@ import numpy as np
 import bench
 from rajepy_amd import _lib, engine as E
 
+MODE = os.environ.get("AB_MODE", "tau")        # tau | em (a0, em0, ts) | wide (five model fields)
 libs = [("default", None)] + [(os.path.basename(p), os.path.abspath(p)) for p in sys.argv[1:]]
 eng = E.RTEngine(0)
 handles = []
@@ -29,8 +30,10 @@ for name, path in libs:
     assert lb.rjp_ctx_create(0, C.byref(ctx)) == 0
     handles.append((name, lb, ctx))
 shape = bench.CONFIGS["cfg4"][0]
-fields = eng.synth_fields(shape, 20240504, 0, E.RJP_F64, csize_au=0.5, wide=False,
+fields = eng.synth_fields(shape, 20240504, 0, E.RJP_F64, csize_au=0.5, wide=(MODE == "wide"),
                           tau_mode=E.RJP_GFF_SCALAR)
+if MODE == "wide":
+    fields.a0 = fields.em0 = None
 ej = bench.EXAMPLE_BURSTS
 red, blue = [], []
 for t0, hl, chi, which in zip(ej["t_0"], ej["hl"], ej["chi"], ej["which"]):
@@ -45,14 +48,19 @@ fs_gau = fields.struct()
 fs_gau.ts_lo = fs_gau.ts_hi = 0.0
 nx, ny, nz = shape
 sumA = eng._f64(1, fields.npix)
+emap = eng._f64(1, fields.npix) if MODE != "tau" else None
+tavg = eng._f64(fields.npix) if MODE == "wide" else None
+ptr = lambda t: t.data_ptr() if t is not None else None
+nfld = {"tau": 2, "em": 3, "wide": 5}[MODE]
 work = eng._workspace(eng.lib.rjp_ff_scan_workspace(nx, ny, nz, 1))
 epa = _lib.dbl_array([1.0 * bench.YEAR])
 
 
 def time(lib, ctx, fs, reps=20):
     ms = C.c_double()
-    st = lib.rjp_time_ff_scan(ctx, C.byref(fs), C.byref(bursts), epa, 1, 0, sumA.data_ptr(), None,
-                              None, work.data_ptr(), work.numel(), eng._stream(), reps, C.byref(ms))
+    st = lib.rjp_time_ff_scan(ctx, C.byref(fs), C.byref(bursts), epa, 1, 0, sumA.data_ptr(),
+                              ptr(emap), ptr(tavg), work.data_ptr(), work.numel(), eng._stream(),
+                              reps, C.byref(ms))
     assert st == 0, lib.rjp_last_error(ctx)
     return ms.value
 
@@ -67,4 +75,4 @@ for _ in range(5):
 for k, v in rows.items():
     v = np.array(v)
     print("%-28s mean %.4f ms  min %.4f ms  (%.3f of 8 TB/s)" % (
-        k, v.mean(), v.min(), 16.0 * nx * ny * nz / (v.min() * 1e-3) / 8e12))
+        k, v.mean(), v.min(), 8.0 * nfld * nx * ny * nz / (v.min() * 1e-3) / 8e12))
