@@ -199,8 +199,15 @@ hipError_t lt_fill_launch(const rjp_fields* fl, int K, const int32_t* d_rowoff, 
 // ---- the sweep ----------------------------------------------------------------------------------
 __device__ __forceinline__ rjp_d2 lt_load(const rjp_d2* p) { return __builtin_nontemporal_load(p); }
 
+#ifndef RJP_LT_WAVES
+#define RJP_LT_WAVES 32768      /* key ranges are split until about this many waves exist */
+#endif
+#ifndef RJP_LT_OCC
+#define RJP_LT_OCC 1            /* minimum waves per SIMD asked of the register allocator */
+#endif
 template <int N>
-__global__ __launch_bounds__(64) void lt_moments_kernel(const rjp_d2* __restrict__ cells,
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RJP_LT_OCC)))
+void lt_moments_kernel(const rjp_d2* __restrict__ cells,
                                                         const int32_t* __restrict__ off, LtBins b,
                                                         int nsplit, const double* __restrict__ W,
                                                         int64_t npixp, double* __restrict__ part) {
@@ -307,7 +314,7 @@ hipError_t lt_run(const rjp_fields* fl, const MomPlan& mp, int n_epochs, double*
   const LtBins b{mp.s0, mp.inv_h, mp.K};
   // enough waves for ~128 per CU (measured: 8 key ranges per group at cfg5's size); never finer than two keys per wave, and the partial sums
   // (nsplit x 32 planes) stay inside the moment paths' workspace (1280 planes)
-  int nsplit = (int)std::min<int64_t>(std::max<int64_t>(1, (32768 + G - 1) / G), mp.K);
+  int nsplit = (int)std::min<int64_t>(std::max<int64_t>(1, (RJP_LT_WAVES + G - 1) / G), mp.K);
   nsplit = std::min(nsplit, RJP_MOM_MAX_IDX / RJP_MOM_TILE);
   hipError_t err = hipErrorInvalidValue;
   switch (mp.N) {

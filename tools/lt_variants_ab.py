@@ -1,0 +1,68 @@
+#!/usr/bin/env python3
+"""A/B of builds on cfg5's 32-epoch sweep over ONE launch-time-ordered layout (built once by the
+default build), same buffers, one process.   python tools/lt_variants_ab.py lib1.so [...]"""
+import ctypes as C
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+
+import bench
+from rajepy_amd import _lib, engine as E
+
+libs = [("default", None)] + [(os.path.basename(p), os.path.abspath(p)) for p in sys.argv[1:]]
+eng = E.RTEngine(0)
+handles = []
+for name, path in libs:
+    if path is None:
+        handles.append((name, eng.lib, eng.ctx))
+        continue
+    lb = C.CDLL(path)
+    for fn_name, (res, args) in _lib.SIGNATURES.items():
+        fn = getattr(lb, fn_name)
+        fn.restype, fn.argtypes = res, args
+    ctx = C.c_void_p()
+    assert lb.rjp_ctx_create(0, C.byref(ctx)) == 0
+    handles.append((name, lb, ctx))
+shape = bench.CONFIGS["cfg5"][0]
+fields = eng.synth_fields(shape, 20240504, 0, E.RJP_F64, csize_au=0.5, wide=False,
+                          tau_mode=E.RJP_GFF_SCALAR)
+ej = bench.EXAMPLE_BURSTS
+red, blue = [], []
+for t0, hl, chi, which in zip(ej["t_0"], ej["hl"], ej["chi"], ej["which"]):
+    sig = hl * bench.YEAR * 2. / (2. * np.sqrt(2. * np.log(2.)))
+    for jet, lst in (("R", red), ("B", blue)):
+        if jet in str(which):
+            lst.append((t0 * bench.YEAR, chi - 1., sig))
+bursts = E.make_bursts(red, blue)
+info = eng.build_lt(fields, int(os.environ.get("AB_K", "32")))
+nx, ny, nz = shape
+ep = [float(t) for t in np.linspace(0., 5., 32) * bench.YEAR]
+epa = _lib.dbl_array(ep)
+sumA = eng._f64(32, fields.npix)
+work = eng._workspace(eng.lib.rjp_ff_scan_workspace(nx, ny, nz, 32))
+fs = fields.struct()
+assert fs.d_lt_cells
+
+
+def time(lib, ctx, reps=20):
+    ms = C.c_double()
+    st = lib.rjp_time_ff_scan(ctx, C.byref(fs), C.byref(bursts), epa, 32, 0, sumA.data_ptr(), None,
+                              None, work.data_ptr(), work.numel(), eng._stream(), reps, C.byref(ms))
+    assert st == 0, lib.rjp_last_error(ctx)
+    return ms.value
+
+
+rows = {name: [] for name, _, _ in handles}
+for name, lb, ctx in handles:
+    time(lb, ctx, 2)
+    assert lb.rjp_last_scan_path(ctx, None, None) == 2
+for _ in range(5):
+    for name, lb, ctx in handles:
+        rows[name].append(time(lb, ctx))
+print("layout K=%d rows=%d padding %.3f" % (info["K"], info["rows"], info["rows"] * 64 / fields.ncells))
+for k, v in rows.items():
+    v = np.array(v)
+    print("%-28s sweep (pass + reduction): mean %.4f ms  min %.4f ms" % (k, v.mean(), v.min()))
