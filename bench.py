@@ -966,7 +966,7 @@ def main(argv=None):
                       "fp64_vector_peak_lane_ops_per_s": 256 * 4 * 16 * 2.4e9}
     else:
         want_em = wl.em is not None
-        k_ms = eng.time_ff_scan(fields, wl.bursts, wl.my_epochs, wl.gmode, reps=5,
+        k_ms = eng.time_ff_scan(fields, wl.bursts, wl.my_epochs, wl.gmode, reps=5 if n_ep_cfg else 30,
                                 want_em=want_em, want_tavg=False)
         # epoch tiles share a pass over the grid: 32 uniformly spaced epochs, 16 below that,
         # else 8 (f64 lanes) or 4 (f32 lanes)
