@@ -397,12 +397,15 @@ bool chi_table_plan(const rjp_fields* fl, const rjp_bursts* hb, const double* ep
   cp.lo = lo;
   cp.inv_h = ni / (hi - lo);
   cp.n[0] = hb->n[0]; cp.n[1] = hb->n[1];
-  static double xs[kChiNC], vinv[kChiNC][kChiNC];
-  static bool have = false;
-  if (!have) { chi_nodes(xs, vinv); have = true; }
+  struct Nodes {
+    double xs[kChiNC], vinv[kChiNC][kChiNC];
+    Nodes() { chi_nodes(xs, vinv); }
+  };
+  static const Nodes nodes;                       // (initialised once, thread-safely)
   cp.stage.clear();
-  for (int c = 0; c < kChiNC; ++c) for (int m = 0; m < kChiNC; ++m) cp.stage.push_back(vinv[c][m]);
-  for (int m = 0; m < kChiNC; ++m) cp.stage.push_back(xs[m]);
+  for (int c = 0; c < kChiNC; ++c)
+    for (int m = 0; m < kChiNC; ++m) cp.stage.push_back(nodes.vinv[c][m]);
+  for (int m = 0; m < kChiNC; ++m) cp.stage.push_back(nodes.xs[m]);
   for (int j = 0; j < 2; ++j)
     for (int k = 0; k < 3; ++k)
       for (int i = 0; i < hb->n[j]; ++i)

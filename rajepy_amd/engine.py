@@ -571,7 +571,10 @@ class RTEngine:
                 # the first sweep on this path: reserve the buffer, the next one fills it
                 nx, _, nz = fields.shape
                 nbytes = self.lib.rjp_moment_cache_bytes(nx, nz)
-                buf = _torch().empty(nbytes // 8, dtype=_torch().float64, device=self.device)
+                try:
+                    buf = _torch().empty(nbytes // 8, dtype=_torch().float64, device=self.device)
+                except RuntimeError:              # no room for it: sweeps keep their pass
+                    return
                 fields.mom_cache = {"buf": buf, "K": 0, "N": 0, "key": key}
             else:
                 mc["K"], mc["N"] = self.last_moment_shape
