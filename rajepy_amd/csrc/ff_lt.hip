@@ -275,7 +275,7 @@ void lt_moments_kernel(const rjp_d2* __restrict__ cells,
       issue(B, r + 4 * C); step(D, r + 2 * C);
     }
   }
-  for (; q < q1; ++q) flush();                         // the last bin (and empty ones after it)
+  if (q < q1) flush();                                 // the last bin (empty ones after it add nothing)
   const int64_t p = (int64_t)g * kLtLanes + lane;
 #pragma unroll
   for (int e = 0; e < ET; ++e) part[((int64_t)sp * ET + e) * npixp + p] = acc[e];
@@ -312,8 +312,9 @@ hipError_t lt_run(const rjp_fields* fl, const MomPlan& mp, int n_epochs, double*
   const int64_t npix = (int64_t)fl->nx * fl->nz;
   const int64_t G = (npix + kLtLanes - 1) / kLtLanes, npixp = G * kLtLanes;
   const LtBins b{mp.s0, mp.inv_h, mp.K};
-  // enough waves for ~128 per CU (measured: 8 key ranges per group at cfg5's size); never finer than two keys per wave, and the partial sums
-  // (nsplit x 32 planes) stay inside the moment paths' workspace (1280 planes)
+  // enough waves for ~128 per CU (measured: 8 key ranges per group at cfg5's size); never finer
+  // than two keys per wave, and the partial sums (nsplit x 32 planes) stay inside the moment
+  // paths' workspace (1280 planes)
   int nsplit = (int)std::min<int64_t>(std::max<int64_t>(1, (RJP_LT_WAVES + G - 1) / G), mp.K);
   nsplit = std::min(nsplit, RJP_MOM_MAX_IDX / RJP_MOM_TILE);
   hipError_t err = hipErrorInvalidValue;
