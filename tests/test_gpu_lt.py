@@ -280,3 +280,51 @@ def test_jetmodel_light_curves_on_the_prepared_layout(eng, tmp_path):
     np.testing.assert_allclose(lc, lc2, rtol=RTOL)
     jm.ts = jm.ts * 1.0 + 0.0                      # the setter: a new launch-time tensor
     assert jm.device_fields.struct().d_lt_cells is None
+
+
+def test_mixed_jet_sightlines_on_every_sweep_path(eng):
+    """Sightlines that cross BOTH lobes (a real, inclined jet: the red / blue flag changes along
+    y; the synthetic set has one jet per sightline): the layout keys its buckets by (jet, bin),
+    the LDS moments index their table by jet, the table scan picks the jet's half per cell --
+    every path against the oracle, whose chi_xyz selects the lobe per cell (classes.py:866-875)."""
+    from rajepy_amd import engine as E
+    from rajepy_amd.maths import physics as ph
+    shape = (3, 150, 40)
+    g, p = _jet(shape, 2718)
+    rng = np.random.default_rng(5)
+    g["rr"] = np.where(rng.random(shape) < 0.45, -1.0, 1.0)        # lobe per CELL
+    jet = _oracle(p, g)
+    f = _upload(eng, g, jet.csize, E.RJP_GFF_SCALAR)
+    eng.build_lt(f, 24)
+    bursts = U.bursts_from_oracle(jet)
+    ep = [y * orc.YEAR for y in np.linspace(0.2, 4.6, 20)]
+    a, b, c, (path, _), pb, _ = _three(eng, f, bursts, ep, E.RJP_GFF_SCALAR)
+    assert path == "lt" and pb == "moments"
+    np.testing.assert_allclose(a, c, rtol=RTOL)
+    np.testing.assert_allclose(b, c, rtol=RTOL)
+    ctau, _ = E.ff_channel_coeffs([5e9], jet.csize, p["target"]["dist"], E.RJP_GFF_SCALAR,
+                                  [ph.gff(5e9, p["properties"]["T_0"])])
+    for e in (0, 9, 19):
+        jet.time = ep[e]
+        np.testing.assert_allclose(ctau[0] * a[e].reshape(shape[0], shape[2]),
+                                   jet.optical_depth_ff(5e9), rtol=1e-10)
+    # the single-epoch table scan on a map large enough for it, lobes mixed the same way
+    big = (64, 80, 512)
+    f2 = eng.synth_fields(big, 99, 0, 8, csize_au=0.5, tau_mode=0)
+    import torch
+    gen = torch.Generator(device=eng.device)
+    gen.manual_seed(3)
+    flip = torch.rand(f2.ncells, device=eng.device, generator=gen) < 0.5
+    for t in (f2.a0, f2.em0, f2.nd):
+        t[flip] = -t[flip]                                           # the flag lives in the sign bit
+    for ep1 in ([1.0 * orc.YEAR], [2.4 * orc.YEAR]):
+        eng.use_chi_table = True
+        tab = eng.ff_scan(f2, bursts, ep1, 0, want_em=True, want_tavg=False)
+        assert eng.last_scan_path()[0] == "table"
+        tab = [t.clone() for t in tab[:2]]
+        eng.use_chi_table = False
+        ref = eng.ff_scan(f2, bursts, ep1, 0, want_em=True, want_tavg=False)
+        eng.use_chi_table = True
+        eng.synchronize()
+        for got, want in zip(tab, ref[:2]):
+            assert ((got - want).abs() / want).max().item() < 3e-12
