@@ -146,7 +146,9 @@ __global__ __launch_bounds__(kMomBS) void moments_kernel(const double* __restric
 }
 
 // sumA[e][p] = sum_idx M_T[idx][p] * W[idx][e], e < ne <= 32; four moment rows in flight per
-// lane (one at a time left the loop latency-bound: 0.66 -> 0.47 ms at 512x512 sightlines x 1024)
+// lane (one at a time left the loop latency-bound: 0.66 -> 0.47 ms at 512x512 sightlines x 1024;
+// round 4, same-buffer A/B on cfg5's 1272 rows: 2 / 4 / 8 / 12 rows 0.80 / 0.58 / 0.64 / 0.74 ms, two
+// register sets in ping-pong 0.89-1.07 ms: four plain rows stay)
 #ifndef RJP_EVAL_UI
 #define RJP_EVAL_UI 4
 #endif
