@@ -21,6 +21,7 @@ def eng():
     from rajepy_amd.engine import RTEngine
     e = RTEngine(0)
     e.force_moments = True         # sweeps of >= 12 epochs on grids this small: the moment path
+    e.cache_moments = False        # (every sweep here is meant to run its own pass)
     yield e
     e.close()
 
@@ -122,6 +123,18 @@ def test_random_models_match_the_oracle_on_every_layout(eng, seed):
         ok = _t != 0
         assert np.array_equal(_m == 0, _t == 0)
         np.testing.assert_allclose(_m[ok], _t[ok], rtol=6e-11)
+        # ... and, for sweeps it can serve (<= 32 epochs), on the launch-time-ordered layout with
+        # a random bin count: NaN cells in every field, dips, bursts in one jet only -- whatever
+        # path the library then takes (the layout when some order <= 32 passes its check)
+        if len(ep) <= 32 and eng.launch_time_range(f) is not None:
+            eng.build_lt(f, int(rng.integers(6, 41)))
+            lt, _, _ = eng.ff_scan(f, bursts, ep, mode, want_em=False, want_tavg=False)
+            eng.synchronize()
+            assert eng.last_scan_path()[0] in ("lt", "moments", "tiles")
+            _l = lt.cpu().numpy()
+            assert np.array_equal(_l == 0, _t == 0)
+            np.testing.assert_allclose(_l[ok], _t[ok], rtol=6e-11)
+            f.lt = None
 
 
 @pytest.mark.parametrize("seed", list(range(14)))
