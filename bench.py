@@ -679,11 +679,11 @@ def measure_other_configs(eng, args, torch):
                    "sweeps_to_amortise_the_build": info["build_ms"] /
                    max(1e-9, lds["ms_per_step"] - lt["ms_per_step"])})
         # a model swept again and again (other epochs, other burst parameters): the moment maps of
-        # a0 are model state -- with the engine's cache on, the third sweep onwards is the
+        # a0 are model state -- with the engine's cache on, the second sweep onwards is the
         # contraction + the light-curve kernel alone (NOT a pass over the grid: never `value`)
         w.fields.lt = None
         eng.cache_moments = True
-        for _ in range(3):
+        for _ in range(2):
             w.local_step()
         cached_path = eng.last_scan_path()[0]
         cached_ms = wall(w.local_step, 20, 0)
@@ -747,7 +747,7 @@ def measure_other_configs(eng, args, torch):
               "lds_moments": lds, "lt_layout": lt, "fresh_model_to_first_light_curve": fresh,
               "repeat_sweep_with_cached_moment_maps": {
                   "scan_path": cached_path, "ms_per_sweep": cached_ms,
-                  "what": "third and later sweeps of ONE model with RTEngine.cache_moments (the "
+                  "what": "second and later sweeps of ONE model with RTEngine.cache_moments (the "
                           "default of the Python layer): contraction of the kept moment maps "
                           "(2.7 GB) + light-curve kernel; no pass over the grid, so this is a "
                           "property of the workload, not a kernel figure"},

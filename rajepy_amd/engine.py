@@ -152,7 +152,7 @@ class RTEngine:
         # LDS (ff_scan_tab.hip; needs the launch-time range); False: always the Gaussians
         self.use_chi_table = True
         # keep the launch-time moment maps of a model that is swept repeatedly (2.7 GB at
-        # 512 x 512 sightlines): from the third long sweep on only the contraction runs
+        # 512 x 512 sightlines): from the second long sweep on only the contraction runs
         self.cache_moments = True
         self.last_moment_shape = (0, 0)
 
@@ -543,11 +543,12 @@ class RTEngine:
         return sumA, em, tavg
 
     def _attach_moment_cache(self, fields, bursts, fs, n_epochs, want_em):
-        """The caller-kept moment maps of include/rjprt.h `rjp_fields.d_mom_cache`.  A model's
-        first long sweep runs as before; once a sweep HAS taken the LDS moment path the buffer is
-        allocated, the next sweep's pass fills it, and every later sweep of the same fields (same
-        launch times, same set of jets with bursts) is the contraction alone.  Returns the key
-        the cache would be valid for (None: this scan cannot use one)."""
+        """The caller-kept moment maps of include/rjprt.h `rjp_fields.d_mom_cache`.  A long sweep
+        of a densely filled model gets the buffer at once: its own pass fills it, and every later
+        sweep of the same fields (same launch times, same set of jets with bursts) is the
+        contraction alone; a sparse model -- whose sweeps the library's cost model keeps on the
+        epoch tiles -- reserves it only after a sweep HAS taken the moment path.  Returns the
+        key the cache would be valid for (None: this scan cannot use one)."""
         if not (self.cache_moments and self.use_moments and n_epochs >= 12 and not want_em and
                 bursts is not None and fields.a0 is not None and fields.ts is not None and
                 fs.ts_lo != fs.ts_hi):
@@ -555,6 +556,9 @@ class RTEngine:
         key = (fields.a0.data_ptr(), fs.d_ts, fs.ts_lo, fs.ts_hi, int(bursts.n[0]) > 0,
                int(bursts.n[1]) > 0)
         mc = fields.mom_cache
+        if mc is None and (fields.ylo is None or
+                           2 * int(fields.occupied_cells) >= fields.ncells):
+            mc = self._reserve_moment_cache(fields, key)
         if mc is not None and mc.get("buf") is not None:
             if mc["key"] != key:
                 mc["K"] = mc["N"] = 0
@@ -563,24 +567,32 @@ class RTEngine:
             fs.mom_cache_K, fs.mom_cache_N = mc["K"], mc["N"]
         return key
 
+    def _reserve_moment_cache(self, fields, key):
+        nx, _, nz = fields.shape
+        nbytes = self.lib.rjp_moment_cache_bytes(nx, nz)
+        try:
+            buf = _torch().empty(nbytes // 8, dtype=_torch().float64, device=self.device)
+        except RuntimeError:                      # no room for it: sweeps keep their pass
+            return None
+        fields.mom_cache = {"buf": buf, "K": 0, "N": 0, "key": key}
+        return fields.mom_cache
+
     def _note_moment_sweep(self, fields, key):
         path = self.last_scan_path()[0]
         mc = fields.mom_cache
         if path in ("moments", "cached"):
             if mc is None or mc.get("buf") is None:
-                # the first sweep on this path: reserve the buffer, the next one fills it
-                nx, _, nz = fields.shape
-                nbytes = self.lib.rjp_moment_cache_bytes(nx, nz)
-                try:
-                    buf = _torch().empty(nbytes // 8, dtype=_torch().float64, device=self.device)
-                except RuntimeError:              # no room for it: sweeps keep their pass
-                    return
-                fields.mom_cache = {"buf": buf, "K": 0, "N": 0, "key": key}
+                self._reserve_moment_cache(fields, key)       # the next sweep fills it
             else:
-                mc["K"], mc["N"] = self.last_moment_shape
+                mc["K"], mc["N"] = self.last_moment_shape     # this sweep's pass filled it
                 mc["key"] = key
         elif mc is not None:
-            mc["K"] = mc["N"] = 0                 # (another path ran: the buffer was not refreshed)
+            # another path ran (tiles, the launch-time-ordered layout): nothing was written; a
+            # buffer that has never held moments is given back
+            if mc["K"] == 0:
+                fields.mom_cache = None
+            else:
+                mc["K"] = mc["N"] = 0
 
     def last_scan_path(self):
         """('tiles' | 'moments' | 'lt' | 'table', worst relative error of the expansion) of the

@@ -282,7 +282,7 @@ def test_replacing_the_launch_times_remeasures_their_range(eng):
 def test_cached_moment_maps_serve_further_sweeps_without_a_pass_over_the_grid(eng):
     """rjp_fields.d_mom_cache: the moment maps of a0 depend on the fields, the launch-time range,
     the shape and on which jets have bursts -- not on epochs or burst parameters.  The first long
-    sweep of a model runs as before, the second fills the caller-kept buffer, every later one --
+    sweep of a densely filled model fills the caller-kept buffer, every later one --
     other epochs, other burst parameters -- is the contraction alone and equals the uncached
     result to rounding (same maps, same tables); a different SET of jets with bursts, replaced
     launch times or a sweep that needs another shape refill it."""
@@ -299,9 +299,10 @@ def test_cached_moment_maps_serve_further_sweeps_without_a_pass_over_the_grid(en
     ep2 = [y * yr for y in np.linspace(0.2, 4.4, 17)]
     eng.cache_moments = True
     try:
-        a1 = sweep(bursts, ep1)
-        assert eng.last_scan_path()[0] == "moments" and f.mom_cache["K"] == 0
-        a2 = sweep(bursts, ep1)                                   # fills the buffer
+        eng.cache_moments = False
+        a1 = sweep(bursts, ep1)                                   # reference: no cache anywhere
+        eng.cache_moments = True
+        a2 = sweep(bursts, ep1)                                   # a dense model: fills at once
         assert eng.last_scan_path()[0] == "moments" and (f.mom_cache["K"], f.mom_cache["N"]) == (53, 12)
         a3 = sweep(bursts, ep1)
         assert eng.last_scan_path()[0] == "cached"
@@ -325,6 +326,21 @@ def test_cached_moment_maps_serve_further_sweeps_without_a_pass_over_the_grid(en
         assert eng.last_scan_path()[0] == "moments"
         sweep(one, ep2)
         assert eng.last_scan_path()[0] == "cached"
+        # a sparse model (occupied y-ranges, < half of the grid): the buffer comes only after a
+        # sweep has taken the moment path
+        g3 = {k: v.copy() for k, v in g.items()}
+        g3["nd"][:, 40:, :] = np.nan
+        g3["temp"][:, 40:, :] = np.nan
+        f3 = eng.upload_fields(g3["nd"], g3["xi"], g3["temp"], g3["ff"], g3["areas"], g3["ts"],
+                               g3["rr"] < 0, csize_au=jet.csize, dtype=8)
+        eng.tau_layout(f3, E.RJP_GFF_SCALAR)
+        eng.compute_y_bounds(f3)
+        eng.ff_scan(f3, bursts, ep1, 0, want_em=False, want_tavg=False)
+        assert eng.last_scan_path()[0] == "moments" and f3.mom_cache["K"] == 0     # reserved
+        eng.ff_scan(f3, bursts, ep1, 0, want_em=False, want_tavg=False)
+        assert f3.mom_cache["K"] == 53
+        eng.ff_scan(f3, bursts, ep1, 0, want_em=False, want_tavg=False)
+        assert eng.last_scan_path()[0] == "cached"
         # narrower bursts need another shape: the pass runs again into the buffer
         ej = U.example_bursts_params()
         ej["hl"] = np.asarray(ej["hl"], float) * 0.8
@@ -332,6 +348,7 @@ def test_cached_moment_maps_serve_further_sweeps_without_a_pass_over_the_grid(en
         nb = U.bursts_from_oracle(jet2)
         n1 = sweep(nb, ep1)
         assert eng.last_scan_path()[0] == "moments" and eng.last_moment_shape == (39, 16)
+        assert (f.mom_cache["K"], f.mom_cache["N"]) == (39, 16)
         n2 = sweep(nb, ep1)
         assert eng.last_scan_path()[0] == "cached"
         np.testing.assert_allclose(n2.cpu().numpy(), n1.cpu().numpy(), rtol=1e-12)
