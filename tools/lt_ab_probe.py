@@ -20,6 +20,7 @@ YEAR = 31536000.0
 def main():
     Ks = [int(a) for a in sys.argv[1:]] or [32]
     eng = E.RTEngine(0)
+    eng.cache_moments = False      # every sweep here runs its own pass over the grid
     shape = (512, 4096, 512)
     f = eng.synth_fields(shape, bench.SEED, 0, E.RJP_F64, csize_au=0.5, wide=False,
                          tau_mode=E.RJP_GFF_SCALAR)

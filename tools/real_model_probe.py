@@ -45,6 +45,7 @@ for inc in (90., 60., 30.):
     rec = {"inc": inc, "grid": [jm.nx, jm.ny, jm.nz], "cells": jm.nx * jm.ny * jm.nz,
            "construct_ms": (time.perf_counter() - t0) * 1e3}
     eng = jm.engine
+    eng.cache_moments = False
     rec["occupied_cells"] = int(dev.occupied_cells) if dev.occupied_cells is not None else None
     lo, hi = eng.launch_time_range(dev)
     rec["ts_range_yr"] = [lo / YEAR, hi / YEAR]
