@@ -690,7 +690,10 @@ def measure_other_configs(eng, args, torch):
         eng.cache_moments = False
         w.fields.mom_cache = None
         w.release()
-        torch.cuda.empty_cache()
+        # (no empty_cache() here: giving ~100 GB back to the driver makes the NEXT allocation
+        # wait seconds for the frees -- tools/alloc_probe.py: ten 8.6 GB buffers take 0.25 s in
+        # a fresh process and 2.7 s right after an empty_cache(); the model below reuses the
+        # blocks PyTorch's allocator kept)
         # a FRESH model to its first light curve: the reference's example jet on a
         # 512x4096x512 grid of the same physical box, JetModel() -- K4 builds the fields on the
         # GPU -- then flux_vs_time(32 epochs, 64 channels).  A real jet fills ~1 % of its grid:
@@ -727,9 +730,9 @@ def measure_other_configs(eng, args, torch):
             fresh = {"model": "files/example-model-params.py jet on 512x4096x512 (cell size / %.2f)"
                               % scale,
                      "construct_ms": (t1 - t0) * 1e3,
-                     "construct_note": "JetModel() to resident fields: K4, y-ranges, scan fields -- "
-                                       "and the allocation of ~90 GB of device memory, which "
-                                       "dominates after the earlier legs' buffers were freed",
+                     "construct_note": "JetModel() to resident fields: ten 8.6 GB arrays (taken from "
+                                       "PyTorch's cached blocks here; 0.25 s from the driver in "
+                                       "a fresh process), K4, occupied y-ranges",
                      "first_light_curve_ms": (t2 - t1) * 1e3,
                      "second_light_curve_ms": (t3 - t2) * 1e3,
                      "scan_path": eng.last_scan_path()[0],
