@@ -573,12 +573,16 @@ class Workload:
     def step(self):
         return collect(self.local_step(), self.pl, self.rank, self.world, self.args.backend)
 
-    def release(self):
+    def release(self, to_driver=True):
+        """Drop this workload's device buffers; `to_driver=False` leaves them in PyTorch's
+        allocator cache (the next allocations reuse them instead of waiting for the driver)."""
         if self.fields is not None:
             self.fields.lt = None
+            self.fields.mom_cache = None
         self.fields = self._em0 = self.sumA = self.em = self.tau = self.flux = None
-        import torch
-        torch.cuda.empty_cache()
+        if to_driver:
+            import torch
+            torch.cuda.empty_cache()
 
 
 # ---------------------------------------------------------------------------------------
@@ -689,7 +693,7 @@ def measure_other_configs(eng, args, torch):
         cached_ms = wall(w.local_step, 20, 0)
         eng.cache_moments = False
         w.fields.mom_cache = None
-        w.release()
+        w.release(to_driver=False)
         # (no empty_cache() here: giving ~100 GB back to the driver makes the NEXT allocation
         # wait seconds for the frees -- tools/alloc_probe.py: ten 8.6 GB buffers take 0.25 s in
         # a fresh process and 2.7 s right after an empty_cache(); the model below reuses the
