@@ -279,15 +279,18 @@ __global__ __launch_bounds__(kBlock) void ff_ftot_kernel(
     double A[VEC], ta[VEC];
     load_plain(sumA + (int64_t)e * npix + p, A);
     load_plain(tavg + p, ta);
+    // nansum, hoisted: a flux is NaN exactly where T_avg is (an empty sightline; the sums A and
+    // 1 - e^-tau are never NaN) -- such a pixel adds zero to every channel, so its T_avg is
+    // zeroed ONCE and the channel loop is one multiply and one FMA around 1 - e^-tau
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) ta[v] = ta[v] == ta[v] ? ta[v] : 0.0;
 #pragma unroll
     for (int j = 0; j < kFtotFC; ++j) {
       if (j < nf) {
         const double ct = ctau[f0 + j], cf = cflux[f0 + j];
 #pragma unroll
-        for (int v = 0; v < VEC; ++v) {
-          const double s = cf * (ta[v] * one_minus_exp_neg(ct * A[v]));
-          acc[j] += s == s ? s : 0.0;              // nansum
-        }
+        for (int v = 0; v < VEC; ++v)
+          acc[j] = __builtin_fma(cf * ta[v], one_minus_exp_neg(ct * A[v]), acc[j]);
       }
     }
   }
