@@ -504,7 +504,7 @@ class Workload:
         # the launch-time-ordered layout (epoch sweeps): per-model state, built once
         self.lt_info = None
         if (args.lt if lt is None else lt) and pl["n_ep_cfg"] and self.fields.a0 is not None:
-            info = eng.build_lt(self.fields, 32)
+            info = eng.build_lt(self.fields, 20)
             self.lt_info = {k: info[k] for k in ("K", "rows", "build_ms",
                                                  "build_with_allocation_ms", "bytes")}
             self.lt_info["padding"] = info["rows"] * 64 / float(self.ncell_loc)
@@ -674,7 +674,7 @@ def measure_other_configs(eng, args, torch):
         first_ever = (time.perf_counter() - t0) * 1e3
         lds = leg()
         lds["first_call_in_this_process_ms"] = first_ever  # + the kernels' code objects
-        info = eng.build_lt(w.fields, 32)
+        info = eng.build_lt(w.fields, 20)
         lt = leg()
         lt.update({"layout_build_ms": info["build_ms"],
                    "layout_build_with_allocation_ms": info["build_with_allocation_ms"],

@@ -639,7 +639,7 @@ class JetModel:
         return parallel.sweep_flux_vs_time(self, np.atleast_1d(np.asarray(times_s, float)),
                                            freq, rank=rank, world=world)
 
-    def prepare_epoch_sweeps(self, bins=32):
+    def prepare_epoch_sweeps(self, bins=20):
         """Optional, for a model whose light curves are computed MANY times (e.g. while fitting
         burst parameters): bucket the cells of every sightline by (jet, launch-time bin) once
         (`RTEngine.build_lt`, ~50 ms and ~1.2 x the bytes of two fields for 1e9 cells).  Sweeps of

@@ -298,14 +298,17 @@ class RTEngine:
         fields._ts_range_of = fields.ts.data_ptr()
         return fields.ts_range
 
-    def build_lt(self, fields, K=32):
+    def build_lt(self, fields, K=20):
         """Attach the launch-time-ordered layout of (a0, ts) to `fields` (rjp_lt_count +
         rjp_lt_fill; include/rjprt.h `rjp_fields.d_lt_cells`): every group of 64 sightlines
         bucketed by (jet, launch-time bin), so that epoch sweeps of 12-32 epochs accumulate their
         Chebyshev moments in registers -- no LDS atomics, no moment maps in HBM.  A one-off per
         model (two passes + scattered 16-byte writes: ~50 ms for 1.07e9 cells, ~1.2 x the bytes of
         a0 + ts resident): worth it for a model that is swept many times.  Rebuild after `a0` or
-        `ts` change (a stale layout is ignored by `struct()`)."""
+        `ts` change (a stale layout is ignored by `struct()`).  K bins per jet: fewer, wider bins
+        pad less (rows are as long as the fullest of 64 lanes: 1.15 x at K = 16, 1.17 x at 20,
+        1.22 x at 32 on the dense benchmark grid) but need a higher order for the same bursts
+        (24 / 20 / 16 for the example's); 20 measured fastest there."""
         torch = _torch()
         fields.lt = None
         if fields.a0 is None or fields.ts is None or fields.dtype != RJP_F64:
