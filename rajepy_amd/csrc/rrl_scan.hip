@@ -767,8 +767,11 @@ __global__ __launch_bounds__(kRB) void rrl_cells_kernel(RrlFields<T> f, int64_t 
 // Tile = ZT z-adjacent sightlines (8 for LF = 256, else 16), slab = 256 / ZT y-rows.
 // The per-(sightline, channel) accumulators live in LDS, one slot per thread and sightline,
 // so the sightline loop is NOT unrolled: one inlined copy of the Voigt code, < 128 VGPRs.
+#ifndef RJP_K3_ZT256
+#define RJP_K3_ZT256 8      /* sightlines per workgroup of the 256-channel-lane kernel */
+#endif
 template <int LF> struct RrlTile {
-  static constexpr int ZT = LF == 256 ? 8 : 16;
+  static constexpr int ZT = LF == 256 ? RJP_K3_ZT256 : 16;
   static constexpr int YC = kRB / ZT;
   static constexpr int G = kRB / LF;
   static constexpr int NZP = ZT / G;        // sightlines per thread
