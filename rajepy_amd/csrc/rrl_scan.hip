@@ -128,66 +128,71 @@ __device__ __forceinline__ double kmul(double K, double b);
 struct PoleTop { double cos_top, exp_top; };
 __device__ __forceinline__ PoleTop pole_top() {
   PoleTop t;
-  asm volatile("v_mov_b64 %0, %1" : "=v"(t.cos_top) : "s"(-2.62979486641630506e-07));
-  asm volatile("v_mov_b64 %0, %1" : "=v"(t.exp_top) : "s"(1.73659676346479309e-04));
+  // (the coefficients of w^10 and r^7 of the two near-minimax fits below, in the variables the
+  // polynomials now run in: half-turns d = w / pi and binary exponents f = r / ln 2)
+  asm volatile("v_mov_b64 %0, %1" : "=v"(t.cos_top) : "s"(-2.46275154502513423e-02));
+  asm volatile("v_mov_b64 %0, %1" : "=v"(t.exp_top) : "s"(1.33498754716926590e-05));
   return t;
 }
 
-__device__ __forceinline__ void cos_2pi_x3(double u0, double u1, double u2, double top,
+__device__ __forceinline__ void cos_2pi_x3(double h0, double h1, double h2, double top,
                                            double& c0, double& c1, double& c2) {
-  const double u[3] = {u0, u1, u2};
-  double k[3], w2[3], p[3];
+  // the arguments come in HALF-turns (h = 2 u): k = rint(h), d = h - k in [-1/2, 1/2],
+  // cos(2 pi u) = (-1)^k cos(pi d), and the polynomial runs in d^2 with pi^2j folded into its
+  // coefficients -- no multiplication by 2 before the rounding, none by 2 pi after it
+  const double h[3] = {h0, h1, h2};
+  double k[3], d2[3], p[3];
 #pragma unroll
   for (int i = 0; i < 3; ++i) {
-    k[i] = __builtin_rint(2.0 * u[i]);
-    const double w = kmul(6.28318530717958647692, __builtin_fma(-0.5, k[i], u[i]));
-    w2[i] = w * w;
+    k[i] = __builtin_rint(h[i]);
+    const double d = h[i] - k[i];
+    d2[i] = d * d;
   }
-  // near-minimax on |w| <= pi/2 with the two leading coefficients kept at 1, -1/2 (inline
-  // constants): degree 10, max abs error 1.1e-9 (tools/minimax_fit.py) -- the worst error of
+  // near-minimax on |w| <= pi/2 (w = pi d) with the two leading coefficients kept at 1, -1/2:
+  // degree 10, max abs error 1.1e-9 (tools/minimax_fit.py) -- the worst error of
   // the whole path stays the lattice's 3.1e-9 (tools/voigt_design.py; the pole term enters
   // Re w amplified by at most ~10 where sum and pole term cancel, and is itself <= 1e-1 of
   // it there).  Degree 12 (3.9e-12) in the first half of round 3, 14 in round 2, a degree-20
-  // Taylor polynomial in round 1.
-  constexpr double cf[3] = {2.47753637598607603e-05, -1.38886802208908807e-03,
-                            4.16666619921366096e-02};
+  // Taylor polynomial in round 1.  Coefficients times pi^8, pi^6, pi^4, pi^2 here.
+  constexpr double cf[4] = {2.35081807469869619e-01, -1.33524270773875631e+00,
+                            4.05871167107504327e+00, -4.93480220054467900e+00};
 #pragma unroll
-  for (int i = 0; i < 3; ++i) p[i] = fma_k(top, w2[i], cf[0]);
+  for (int i = 0; i < 3; ++i) p[i] = fma_k(top, d2[i], cf[0]);
 #pragma unroll
-  for (int j = 1; j < 3; ++j)
+  for (int j = 1; j < 4; ++j)
 #pragma unroll
-    for (int i = 0; i < 3; ++i) p[i] = fma_k(p[i], w2[i], cf[j]);
+    for (int i = 0; i < 3; ++i) p[i] = fma_k(p[i], d2[i], cf[j]);
 #pragma unroll
-  for (int i = 0; i < 3; ++i) {
-    p[i] = __builtin_fma(p[i], w2[i], -0.5);
-    p[i] = __builtin_fma(p[i], w2[i], 1.0);
-  }
-  // (-1)^k: the parity of k goes straight into the sign bit
+  for (int i = 0; i < 3; ++i) p[i] = __builtin_fma(p[i], d2[i], 1.0);
+  // (-1)^k: the parity of k is ADDED into the sign bit of the high word (shift-and-add is one
+  // instruction; the carry out of bit 31 is dropped)
   auto flip = [](double v, double kk) __attribute__((always_inline)) {
-    const uint64_t sgn = (uint64_t)((uint32_t)(int)kk << 31) << 32;
-    return __builtin_bit_cast(double, __builtin_bit_cast(uint64_t, v) ^ sgn);
+    const uint64_t b = __builtin_bit_cast(uint64_t, v);
+    const uint32_t hi = ((uint32_t)(int)kk << 31) + (uint32_t)(b >> 32);
+    return __builtin_bit_cast(double, ((uint64_t)hi << 32) | (uint32_t)b);
   };
   c0 = flip(p[0], k[0]);
   c1 = flip(p[1], k[1]);
   c2 = flip(p[2], k[2]);
 }
 
-// exp(x) for |x| <= 700 with the polynomial constants in SGPRs (same reduction as exp_any,
-// rjp_device.h; shorter polynomial)
-__device__ __forceinline__ double exp_k(double x, double top) {
-  const double kd = __builtin_rint(kmul(1.4426950408889634074, x));
-  double r = kfma(-6.93147180369123816490e-01, kd, x);
-  r = kfma(-1.90821492927058770002e-10, kd, r);
-  // degree 7, near-minimax on |r| <= ln2/2 with 1, 1, 1/2 kept: relative error 3.9e-10
-  // (tools/minimax_fit.py; degree 8 / 1.6e-12 before -- the path's worst error is unchanged,
-  // tools/voigt_design.py); only the pole term uses this exp
-  double p = fma_k(top, r, 1.39332571536309119e-03);
-  p = fma_k(p, r, 8.33781514566415451e-03);
-  p = fma_k(p, r, 4.16664825818220744e-02);
-  p = fma_k(p, r, 1.66666480404710465e-01);
-  p = __builtin_fma(p, r, 0.5);
-  p = __builtin_fma(p, r, 1.0);
-  p = __builtin_fma(p, r, 1.0);
+// exp(-x2) for 0 <= x2 <= 700 with the polynomial constants in SGPRs: t = -x2 log2(e) = k + f,
+// |f| <= 1/2, 2^f from the degree-7 near-minimax polynomial of exp on |r| <= ln2/2 (1, 1, 1/2
+// kept; relative error 3.9e-10, tools/minimax_fit.py; degree 8 / 1.6e-12 before -- the path's
+// worst error is unchanged, tools/voigt_design.py) with ln2^j folded into its coefficients: the
+// two-constant reduction of the natural-exponent form is one subtraction here (t carries a
+// rounding error of 1e-14 at most).  Only the pole term uses this exp.
+__device__ __forceinline__ double exp_neg_k(double x2, double top) {
+  const double t = kmul(-1.4426950408889634074, x2);
+  const double kd = __builtin_rint(t);
+  const double f = t - kd;
+  double p = fma_k(top, f, 1.54527372032223936e-04);
+  p = fma_k(p, f, 1.33407291670661681e-03);
+  p = fma_k(p, f, 9.61808661438522637e-03);
+  p = fma_k(p, f, 5.55040466349984302e-02);
+  p = fma_k(p, f, 2.40226506959100694e-01);
+  p = fma_k(p, f, 6.93147180559945286e-01);
+  p = __builtin_fma(p, f, 1.0);
   return __builtin_ldexp(p, (int)kd);
 }
 
@@ -311,8 +316,11 @@ __device__ __forceinline__ double voigt_far(double ax, double y) {
   return 0.56418958354775628695 * wi * rcp_fast(__builtin_fma(wr, wr, wi * wi));
 }
 
-__device__ __forceinline__ double voigt_centred(double ax, double y, double ky, double q,
-                                                double cq, double* tab) {
+// `gq` = 2 q exp(y^2) / (1 + q), staged per cell (the pole term is gq exp(-x^2) cos(2 x y)).
+// Polynomial and lattice constants ride in SGPRs (fma_k / kmul / kadd below), as in the other
+// wave-uniform paths.
+__device__ __forceinline__ double voigt_centred(double ax, double y, double ky, double gq,
+                                                double cq, double* tab, double exp_top) {
   // per-cell table, written by the 64 lanes of this wave (all of them are here: y is
   // wave-uniform and so is the branch that leads here)
   {
@@ -323,25 +331,23 @@ __device__ __forceinline__ double voigt_centred(double ax, double y, double ky, 
     wave_lds_fence();
   }
   const double axc = fmin(ax, kCenXMax);
-  const double km = __builtin_rint(__builtin_fma(axc, -1.0 / kHW, -0.5));
-  const double tm = __builtin_fma(km + 0.5, kHW, axc);         // |tm| <= h/2
+  const double km = __builtin_rint(kmul(-1.0 / kHW, axc) - 0.5);
+  const double tm = kfma(kHW, km + 0.5, axc);                   // |tm| <= h/2
   const double w = tm * tm;                                     // <= 0.114
-  double em = 1.0 / 720.0;                                      // exp(-w), degree 6 (5e-11)
-  em = __builtin_fma(em, w, -1.0 / 120.0);
-  em = __builtin_fma(em, w, 1.0 / 24.0);
-  em = __builtin_fma(em, w, -1.0 / 6.0);
+  double em = kadd(-1.0 / 120.0, kmul(1.0 / 720.0, w));         // exp(-w), degree 6 (5e-11)
+  em = fma_k(em, w, 1.0 / 24.0);
+  em = fma_k(em, w, -1.0 / 6.0);
   em = __builtin_fma(em, w, 0.5);
   em = __builtin_fma(em, w, -1.0);
   em = __builtin_fma(em, w, 1.0);
-  const double v = (-2.0 * kHW) * tm;                           // |v| <= 0.456
-  double u = 2.755731922398589e-07;                             // exp(v), degree 10 (4e-12)
-  u = __builtin_fma(u, v, 2.7557319223985893e-06);
-  u = __builtin_fma(u, v, 2.48015873015873e-05);
-  u = __builtin_fma(u, v, 1.984126984126984e-04);
-  u = __builtin_fma(u, v, 1.388888888888889e-03);
-  u = __builtin_fma(u, v, 8.333333333333333e-03);
-  u = __builtin_fma(u, v, 4.1666666666666664e-02);
-  u = __builtin_fma(u, v, 1.6666666666666666e-01);
+  const double v = kmul(-2.0 * kHW, tm);                        // |v| <= 0.456
+  double u = kadd(2.7557319223985893e-06, kmul(2.755731922398589e-07, v));   // exp(v), degree 10 (4e-12)
+  u = fma_k(u, v, 2.48015873015873e-05);
+  u = fma_k(u, v, 1.984126984126984e-04);
+  u = fma_k(u, v, 1.388888888888889e-03);
+  u = fma_k(u, v, 8.333333333333333e-03);
+  u = fma_k(u, v, 4.1666666666666664e-02);
+  u = fma_k(u, v, 1.6666666666666666e-01);
   u = __builtin_fma(u, v, 0.5);
   u = __builtin_fma(u, v, 1.0);
   u = __builtin_fma(u, v, 1.0);
@@ -349,38 +355,34 @@ __device__ __forceinline__ double voigt_centred(double ax, double y, double ky, 
   constexpr double kQ = 0.40202138309465485;                    // exp(-2 h^2)
   const double* t = tab + ((int)km + kCenOff);
   double s = em * t[0];
-  double e = em, r = kC1 * u;                                   // towards +t
+  double e = em, r = kmul(kC1, u);                              // towards +t
 #pragma unroll
   for (int j = 1; j <= kCenJ; ++j) {
-    e *= r; r *= kQ;
+    e *= r;
+    if (j < kCenJ) r = kmul(kQ, r);
     s = __builtin_fma(e, t[j], s);
   }
-  e = em; r = kC1 * rcp_fast(u);                                // towards -t
+  e = em; r = kmul(kC1, rcp_fast(u));                           // towards -t
 #pragma unroll
   for (int j = 1; j <= kCenJ; ++j) {
-    e *= r; r *= kQ;
+    e *= r;
+    if (j < kCenJ) r = kmul(kQ, r);
     s = __builtin_fma(e, t[-j], s);
   }
   s *= ky;                                                      // y h / pi
   // pole term: below 3e-8 Re w by a rigorous bound (measured: 1e-9) once x^2 exceeds the
   // per-cell bound cq; skipped when no lane of the wave needs it
-  if (__builtin_amdgcn_ballot_w64(ax * ax < cq) != 0) {
-    double c;
-    if (kCenYMax <= 0.03 || y < 0.03) {
-      // th = 2 x y < 0.4 wherever the term matters (x^2 < cq < 40, y < 0.03): degree 8, 5e-13
-      const double th = 2.0 * ax * y, t2 = th * th;
-      c = 1.0 / 40320.0;                                        // cos(th), degree 8
-      c = __builtin_fma(c, t2, -1.0 / 720.0);
-      c = __builtin_fma(c, t2, 1.0 / 24.0);
-      c = __builtin_fma(c, t2, -0.5);
-      c = __builtin_fma(c, t2, 1.0);
-    } else {
-      double sn;
-      sincos_2pi(0.31830988618379067154 * ax * y, sn, c);
-    }
-    const double g = exp_any(__builtin_fma(-ax, ax, y * y));    // y^2 - x^2 in [-256, 25]
-    const double p = 2.0 * g * c * q * rcp_fast(1.0 + q);       // y < pi/h: q > 0
-    s += (ax * ax < cq) ? p : 0.0;
+  const double x2 = ax * ax;
+  if (__builtin_amdgcn_ballot_w64(x2 < cq) != 0) {
+    static_assert(kCenYMax <= 0.03, "cos(2 x y) below is a short polynomial: 2 x y < 0.4 needs y < 0.03");
+    // th = 2 x y < 0.4 wherever the term matters (x^2 < cq < 40, y < 0.03): degree 8, 5e-13
+    const double th = 2.0 * ax * y, t2 = th * th;
+    double c = kadd(-1.0 / 720.0, kmul(1.0 / 40320.0, t2));     // cos(th), degree 8
+    c = fma_k(c, t2, 1.0 / 24.0);
+    c = __builtin_fma(c, t2, -0.5);
+    c = __builtin_fma(c, t2, 1.0);
+    const double pterm = exp_neg_k(x2, exp_top) * c * gq;       // x^2 <= 256
+    s += (x2 < cq) ? pterm : 0.0;
   }
   if (__builtin_amdgcn_ballot_w64(ax > kCenXMax) != 0) {
     const double vf = voigt_far(ax, y);
@@ -402,11 +404,8 @@ __device__ __forceinline__ double voigt_rew(double ax, double y, double q, doubl
   // valid everywhere, so a wave that straddles the boundary runs one path, not both
   const bool far = r2 > 64.0 && (ax * ax > 64.0 || y > 1.0);
   if (__builtin_amdgcn_ballot_w64(!far) == 0) return voigt_far(ax, y);
-  if constexpr (CEN) {
-    if (y < kCenYMax) return voigt_centred(ax, y, y * (kHW / 3.14159265358979323846), q, cq, tab);
-  } else {
-    if (y < 0.03) return voigt_core_shifted(ax, y, q, -2.0 * (3.14159265358979323846 / kH) * y);
-  }
+  static_assert(!CEN, "the wave-uniform kernels call their paths directly (path codes)");
+  if (y < 0.03) return voigt_core_shifted(ax, y, q, -2.0 * (3.14159265358979323846 / kH) * y);
 
   // Plain lattice t = n h.  Pair (+t,-t):
   //   c [1/((x-t)^2+y^2) + 1/((x+t)^2+y^2)] = 2c (A + tau) / (A^2 + tau (W + tau)),
@@ -533,10 +532,10 @@ __device__ __forceinline__ double voigt_far_series(double ax, double y) {
 // of the generic path does.  Relative error <= 3.4e-9 against wofz for 0.03 <= y, x^2 <= 64,
 // pole term included (worst at x = 0 just above y = pi/h, where the pole term ends;
 // tools/voigt_design.py).  Rounds 1-2: h = 0.6, ten pairs, 1e-11.
-// `ky` = y h / pi, staged per cell.
+// `ky` = y h / pi, staged per cell.  `ax` may carry either sign (see the channel loop).
 template <bool POLE>
 __device__ __forceinline__ double voigt_plain_wave(double ax, double y, double ky, double q,
-                                                   const PoleTop& top) {
+                                                   double gq, const PoleTop& top) {
   constexpr double tau[kNPairW] = {0.0, 0.45562500000000006, 1.8225000000000002,
                                    4.100625000000002, 7.290000000000001, 11.390625,
                                    16.402500000000007, 22.325625000000006};
@@ -572,16 +571,16 @@ __device__ __forceinline__ double voigt_plain_wave(double ax, double y, double k
   // is negligible where x^2 exceeds the per-cell bound cq, and harmless there):
   // Re[e^{-i phi} conj(q - e^{-i theta})] = q cos(phi) - cos(theta - phi), phi = 2 x y;
   // |q - e^{-i theta}|^2 = 1 - 2 q cos(theta) + q^2 >= (1 - q)^2 >= 0.06 for y >= 0.03
-  const double e = __builtin_fma(y, y, -x2);      // in (-|x|^2, (pi/h)^2 = 21.7): no clamp
-  const double u = kmul(1.0 / kHW, ax);                         // theta / 2 pi (+ whole turns)
-  const double ph = kmul(0.31830988618379067154, ax * y);       // phi / 2 pi
+  // `gq` = 2 q exp(y^2) is staged per cell: exp(y^2 - x^2) costs the lane exp(-x^2) only
+  const double u = kmul(2.0 / kHW, ax);                         // theta / pi (half-turns)
+  const double ph = kmul(0.63661977236758134308, ax * y);       // phi / pi
   double cth, cph, cps;
   cos_2pi_x3(u, ph, u - ph, top.cos_top, cth, cph, cps);
   const double den = __builtin_fma(q, q - 2.0 * cth, 1.0);
   const double num = __builtin_fma(q, cph, -cps);
   // one reciprocal for both fractions: (Nall ky den + 2 E q num Dall) / (Dall den), with
   // Dall <= (|z|^2 + 23)^16 < 1e32 for the |x| <= 8 a wave of this path can hold
-  const double pq = 2.0 * exp_k(e, top.exp_top) * q * num;
+  const double pq = exp_neg_k(x2, top.exp_top) * gq * num;
   return __builtin_fma(Nall * ky, den, pq * Dall) * rcp_fast(Dall * den);
 }
 
@@ -879,7 +878,14 @@ __global__ __launch_bounds__(kRB, RJP_K3_WAVES) void rrl_scan_kernel(
       // wave-uniform kernels stage the derived forms in the same slots: s_C <- A, s_nu0 <- c1,
       // s_E0 <- B (the per-lane layouts keep the plain constants)
       s_C[tid] = CEN ? cl.A : C; s_nu0[tid] = CEN ? cl.c1 : nu0; s_is2[tid] = is2; s_y[tid] = yv;
-      s_a[tid] = a; s_E0[tid] = CEN ? cl.B : E0; s_q[tid] = q; s_cq[tid] = cq;
+      // (wave-uniform kernels: the bound cq is used up by path_code below for cells of the
+      // plain lattice, y >= 0.03 -- their slot carries 2 q exp(y^2) for the pole term instead;
+      // q < 0 marks y >= pi/h, where no pole term exists)
+      // cells of the centred lattice, y < 0.03: q is needed as 2 q exp(y^2) / (1 + q) only
+      const bool cen_cell = CEN && yv < kCenYMax;
+      const double gq = q >= 0.0 ? 2.0 * q * exp(yv * yv) : 0.0;
+      s_a[tid] = a; s_E0[tid] = CEN ? cl.B : E0; s_q[tid] = cen_cell ? gq / (1.0 + q) : q;
+      s_cq[tid] = (CEN && !cen_cell) ? gq : cq;
       if constexpr (CEN) {
         s_ky[tid] = yv * (kHW / 3.14159265358979323846);
 #pragma unroll
@@ -922,13 +928,19 @@ __global__ __launch_bounds__(kRB, RJP_K3_WAVES) void rrl_scan_kernel(
             continue;
           }
           const double yv = s_y[ci];
-          const double ax = fabs(__builtin_fma(nu_f, s_is2[ci], s_nu0[ci]));     // s_nu0 holds c1
+          // Re w is even in x, and the lattice and its pole term are written in x^2 and in
+          // cosines of angles odd in x: they take the SIGNED x (no |x| to materialise for the
+          // inline-asm constant multiplies, which carry no source modifiers)
+          const double xs = __builtin_fma(nu_f, s_is2[ci], s_nu0[ci]);            // s_nu0 holds c1
+          const double ax = fabs(xs);
           double V;
           if (path == kPathFarA) V = voigt_far_series<6>(ax, yv);
           else if (path == kPathFarB) V = voigt_far_series<4>(ax, yv);
-          else if (path == kPathPlain) V = voigt_plain_wave<false>(ax, yv, s_ky[ci], 0.0, ptop);
-          else if (path == kPathPlainPole) V = voigt_plain_wave<true>(ax, yv, s_ky[ci], s_q[ci], ptop);
-          else V = voigt_centred(ax, yv, s_ky[ci], s_q[ci], s_cq[ci], s_tab[tid / RJP_WAVE]);
+          else if (path == kPathPlain) V = voigt_plain_wave<false>(xs, yv, s_ky[ci], 0.0, 0.0, ptop);
+          else if (path == kPathPlainPole)
+            V = voigt_plain_wave<true>(xs, yv, s_ky[ci], s_q[ci], s_cq[ci], ptop);   // s_cq: 2 q e^(y^2)
+          else V = voigt_centred(ax, yv, s_ky[ci], s_q[ci], s_cq[ci], s_tab[tid / RJP_WAVE],
+                                 ptop.exp_top);                               // s_q: 2 q e^(y^2) / (1 + q)
           // C V (1 - exp(-h nu / kT)) with 1 - exp(...) = 1 - E0 exp(-a (nu - nu_ref)); to first
           // order in a dnu over the band (unless the path code says otherwise) that is
           // V (A + B dnu), A = C (1 - E0), B = C E0 a staged per cell: two fmas

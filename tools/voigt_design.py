@@ -42,18 +42,25 @@ def horner(c, x):
     return p
 
 
-def cos_2pi(u):
-    k = np.rint(2.0 * u)
-    w = 6.28318530717958647692 * (u - 0.5 * k)
-    p = horner(COS12, w * w)
+def cos_halfturns(h):
+    """cos(pi h) as the kernel evaluates it (cos_2pi_x3): k = rint(h), d = h - k, the polynomial
+    in d^2 with pi^2j folded into the coefficients, (-1)^k into the sign bit"""
+    k = np.rint(h)
+    d = h - k
+    c = [COS12[j] * np.pi ** (10 - 2 * j) for j in range(6)]
+    p = horner(c, d * d)
     return np.where(k.astype(np.int64) & 1, -p, p)
 
 
-def exp_k(x):
-    kd = np.rint(1.4426950408889634074 * x)
-    r = x - kd * 6.93147180369123816490e-01
-    r = r - kd * 1.90821492927058770002e-10
-    return np.ldexp(horner(EXP8, r), kd.astype(np.int64))
+def exp_neg_k(x2):
+    """exp(-x2) as the kernel evaluates it: t = -x2 log2(e) = k + f, 2^f from the exp polynomial
+    with ln2^j folded into its coefficients"""
+    t = -1.4426950408889634074 * x2
+    kd = np.rint(t)
+    f = t - kd
+    ln2 = np.log(2.0)
+    c = [EXP8[j] * ln2 ** (7 - j) for j in range(8)]
+    return np.ldexp(horner(c, f), kd.astype(np.int64))
 
 
 def far_series(x, y, K):
@@ -92,13 +99,13 @@ def plain_wave(x, y, pole):
     if not pole:
         return Nall / Dall * ky
     q = np.exp(-2.0 * np.pi * y / H)
-    e = y * y - x2
-    u = x / H
-    ph = 0.31830988618379067154 * (x * y)
-    cth, cph, cps = cos_2pi(u), cos_2pi(ph), cos_2pi(u - ph)
+    gq = 2.0 * q * np.exp(y * y)               # staged per cell
+    u = (2.0 / H) * x                          # half-turns
+    ph = 0.63661977236758134308 * (x * y)
+    cth, cph, cps = cos_halfturns(u), cos_halfturns(ph), cos_halfturns(u - ph)
     den = q * (q - 2.0 * cth) + 1.0
     num = q * cph - cps
-    pq = 2.0 * exp_k(e) * q * num
+    pq = exp_neg_k(x2) * gq * num
     return (Nall * ky * den + pq * Dall) / (Dall * den)
 
 
@@ -140,8 +147,8 @@ def centred(x, y):
     th = 2.0 * x * y
     t2 = th * th
     c = horner([1.0 / 40320.0, -1.0 / 720.0, 1.0 / 24.0, -0.5, 1.0], t2)     # cos, degree 8
-    g = np.exp(y * y - x * x)
-    return s + 2.0 * g * c * q / (1.0 + q)
+    gq = 2.0 * q * np.exp(y * y) / (1.0 + q)       # staged per cell
+    return s + exp_neg_k(x * x) * c * gq
 
 
 def rel(a, ref):
