@@ -533,7 +533,9 @@ __device__ __forceinline__ double voigt_far_series(double ax, double y) {
 // pole term included (worst at x = 0 just above y = pi/h, where the pole term ends;
 // tools/voigt_design.py).  Rounds 1-2: h = 0.6, ten pairs, 1e-11.
 // `ky` = y h / pi, staged per cell.  `ax` may carry either sign (see the channel loop).
-template <bool POLE>
+// POLE: 0 = no pole term, 1 = the full term, 2 = its leading order in q (cells with y >= 1.3).
+constexpr double kPoleLiteY = 1.3;
+template <int POLE>
 __device__ __forceinline__ double voigt_plain_wave(double ax, double y, double ky, double q,
                                                    double gq, const PoleTop& top) {
   constexpr double tau[kNPairW] = {0.0, 0.45562500000000006, 1.8225000000000002,
@@ -566,7 +568,7 @@ __device__ __forceinline__ double voigt_plain_wave(double ax, double y, double k
   const double Nall = __builtin_fma(N01, D23, kmul(w2[4] / w2[0], N23 * D01)), Dall = D01 * D23;
   // sum = w2[0] * Nall / Dall (w2[0] = 1); Re w = (h y / pi) * sum = ky * sum
   static_assert(w2[0] == 1.0, "ky carries no node weight");
-  if (!POLE) return Nall * rcp_fast(Dall) * ky;
+  if (POLE == 0) return Nall * rcp_fast(Dall) * ky;
   // P = Re[ 2 exp(-z^2) q / (q - exp(-i theta)) ], theta = 2 pi x / h, for every lane (it
   // is negligible where x^2 exceeds the per-cell bound cq, and harmless there):
   // Re[e^{-i phi} conj(q - e^{-i theta})] = q cos(phi) - cos(theta - phi), phi = 2 x y;
@@ -574,6 +576,15 @@ __device__ __forceinline__ double voigt_plain_wave(double ax, double y, double k
   // `gq` = 2 q exp(y^2) is staged per cell: exp(y^2 - x^2) costs the lane exp(-x^2) only
   const double u = kmul(2.0 / kHW, ax);                         // theta / pi (half-turns)
   const double ph = kmul(0.63661977236758134308, ax * y);       // phi / pi
+  if constexpr (POLE == 2) {
+    // y >= 1.3: q = exp(-2 pi y / h) <= 5.6e-6, and P = -2 E q cos(theta - phi) (1 + O(q)) with
+    // |P| <= 1.3e-4 Re w there: the terms of order q^2 E stay below 5e-10 Re w (the path's worst
+    // error remains the lattice's 3.1e-9, tools/voigt_design.py) -- ONE cosine, no denominator
+    double c0, c1, cps;
+    cos_2pi_x3(u - ph, 0.0, 0.0, top.cos_top, cps, c0, c1);     // (the idle slots fold away)
+    const double pq = exp_neg_k(x2, top.exp_top) * gq * cps;
+    return __builtin_fma(Nall, ky, -pq * Dall) * rcp_fast(Dall);
+  }
   double cth, cph, cps;
   cos_2pi_x3(u, ph, u - ph, top.cos_top, cth, cph, cps);
   const double den = __builtin_fma(q, q - 2.0 * cth, 1.0);
@@ -596,6 +607,7 @@ enum : int {
   kPathCentred = 5,   // y < 0.03: centred lattice
   kPathGeneric = 6,   // irregular constants (inf ...) or |x| > 1e6 beside core lanes:
                       // per-lane generic code with NumPy's NaN filter
+  kPathPlainPoleLite = 7, // plain lattice + the pole term to leading order in q (y >= 1.3)
   kPathExpFlag = 8    // bit 3: h nu / kT is not small over the band -> exp() per lane
 };
 
@@ -702,7 +714,8 @@ __device__ __forceinline__ int path_code(const CellLine& c, const double (&rg)[4
   else if (r2min > 64.0 && (x2min > 64.0 || c.y > 1.0)) code = r2min > 196.0 ? kPathFarB : kPathFarA;
   else if (xmax > 1e6) code = kPathGeneric;
   else if (c.y < kCenYMax) code = kPathCentred;
-  else code = (c.q >= 0.0 && x2min < c.cq) ? kPathPlainPole : kPathPlain;
+  else code = (c.q >= 0.0 && x2min < c.cq)
+                  ? (c.y >= kPoleLiteY ? kPathPlainPoleLite : kPathPlainPole) : kPathPlain;
   // 1 - E0 exp(-a dnu) to first order in a dnu: the dropped term (a dnu)^2 / 2 stays below
   // 2e-9 of the factor itself (which is ~ a nu_ref for h nu << k T)
   if (!(0.5 * (c.a * dnu_max) * (c.a * dnu_max) < 2e-9 * (1.0 - c.E0))) code |= kPathExpFlag;
@@ -808,6 +821,20 @@ __global__ __launch_bounds__(kRB, RJP_K3_WAVES) void rrl_scan_kernel(
   const int x = blockIdx.x / ntz;
   const int z0 = (blockIdx.x - x * ntz) * ZT;
   const int tid = threadIdx.x;
+  // 256 channel lanes: the four waves of a workgroup hold four BANDS of |x| (the folded channel
+  // order below), i.e. paths of very different cost (line core: lattice + pole term, 113
+  // instructions; outermost band: 37), and they meet at a barrier per slab.  Which wave takes
+  // which band ROTATES WITH THE SIGHTLINE inside a slab (band = (wave + j) mod 4, j = the
+  // sightline of the tile): every wave gets every band twice per slab, so the four waves reach
+  // the barrier together instead of three of them waiting for the one that holds the line core.
+  // A (sightline, band) pair still belongs to exactly one wave per slab: no atomics, the same
+  // summation order.  The accumulators are LDS slots per CHANNEL already; the channel
+  // frequencies go to LDS too.
+#ifndef RJP_K3_ROT
+#define RJP_K3_ROT 1
+#endif
+  constexpr bool ROT = LF == 256 && RJP_K3_ROT != 0;
+  __shared__ double s_nu[ROT ? kRB : 1];
   const int fl = tid % LF;
   const int g = tid / LF;
   // Lanes take the channels of this block folded about the block centre: lane 0 -> first,
@@ -818,8 +845,8 @@ __global__ __launch_bounds__(kRB, RJP_K3_WAVES) void rrl_scan_kernel(
   const int nblk = min(LF, nchan - fbase);
   const int fi = fbase + ((fl & 1) ? nblk - 1 - (fl >> 1) : (fl >> 1));
   const bool chan_live = fl < nblk;
-  const double nu_f = chan_live ? nu[fi] : ln.nu_ref;
-  const double dnu = nu_f - ln.nu_ref;
+  const double nu_f0 = chan_live ? nu[fi] : ln.nu_ref;
+  if constexpr (ROT) s_nu[tid] = nu_f0;          // (visible after the barrier of the range block)
 
 #pragma unroll
   for (int j = 0; j < NZP; ++j) s_acc[j * kRB + tid] = 0.0;
@@ -827,8 +854,8 @@ __global__ __launch_bounds__(kRB, RJP_K3_WAVES) void rrl_scan_kernel(
   if constexpr (CEN) {
     // frequency range of this wave's even and odd lanes (its two runs of channels)
     const double inf = __builtin_inf();
-    double r0 = (chan_live && !(fl & 1)) ? nu_f : inf, r1 = (chan_live && !(fl & 1)) ? nu_f : -inf;
-    double r2 = (chan_live && (fl & 1)) ? nu_f : inf, r3 = (chan_live && (fl & 1)) ? nu_f : -inf;
+    double r0 = (chan_live && !(fl & 1)) ? nu_f0 : inf, r1 = (chan_live && !(fl & 1)) ? nu_f0 : -inf;
+    double r2 = (chan_live && (fl & 1)) ? nu_f0 : inf, r3 = (chan_live && (fl & 1)) ? nu_f0 : -inf;
 #pragma unroll
     for (int d = RJP_WAVE / 2; d > 0; d >>= 1) {
       r0 = fmin(r0, __shfl_xor(r0, d, RJP_WAVE));
@@ -837,7 +864,7 @@ __global__ __launch_bounds__(kRB, RJP_K3_WAVES) void rrl_scan_kernel(
       r3 = fmax(r3, __shfl_xor(r3, d, RJP_WAVE));
     }
     if ((tid & (RJP_WAVE - 1)) == 0) {
-      const int w = (tid % LF) / RJP_WAVE;       // LF = 64: every wave holds the same channels
+      const int w = fl / RJP_WAVE;               // LF = 64: every wave holds the same channels
       s_rng[w][0] = r0; s_rng[w][1] = r1; s_rng[w][2] = r2; s_rng[w][3] = r3;
     }
     __syncthreads();
@@ -863,7 +890,7 @@ __global__ __launch_bounds__(kRB, RJP_K3_WAVES) void rrl_scan_kernel(
   }
 
   // (a scalar: the path code must reach the branches below as a wave-uniform value)
-  const int wq = (CEN && LF > RJP_WAVE) ? __builtin_amdgcn_readfirstlane(tid / RJP_WAVE) : 0;
+  const int wave = (CEN && LF > RJP_WAVE) ? __builtin_amdgcn_readfirstlane(fl / RJP_WAVE) : 0;
 
   for (int yb = ya; yb < ye; yb += YC) {
     // ---- phase 1: per-cell line constants --------------------------------------------
@@ -900,7 +927,11 @@ __global__ __launch_bounds__(kRB, RJP_K3_WAVES) void rrl_scan_kernel(
     // ---- phase 2: lanes over channels ------------------------------------------------
 #pragma unroll 1
     for (int j = 0; j < NZP; ++j) {
-      double acc = s_acc[j * kRB + tid];
+      const int wq = ROT ? (wave + j) & 3 : wave;                          // this wave's band
+      const int slot = ROT ? (wq << 6) | (tid & (RJP_WAVE - 1)) : tid;     // channel slot of this lane
+      const double nu_f = ROT ? s_nu[slot] : nu_f0;
+      const double dnu = nu_f - ln.nu_ref;
+      double acc = s_acc[j * kRB + slot];
       if constexpr (CEN) {
         // the wave works on ONE cell per trip: its path was decided in phase 1
         const uint8_t* cb = s_cb + (wq * ZT + g * NZP + j) * YC;
@@ -936,9 +967,11 @@ __global__ __launch_bounds__(kRB, RJP_K3_WAVES) void rrl_scan_kernel(
           double V;
           if (path == kPathFarA) V = voigt_far_series<6>(ax, yv);
           else if (path == kPathFarB) V = voigt_far_series<4>(ax, yv);
-          else if (path == kPathPlain) V = voigt_plain_wave<false>(xs, yv, s_ky[ci], 0.0, 0.0, ptop);
+          else if (path == kPathPlain) V = voigt_plain_wave<0>(xs, yv, s_ky[ci], 0.0, 0.0, ptop);
           else if (path == kPathPlainPole)
-            V = voigt_plain_wave<true>(xs, yv, s_ky[ci], s_q[ci], s_cq[ci], ptop);   // s_cq: 2 q e^(y^2)
+            V = voigt_plain_wave<1>(xs, yv, s_ky[ci], s_q[ci], s_cq[ci], ptop);     // s_cq: 2 q e^(y^2)
+          else if (path == kPathPlainPoleLite)
+            V = voigt_plain_wave<2>(xs, yv, s_ky[ci], 0.0, s_cq[ci], ptop);
           else V = voigt_centred(ax, yv, s_ky[ci], s_q[ci], s_cq[ci], s_tab[tid / RJP_WAVE],
                                  ptop.exp_top);                               // s_q: 2 q e^(y^2) / (1 + q)
           // C V (1 - exp(-h nu / kT)) with 1 - exp(...) = 1 - E0 exp(-a (nu - nu_ref)); to first
@@ -966,7 +999,7 @@ __global__ __launch_bounds__(kRB, RJP_K3_WAVES) void rrl_scan_kernel(
           }
         }
       }
-      s_acc[j * kRB + tid] = acc;
+      s_acc[j * kRB + slot] = acc;
     }
     __syncthreads();
   }

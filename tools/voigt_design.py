@@ -24,6 +24,7 @@ CEN_J = 7                  # centred lattice: nodes on each side of the middle o
 CEN_YMAX = 0.03            # below: centred lattice (sum and pole term of the plain one cancel)
 FAR = ((6, 64.0), (4, 196.0))     # (series terms K, |z|^2 above which every lane must lie)
 TOL_POLE = 3e-8            # pole term skipped where a rigorous bound puts it below this * Re w
+POLE_LITE_Y = 1.3          # from here on the pole term is taken to leading order in q (one cosine)
 C_FAR = [1.0, 0.5, 0.75, 1.875, 6.5625, 29.53125, 162.421875, 1055.7421875, 7918.06640625]
 
 # near-minimax polynomials (tools/minimax_fit.py): cos on |w| <= pi/2 in s = w^2 (degree 10 in
@@ -102,6 +103,9 @@ def plain_wave(x, y, pole):
     gq = 2.0 * q * np.exp(y * y)               # staged per cell
     u = (2.0 / H) * x                          # half-turns
     ph = 0.63661977236758134308 * (x * y)
+    if pole == "lite":                         # y >= POLE_LITE_Y: P = -2 E q cos(theta - phi)
+        pq = exp_neg_k(x2) * gq * cos_halfturns(u - ph)
+        return (Nall * ky - pq * Dall) / Dall
     cth, cph, cps = cos_halfturns(u), cos_halfturns(ph), cos_halfturns(u - ph)
     den = q * (q - 2.0 * cth) + 1.0
     num = q * cph - cps
@@ -160,14 +164,15 @@ def main():
     # ---- plain lattice (+ pole term) over its domain: 0.03 <= y, |z|^2 <= 64 or (x^2 <= 64, y <= 1)
     worst = (0, None)
     worst_skip = (0, None)
-    for y in np.concatenate([np.geomspace(CEN_YMAX, 1, 80), np.linspace(1, 8.1, 143)]):
+    for y in np.concatenate([np.geomspace(CEN_YMAX, 1, 80), np.linspace(1, 8.1, 143),
+                             POLE_LITE_Y + np.array([0.0, 1e-9, 0.01, 0.03])]):
         x = np.linspace(0, 8.0, 6401)
         x = x[(x * x + y * y <= 64.0) | ((x * x <= 64.0) & (y <= 1.0))]
         if x.size == 0:
             continue
         ref = wofz(x + 1j * y).real
         has_pole = y < np.pi / H
-        full = plain_wave(x, y, has_pole)
+        full = plain_wave(x, y, ("lite" if y >= POLE_LITE_Y else True) if has_pole else False)
         e = rel(full, ref)
         i = int(np.argmax(e))
         if e[i] > worst[0]:
