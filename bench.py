@@ -809,6 +809,19 @@ def measure_other_configs(eng, args, torch):
                 c3["valu_issue_frac_of_256x4x16_lanes_at_2.4GHz"] = evals * ipe / (256 * 4 * 16 * 2.4e9)
             except Exception:
                 pass
+        f = _latest_profile("cfg3_f64_pmc.json")
+        if f:
+            try:
+                pm = json.load(open(f))
+                c3["traffic"] = pm["hbm_bytes_per_launch"]
+                c3["traffic_raw_fetch"] = pm.get("hbm_bytes_per_launch_raw_fetch")
+                c3["algorithmic_bytes"] = 6 * w.ncell_loc * 8 + w.nchan * w.P * 8
+                c3["traffic_source"] = os.path.relpath(f, ROOT) + \
+                    " (rocprofv3 --pmc passes of an earlier run; 8 B/lane reads in 64-byte " \
+                    "runs are uncalibrated for the FETCH_SIZE rule: between raw and doubled; " \
+                    "<= 5 % of the HBM peak either way -- this kernel is FP64-vector-bound)"
+            except Exception:
+                pass
         out["cfg3"] = c3
         w.release()
         del w
