@@ -984,7 +984,21 @@ def main(argv=None):
         alg_8d = alg_bytes
         kname = "rrl_scan_kernel"
         roof_extra = {"voigt_evals_per_s": ncell_loc * wl.nchan / (k_ms * 1e-3),
-                      "fp64_vector_peak_lane_ops_per_s": 256 * 4 * 16 * 2.4e9}
+                      "fp64_vector_peak_lane_ops_per_s": 256 * 4 * 16 * 2.4e9,
+                      "bound_note": "K3 is FP64-vector-bound by construction (no contraction: no "
+                                    "MFMA): `frac` against HBM is low by design; the figure that "
+                                    "prices it is valu_issue_frac below"}
+        f = _latest_profile("cfg3_k3_sq.json")
+        if f:
+            try:
+                ipe = json.load(open(f))["derived"]["valu_lane_insts_per_work_item"]
+                roof_extra["valu_insts_per_eval"] = ipe
+                roof_extra["valu_insts_per_eval_source"] = os.path.relpath(f, ROOT) + \
+                    " (SQ counters of an earlier run)"
+                roof_extra["valu_issue_frac_of_256x4x16_lanes_at_2.4GHz"] = \
+                    roof_extra["voigt_evals_per_s"] * ipe / (256 * 4 * 16 * 2.4e9)
+            except Exception:
+                pass
     else:
         want_em = wl.em is not None
         k_ms = eng.time_ff_scan(fields, wl.bursts, wl.my_epochs, wl.gmode, reps=5 if n_ep_cfg else 30,
