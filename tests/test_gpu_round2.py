@@ -279,6 +279,47 @@ def test_k3_channels_concentrated_at_the_path_boundaries(eng, temp_k):
     np.testing.assert_allclose(tau.cpu().numpy().reshape(ref.shape), ref, rtol=U.K3_RTOL_WAVE)
 
 
+def test_k3_cells_pinned_at_the_y_boundaries_of_the_paths(eng):
+    """The wave-uniform paths also switch on the cell's Voigt y: centred lattice below 0.03, the
+    plain lattice with its full pole term up to 1.3, the pole term to leading order in q from
+    there to pi/h = 4.654, none above.  Every cell here sits within 0.5 % of one of those three
+    values, on either side, and the 256 channels cover the line core (|x| <= 6, where the pole
+    term is needed) on both wings.  Against the oracle (scipy.special.wofz) at the design bound."""
+    from rajepy_amd import _lib
+    from rajepy_amd.maths import rrls
+    shape = (2, 48, 8)
+    g = U.synth_host(shape, 515151, 0)
+    temp_k = 9.0e3
+    g["temp"][:] = temp_k
+    g["vy"][:] = 6.2
+    g["xi"][:] = 0.2
+    lc = rrls.line_constants("H66a")
+    nu_c = lc["nu_rest"] * (1.0 - 6.2 * 1000.0 / 299792458.0)
+    sig2 = lc["kG"] * np.sqrt(temp_k) * nu_c / 2.0 / 1.1774100225154747 * np.sqrt(2.0)  # sigma sqrt 2
+    rng = np.random.default_rng(7)
+    ys = np.array([0.03, 1.3, np.pi / 0.675])
+    y = ys[rng.integers(0, 3, size=shape)] * (1.0 + rng.uniform(-5e-3, 5e-3, size=shape))
+    ne = 2.0 * y * sig2 / lc["kL"]                      # y = 0.5 kL ne / (sigma sqrt 2)
+    g["nd"] = np.where(np.isnan(g["nd"]), np.nan, ne / 0.2)
+    p = copy.deepcopy(U.load_golden("cfg1_example")[2])
+    p["ejection"] = U.example_bursts_params()
+    p["grid"].update(n_x=shape[0], n_y=shape[1], n_z=shape[2])
+    jet = orc.OracleJet.from_fields(p, g["nd"], g["xi"], g["temp"], g["ff"], g["areas"],
+                                    g["ts"], g["rr"], g["vy"])
+    jet.time = 40.0 * YEAR                              # long after the last burst: chi = 1
+    fields = eng.upload_fields(g["nd"], g["xi"], g["temp"], g["ff"], g["areas"], g["ts"],
+                               g["rr"] < 0, vy=g["vy"], csize_au=jet.csize, dtype=8)
+    xs = np.linspace(0.0, 6.0, 128)
+    nu = np.concatenate([nu_c - xs[::-1] * sig2, nu_c + xs[1:] * sig2, [nu_c + 6.05 * sig2]])
+    assert nu.size == 256
+    line = _lib.Line(**lc)
+    tau = eng.rrl_scan(fields, U.bursts_from_oracle(jet), jet.time, line, list(nu))
+    eng.synchronize()
+    ref = jet.optical_depth_rrl("H66a", nu)
+    assert np.isfinite(ref).all() and (ref > 0).all()
+    np.testing.assert_allclose(tau.cpu().numpy().reshape(ref.shape), ref, rtol=U.K3_RTOL_WAVE)
+
+
 def test_k3_generic_path_and_odd_channel_lists(eng):
     """The wave-uniform K3 paths are chosen from the frequency range of a wave's channels, so
     the list may come in any order; a wave whose channels sit beside the line AND absurdly
