@@ -16,7 +16,7 @@ cd /tmp
 export PROBE_NO_EM=1
 cells=$((512*4096*512))
 for variant in lds lt; do
-  if [[ $variant == lt ]]; then flags=(--lt); kern="lt_moments_kernel"; sfx="_lt"; export PROBE_LT=32
+  if [[ $variant == lt ]]; then flags=(--lt); kern="lt_moments_kernel"; sfx="_lt"; export PROBE_LT=20
   else flags=(); kern="moments_kernel"; sfx=""; unset PROBE_LT; fi
   B=(python3 "$root/bench.py" --config cfg5 "${flags[@]}" --no-cpu-baseline)
   "${B[@]}" > "$out/${tag}_cfg5_f64${sfx}_bench.json" 2> "$out/${tag}_cfg5_f64${sfx}_bench.err"
