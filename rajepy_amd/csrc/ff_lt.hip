@@ -199,8 +199,19 @@ hipError_t lt_fill_launch(const rjp_fields* fl, int K, const int32_t* d_rowoff, 
 // ---- the sweep ----------------------------------------------------------------------------------
 __device__ __forceinline__ rjp_d2 lt_load(const rjp_d2* p) { return __builtin_nontemporal_load(p); }
 
+// final write of the sweep by the pass itself, when every group is one wave's work
+struct LtDirect {
+  double* sumA;             // null: write partial planes, lt_reduce_kernel finishes
+  const double* aux;
+  int64_t npix;
+  int ne, hb_red, hb_blue;
+};
+
 #ifndef RJP_LT_WAVES
-#define RJP_LT_WAVES 32768      /* key ranges are split until about this many waves exist */
+#define RJP_LT_WAVES 32768      /* small maps: key ranges are split until about this many waves exist ... */
+#endif
+#ifndef RJP_LT_MIN_WAVES
+#define RJP_LT_MIN_WAVES 2048   /* ... but not once this many do */
 #endif
 #ifndef RJP_LT_OCC
 #define RJP_LT_OCC 1            /* minimum waves per SIMD asked of the register allocator */
@@ -210,7 +221,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RJP_LT_OCC))
 void lt_moments_kernel(const rjp_d2* __restrict__ cells,
                                                         const int32_t* __restrict__ off, LtBins b,
                                                         int nsplit, const double* __restrict__ W,
-                                                        int64_t npixp, double* __restrict__ part) {
+                                                        int64_t npixp, double* __restrict__ part,
+                                                        LtDirect dir) {
   constexpr int ET = RJP_MOM_TILE, C = kLtChunk;
   const int Q = 2 * b.K;
   const int g = blockIdx.x / nsplit, sp = blockIdx.x % nsplit;
@@ -277,6 +289,20 @@ void lt_moments_kernel(const rjp_d2* __restrict__ cells,
   }
   if (q < q1) flush();                                 // the last bin (empty ones after it add nothing)
   const int64_t p = (int64_t)g * kLtLanes + lane;
+  if (dir.sumA) {
+    // one wave per group (nsplit == 1): the epoch sums are final -- add the cells that never
+    // entered the layout and write the maps, no partial planes, no reduction kernel
+    if (p < dir.npix) {
+      double extra = 0.0;
+      if (!dir.hb_red) extra += dir.aux[p];
+      if (!dir.hb_blue) extra += dir.aux[dir.npix + p];
+      const bool inf = dir.aux[2 * dir.npix + p] != 0.0;
+#pragma unroll
+      for (int e = 0; e < ET; ++e)
+        if (e < dir.ne) dir.sumA[(int64_t)e * dir.npix + p] = inf ? __builtin_inf() : acc[e] + extra;
+    }
+    return;
+  }
 #pragma unroll
   for (int e = 0; e < ET; ++e) part[((int64_t)sp * ET + e) * npixp + p] = acc[e];
 }
@@ -300,9 +326,10 @@ __global__ __launch_bounds__(256) void lt_reduce_kernel(const double* __restrict
 
 template <int N>
 static hipError_t lt_pass(const rjp_fields* fl, const MomPlan& mp, const LtBins& b, int nsplit,
-                          int64_t G, int64_t npixp, const double* W, double* ws, hipStream_t st) {
+                          int64_t G, int64_t npixp, const double* W, double* ws,
+                          const LtDirect& dir, hipStream_t st) {
   hipLaunchKernelGGL((lt_moments_kernel<N>), dim3((unsigned)(G * nsplit)), dim3(64), 0, st,
-                     (const rjp_d2*)fl->d_lt_cells, fl->d_lt_rowoff, b, nsplit, W, npixp, ws);
+                     (const rjp_d2*)fl->d_lt_cells, fl->d_lt_rowoff, b, nsplit, W, npixp, ws, dir);
   return hipGetLastError();
 }
 
@@ -312,22 +339,30 @@ hipError_t lt_run(const rjp_fields* fl, const MomPlan& mp, int n_epochs, double*
   const int64_t npix = (int64_t)fl->nx * fl->nz;
   const int64_t G = (npix + kLtLanes - 1) / kLtLanes, npixp = G * kLtLanes;
   const LtBins b{mp.s0, mp.inv_h, mp.K};
-  // enough waves for ~128 per CU (measured: 8 key ranges per group at cfg5's size); never finer
-  // than two keys per wave, and the partial sums (nsplit x 32 planes) stay inside the moment
-  // paths' workspace (1280 planes)
-  int nsplit = (int)std::min<int64_t>(std::max<int64_t>(1, (RJP_LT_WAVES + G - 1) / G), mp.K);
-  nsplit = std::min(nsplit, RJP_MOM_MAX_IDX / RJP_MOM_TILE);
+  // Waves: ONE per group when that already gives ~2/3 of the chip's resident waves (2048 of
+  // 256 CUs x 4 SIMDs x 3): each streams its group's contiguous rows end to end and writes the
+  // final sums itself.  Same-buffer A/B at cfg5's size (4096 groups, 20 bins): 1 / 2 / 3 / 4 / 6
+  // / 8 key ranges per group = 3.15 / 3.57 / 4.58 / 3.74 / 4.85 / 3.42 ms (profiles/
+  // r04_lt_waves_ab.md) -- the split costs partial planes, a reduction and ragged last rounds.
+  // Smaller maps split the key range (powers of two, never finer than two keys per wave; the
+  // partial sums, nsplit x 32 planes, stay inside the moment paths' workspace of 1280 planes).
+  int nsplit = 1;
+  while (G * nsplit < RJP_LT_MIN_WAVES && 2 * nsplit <= mp.K &&
+         2 * nsplit <= RJP_MOM_MAX_IDX / RJP_MOM_TILE && G * nsplit < RJP_LT_WAVES)
+    nsplit *= 2;
+  const LtDirect dir{nsplit == 1 ? sumA : nullptr, fl->d_lt_aux, npix, n_epochs,
+                     mp.has_bursts[0], mp.has_bursts[1]};
   hipError_t err = hipErrorInvalidValue;
   switch (mp.N) {
-    case 8: err = lt_pass<8>(fl, mp, b, nsplit, G, npixp, mp.d_Wsel, ws, st); break;
-    case 12: err = lt_pass<12>(fl, mp, b, nsplit, G, npixp, mp.d_Wsel, ws, st); break;
-    case 16: err = lt_pass<16>(fl, mp, b, nsplit, G, npixp, mp.d_Wsel, ws, st); break;
-    case 20: err = lt_pass<20>(fl, mp, b, nsplit, G, npixp, mp.d_Wsel, ws, st); break;
-    case 24: err = lt_pass<24>(fl, mp, b, nsplit, G, npixp, mp.d_Wsel, ws, st); break;
-    case 28: err = lt_pass<28>(fl, mp, b, nsplit, G, npixp, mp.d_Wsel, ws, st); break;
-    case 32: err = lt_pass<32>(fl, mp, b, nsplit, G, npixp, mp.d_Wsel, ws, st); break;
+    case 8: err = lt_pass<8>(fl, mp, b, nsplit, G, npixp, mp.d_Wsel, ws, dir, st); break;
+    case 12: err = lt_pass<12>(fl, mp, b, nsplit, G, npixp, mp.d_Wsel, ws, dir, st); break;
+    case 16: err = lt_pass<16>(fl, mp, b, nsplit, G, npixp, mp.d_Wsel, ws, dir, st); break;
+    case 20: err = lt_pass<20>(fl, mp, b, nsplit, G, npixp, mp.d_Wsel, ws, dir, st); break;
+    case 24: err = lt_pass<24>(fl, mp, b, nsplit, G, npixp, mp.d_Wsel, ws, dir, st); break;
+    case 28: err = lt_pass<28>(fl, mp, b, nsplit, G, npixp, mp.d_Wsel, ws, dir, st); break;
+    case 32: err = lt_pass<32>(fl, mp, b, nsplit, G, npixp, mp.d_Wsel, ws, dir, st); break;
   }
-  if (err != hipSuccess) return err;
+  if (err != hipSuccess || nsplit == 1) return err;
   hipLaunchKernelGGL(lt_reduce_kernel, dim3((unsigned)((npix + 255) / 256), (unsigned)n_epochs),
                      dim3(256), 0, st, ws, nsplit, npix, npixp, n_epochs, fl->d_lt_aux,
                      mp.has_bursts[0], mp.has_bursts[1], sumA);
