@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define RJP_VERSION 108          /* 0.1.8 */
+#define RJP_VERSION 109          /* 0.1.9 */
 #define RJP_RANGE_BLOCKS 2048    /* partial (min, max) pairs rjp_field_range writes */
 #define RJP_MAX_EPOCH_TILE 32    /* most epochs evaluated per grid pass: 32 uniformly spaced ones (with or without d_em), 16 when only 16-31 are left, else tiles of 8, 4, 2, 1 */
 
@@ -111,8 +111,19 @@ typedef struct rjp_fields {
    * epochs (on the device) and the path is used only when every coefficient table is good to 1e-11
    * relative AND a cost model says it is the faster one (long, densely filled sightlines; else
    * the epoch tiles run, as before); sums are reproducible to rounding, not bit
-   * for bit (LDS atomics).  A range that does not contain every finite launch time gives wrong
-   * maps: pass what rjp_field_range returned for d_ts, or zeros.
+   * for bit (LDS atomics).  The range must contain every finite launch time of d_ts: pass what
+   * rjp_field_range returned for it, or zeros.
+   * LAUNCH-TIME RANGE GUARD (ABI 109).  The paths below clamp a launch time into their bins /
+   * table, so a range that misses some would give silently wrong maps -- the reference has no
+   * such failure mode (classes.py:844-845 evaluates every cell).  Therefore: (1) the first
+   * rjp_ff_scan / rjp_ff_step that uses a (d_ts, ts_lo, ts_hi) this context has not seen checks
+   * it with one pass over d_ts and ONE stream synchronisation (1.3 ms for 1.07e9 cells, once per
+   * model) and returns RJP_ERR_ARG with nothing enqueued when a finite launch time lies outside;
+   * rjp_lt_count does the same inside its counting pass; (2) every kernel that bins or tabulates
+   * by launch time watches the times it reads: a sightline that meets a finite one outside the
+   * range gets NaN sums (never a clamped, plausible-looking value) and the context's guard flag is
+   * raised -- the next entry point called on the context returns RJP_ERR_ARG once and enqueues
+   * nothing; rjp_range_guard() queries and clears the flag after a synchronisation.
    * The same range lets SINGLE-epoch scans of large f64 maps (>= 32768 sightlines, >= 64 rows; the
    * tau layout or the five model fields) take the burst factor chi(t - ts) from a table in LDS
    * instead of evaluating the Gaussians per cell: piecewise polynomials of degree 7 over the
@@ -261,6 +272,12 @@ int rjp_ff_scan(rjp_ctx* ctx, const rjp_fields* fields, const rjp_bursts* bursts
                 double* d_sumA, double* d_em, double* d_tavg,
                 void* d_work, size_t work_bytes, void* stream);
 
+/* Launch-time range guard (see rjp_fields.ts_lo): 1 = a kernel of this context has met a finite
+ * launch time outside fields.ts_lo / ts_hi since the last query (the sums of those sightlines are
+ * NaN); the flag is cleared.  0 = none.  Meaningful after the caller has synchronised the stream
+ * the scans ran on. */
+int rjp_range_guard(rjp_ctx* ctx);
+
 /* Which path the last rjp_ff_scan of this context took: 0 = epoch tiles, 1 = launch-time moments
  * in LDS + contraction, 2 = launch-time moments on the launch-time-ordered layout, 3 = the
  * single-epoch tau-layout scan with the burst factor from a table in LDS, 4 = contraction of the
@@ -313,6 +330,22 @@ int rjp_ff_maps(rjp_ctx* ctx, const double* d_sumA, const double* d_tavg, int64_
                 int32_t n_epochs, const double* h_ctau, const double* h_cflux, int32_t n_chan,
                 double* d_tau, double* d_flux, double* d_ftot,
                 void* d_work, size_t work_bytes, void* stream);
+
+/* ---- K1 + K2 from ONE call ----------------------------------------------------------------
+ * rjp_ff_scan followed by rjp_ff_maps on the same stream, for callers whose step is shorter than
+ * two round trips through their FFI (an x-slab of a sharded grid: 0.3 ms per step at 64 x 4096 x
+ * 512; a 256 x 1024 x 256 model: 0.2 ms): what JetModel.optical_depth_ff / flux_ff ask per epoch
+ * (classes.py:1375-1432, 1466-1541).  Arguments as for the two calls; d_tavg is the model's T_avg
+ * map (rjp_tavg: INPUT here, the scan derives none); d_em, d_tau, d_flux, d_ftot may be NULL.
+ * Every argument of both stages is validated before anything is enqueued.  d_work >=
+ * rjp_ff_scan_workspace(), d_work_maps >= rjp_ff_maps_workspace() (two buffers: the scan of the
+ * next step may overlap this step's map stage on another stream). */
+int rjp_ff_step(rjp_ctx* ctx, const rjp_fields* fields, const rjp_bursts* bursts,
+                const double* h_epochs_s, int32_t n_epochs, int32_t gff_mode,
+                const double* d_tavg, const double* h_ctau, const double* h_cflux, int32_t n_chan,
+                double* d_sumA, double* d_em, double* d_tau, double* d_flux, double* d_ftot,
+                void* d_work, size_t work_bytes, void* d_work_maps, size_t work_maps_bytes,
+                void* stream);
 
 /* ---- K3: recombination-line scan ------------------------------------------------------
  * Replaces JetModel.optical_depth_rrl (classes.py:1159-1214): per cell Doppler-shifted rest

@@ -18,7 +18,7 @@ RJP_F32, RJP_F64 = 4, 8
 RJP_GFF_SCALAR, RJP_GFF_POWERLAW = 0, 1
 RJP_MAX_EPOCH_TILE = 32
 RJP_RANGE_BLOCKS = 2048
-RJP_VERSION = 108             # include/rjprt.h; the binding below matches exactly this ABI
+RJP_VERSION = 109             # include/rjprt.h; the binding below matches exactly this ABI
 RJP_OK = 0
 RJP_ERR_ARG, RJP_ERR_HIP, RJP_ERR_NODEVICE, RJP_ERR_WORKSPACE, RJP_ERR_DEGENERATE = \
     -1, -2, -3, -4, -5
@@ -96,6 +96,7 @@ SIGNATURES = {
     "rjp_ff_scan_workspace": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
     "rjp_ff_scan": (C.c_int, [_P, C.POINTER(Fields), C.POINTER(Bursts), _DP, C.c_int32,
                               C.c_int32, _P, _P, _P, _P, C.c_size_t, _P]),
+    "rjp_range_guard": (C.c_int, [_P]),
     "rjp_last_scan_path": (C.c_int, [_P, _DP, C.POINTER(C.c_int32)]),
     "rjp_last_table_build_ms": (C.c_double, [_P]),
     "rjp_moment_cache_bytes": (C.c_size_t, [C.c_int32, C.c_int32]),
@@ -105,6 +106,9 @@ SIGNATURES = {
     "rjp_ff_maps_workspace": (C.c_size_t, [C.c_int64, C.c_int32, C.c_int32]),
     "rjp_ff_maps": (C.c_int, [_P, _P, _P, C.c_int64, C.c_int32, _DP, _DP, C.c_int32,
                               _P, _P, _P, _P, C.c_size_t, _P]),
+    "rjp_ff_step": (C.c_int, [_P, C.POINTER(Fields), C.POINTER(Bursts), _DP, C.c_int32,
+                              C.c_int32, _P, _DP, _DP, C.c_int32, _P, _P, _P, _P, _P,
+                              _P, C.c_size_t, _P, C.c_size_t, _P]),
     "rjp_rrl_scan": (C.c_int, [_P, C.POINTER(Fields), C.POINTER(Bursts), C.c_double,
                                C.POINTER(Line), _DP, C.c_int32, _P, _P]),
     "rjp_ff_cells": (C.c_int, [_P, C.POINTER(Fields), C.POINTER(Bursts), C.c_double, C.c_int32,

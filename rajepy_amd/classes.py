@@ -369,7 +369,13 @@ class JetModel:
                 self.log.add_entry("INFO", "Calculating cells' fill factors/projected areas")
             then = _time.time()
             geom = geometry_struct(self.params, self.nx, self.ny, self.nz)
-            self._dev = build_model_fields(self, geom)
+            # LEAN first (f64 storage): the continuum path reads a0, em0, temp, ts -- four
+            # grid-sized arrays; nd / xi / pf / vy are built by the first call that needs them
+            # (`_wide_fields`: RRL, collapse=False, grid accessors, the xi / vel setters), as
+            # the reference's lazy properties do (classes.py:571-1000)
+            eng = self.engine
+            lean = self._dtype == _lib.RJP_F64 and eng.use_compact and eng.use_tau
+            self._dev = build_model_fields(self, geom, want_wide=not lean, want_vy=not lean)
             # a jet fills a few per cent of its grid: record each sightline's occupied rows
             # once so that every later scan touches only those
             self.engine.compute_y_bounds(self._dev)
@@ -378,6 +384,13 @@ class JetModel:
                 self.log.add_entry("INFO", _time.strftime(
                     'Finished in %Hh%Mm%Ss', _time.gmtime(_time.time() - then)))
         return self._dev
+
+    def _wide_fields(self):
+        """`device_fields` with nd, xi, pf and vy resident (built on first need)."""
+        dev = self.device_fields
+        if dev.nd is None or dev.xi is None or dev.pf is None or dev.vy is None:
+            self.engine.build_wide(dev, geometry_struct(self.params, self.nx, self.ny, self.nz))
+        return dev
 
     def _host_launch_times(self, x0=0, x1=None):
         """Launch times [s] of rows [x0, x1) of the grid evaluated on the host with scipy's
@@ -462,13 +475,13 @@ class JetModel:
     @property
     def fill_factor(self):
         return self._grid(self.device_fields.ff_raw) if self.device_fields.ff_raw is not None \
-            else self._grid(self.device_fields.pf)
+            else self._grid(self._wide_fields().pf)
 
     @property
     def areas(self):
         d = self.device_fields
         return self._grid(d.areas_raw) if d.areas_raw is not None else \
-            np.where(np.isnan(self._grid(d.pf)), np.nan, 1.0)
+            np.where(np.isnan(self._grid(self._wide_fields().pf)), np.nan, 1.0)
 
     @property
     def ts(self):
@@ -482,11 +495,11 @@ class JetModel:
 
     @property
     def ion_fraction(self):
-        return self._grid(self.device_fields.xi)
+        return self._grid(self._wide_fields().xi)
 
     @ion_fraction.setter
     def ion_fraction(self, new_xis):
-        self.engine.replace_field(self.device_fields, "xi", new_xis)
+        self.engine.replace_field(self._wide_fields(), "xi", new_xis)
         self._invalidate()
 
     @property
@@ -501,13 +514,13 @@ class JetModel:
     @property
     def chi_xyz(self):
         """Burst factor per cell (classes.py:861-870)."""
-        red = np.signbit(self._grid(self.device_fields.nd))
+        red = np.signbit(self._grid(self._wide_fields().nd))
         tl = self.ts
         return np.where(red, self._chi_host('R', tl), self._chi_host('B', tl))
 
     @property
     def number_density(self):
-        return np.abs(self._grid(self.device_fields.nd)) * self.chi_xyz
+        return np.abs(self._grid(self._wide_fields().nd)) * self.chi_xyz
 
     @property
     def vel(self):
@@ -518,7 +531,7 @@ class JetModel:
             tmp = self.engine.build_fields(geom, _lib.RJP_F64, want_ts=False, want_vy=False,
                                            want_raw=False, want_vxz=True)
             self._vxz = (self._grid(tmp.vx_raw), self._grid(tmp.vz_raw))
-        return self._vxz[0], self._grid(self.device_fields.vy), self._vxz[1]
+        return self._vxz[0], self._grid(self._wide_fields().vy), self._vxz[1]
 
     @vel.setter
     def vel(self, new_vs):
@@ -530,7 +543,7 @@ class JetModel:
         vx, vy, vz = (np.asarray(v, dtype=np.float64) for v in (vx, vy, vz))
         if not (vx.shape == vy.shape == vz.shape == shape):
             raise ValueError("velocity grids must have the model's shape {}".format(shape))
-        self.engine.replace_field(self.device_fields, "vy", vy)
+        self.engine.replace_field(self._wide_fields(), "vy", vy)
         self._vxz = (vx.copy(), vz.copy())
         self._invalidate()
 
@@ -613,7 +626,7 @@ class JetModel:
             raise ValueError("Unexpected number of data dimensions (4)")
         scalar = np.isscalar(freq)
         freqs = np.atleast_1d(np.asarray(freq, dtype=np.float64))
-        dev = self.device_fields
+        dev = self._wide_fields()
         if rrl is None:
             gv = None
             if self.gff_mode == _lib.RJP_GFF_SCALAR:
@@ -685,7 +698,7 @@ class JetModel:
         if self._rrl_cache is not None and self._rrl_cache[0] == key:
             return self._rrl_cache[1]
         line = _lib.Line(**mrrl.line_constants(rrl))
-        tau = self.engine.rrl_scan(self.device_fields, self._rjp_bursts(), float(self.time),
+        tau = self.engine.rrl_scan(self._wide_fields(), self._rjp_bursts(), float(self.time),
                                    line, freqs)
         self._rrl_cache = (key, tau)
         return tau

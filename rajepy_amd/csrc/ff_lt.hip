@@ -57,7 +57,8 @@ size_t lt_rowoff_entries(int nx, int nz, int K) {
 __global__ __launch_bounds__(256) void lt_count_kernel(const double* __restrict__ a0,
                                                        const double* __restrict__ ts, int ny,
                                                        int nz, int64_t npix, LtBins b,
-                                                       int32_t* __restrict__ rows) {
+                                                       int32_t* __restrict__ rows,
+                                                       int* __restrict__ guard) {
   extern __shared__ unsigned lt_cnt[];        // [Q][64]
   const int Q = 2 * b.K;
   for (int i = threadIdx.x; i < Q * kLtLanes; i += 256) lt_cnt[i] = 0;
@@ -79,8 +80,13 @@ __global__ __launch_bounds__(256) void lt_count_kernel(const double* __restrict_
       }
 #pragma unroll
       for (int u = 0; u < 8; ++u)
-        if (y0 + 4 * u < ny && lt_keeps(a[u], t[u]))
+        if (y0 + 4 * u < ny && lt_keeps(a[u], t[u])) {
+          // range guard (include/rjprt.h): the bins cover [ts_lo, ts_hi] only; rjp_lt_count
+          // reports a kept cell outside them instead of building a layout with clamped bins
+          const double kw = __builtin_floor((t[u] - b.s0) * b.inv_h);
+          if ((kw < 0.0 || kw > (double)b.K) && __builtin_fabs(kw) < __builtin_inf()) *guard = 1;
           atomicAdd(&lt_cnt[lt_key(a[u], t[u], b) * kLtLanes + lane], 1u);
+        }
     }
   }
   __syncthreads();
@@ -170,14 +176,15 @@ __global__ __launch_bounds__(64) void lt_fill_kernel(const double* __restrict__ 
   }
 }
 
-hipError_t lt_count_launch(const rjp_fields* fl, int K, int32_t* d_rowoff, hipStream_t st) {
+hipError_t lt_count_launch(const rjp_fields* fl, int K, int32_t* d_rowoff, int* d_guard,
+                           hipStream_t st) {
   const int64_t npix = (int64_t)fl->nx * fl->nz;
   const int64_t G = (npix + kLtLanes - 1) / kLtLanes;
   const double span = fl->ts_hi - fl->ts_lo;
   const LtBins b{fl->ts_lo, span > 0.0 ? K / span : 1.0, K};
   hipLaunchKernelGGL(lt_count_kernel, dim3((unsigned)G), dim3(256), (size_t)2 * K * kLtLanes * 4, st,
                      (const double*)fl->d_a0, (const double*)fl->d_ts, fl->ny, fl->nz, npix, b,
-                     d_rowoff);
+                     d_rowoff, d_guard);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(lt_scan_kernel, dim3(1), dim3(1024), 0, st, d_rowoff, G * 2 * K);
@@ -334,7 +341,7 @@ static hipError_t lt_pass(const rjp_fields* fl, const MomPlan& mp, const LtBins&
 }
 
 hipError_t lt_run(const rjp_fields* fl, const MomPlan& mp, int n_epochs, double* sumA, double* ws,
-                  hipStream_t st) {
+                  size_t work_bytes, hipStream_t st) {
   if (n_epochs > RJP_LT_MAX_EPOCHS || mp.K != fl->lt_K) return hipErrorInvalidValue;
   const int64_t npix = (int64_t)fl->nx * fl->nz;
   const int64_t G = (npix + kLtLanes - 1) / kLtLanes, npixp = G * kLtLanes;
@@ -345,11 +352,15 @@ hipError_t lt_run(const rjp_fields* fl, const MomPlan& mp, int n_epochs, double*
   // / 8 key ranges per group = 3.15 / 3.57 / 4.58 / 3.74 / 4.85 / 3.42 ms (profiles/
   // r04_lt_waves_ab.md) -- the split costs partial planes, a reduction and ragged last rounds.
   // Smaller maps split the key range (powers of two, never finer than two keys per wave; the
-  // partial sums, nsplit x 32 planes, stay inside the moment paths' workspace of 1280 planes).
+  // partial sums are nsplit x 32 planes of npixp = 64 G doubles: never more than the CALLER'S
+  // workspace holds -- on tiny maps 64 G exceeds the 16-sightline padding the moment paths'
+  // workspace is sized with).
   int nsplit = 1;
   while (G * nsplit < RJP_LT_MIN_WAVES && 2 * nsplit <= mp.K &&
-         2 * nsplit <= RJP_MOM_MAX_IDX / RJP_MOM_TILE && G * nsplit < RJP_LT_WAVES)
+         2 * nsplit <= RJP_MOM_MAX_IDX / RJP_MOM_TILE && G * nsplit < RJP_LT_WAVES &&
+         (size_t)2 * nsplit * RJP_MOM_TILE * npixp * sizeof(double) <= work_bytes)
     nsplit *= 2;
+  if (nsplit > 1 && !ws) return hipErrorInvalidValue;
   const LtDirect dir{nsplit == 1 ? sumA : nullptr, fl->d_lt_aux, npix, n_epochs,
                      mp.has_bursts[0], mp.has_bursts[1]};
   hipError_t err = hipErrorInvalidValue;

@@ -56,6 +56,7 @@ constexpr int kMomNShapes = sizeof(kMomShapes) / sizeof(kMomShapes[0]);
 struct MomDev {
   double s0, inv_h;
   int has_bursts[2];
+  int* guard;      // range guard: raised by a weighted cell whose launch time is outside the bins
 };
 
 template <int K, int N>
@@ -103,7 +104,14 @@ __global__ __launch_bounds__(kMomBS) void moments_kernel(const double* __restric
     }
     if (am != 0.0) {
       const double w = (tv - md.s0) * md.inv_h;
-      const double kf = __builtin_fmin(__builtin_fmax(__builtin_floor(w), 0.0), (double)(K - 1));
+      const double kw = __builtin_floor(w);
+      const double kf = __builtin_fmin(__builtin_fmax(kw, 0.0), (double)(K - 1));
+      // range guard (include/rjprt.h): bins cover [ts_lo, ts_hi] only (kw == K: ts == ts_hi); a
+      // finite launch time outside poisons the sightline with NaN and raises the context's flag
+      if ((kw < 0.0 || kw > (double)K) && __builtin_fabs(kw) < __builtin_inf()) {
+        *md.guard = 1;
+        am = __builtin_nan("");
+      }
       const double xi = __builtin_fma(2.0, w - kf, -1.0);
       double* base = s_mom + (((red ? 0 : K) + (int)kf) * N) * SL + sl;
       // the recurrence runs on the WEIGHTED polynomials t_n = am T_n(xi) (it is linear): no
@@ -113,7 +121,7 @@ __global__ __launch_bounds__(kMomBS) void moments_kernel(const double* __restric
       // (an infinite term -- T = 0 makes T^-1.5 infinite, and the reference's sum with it --
       // goes into the zeroth moment only: its coefficient is the bin average of chi^2 > 0,
       // so the sightline comes out +inf as in the tiles, not inf * T_n(xi) = NaN)
-      if (am <= 1.7976931348623157e308) {
+      if (am <= 1.7976931348623157e308) {           // (false for the guard's NaN as well)
         atomicAdd(base + SL, tc);
         const double x2 = 2.0 * xi;
 #pragma unroll
@@ -211,6 +219,30 @@ hipError_t field_range_launch(const void* d_field, int64_t n, int dtype, double*
   else
     hipLaunchKernelGGL(field_range_kernel<float>, dim3(RJP_RANGE_BLOCKS), dim3(256), 0, st,
                        (const float*)d_field, n, d_part);
+  return hipGetLastError();
+}
+
+// any finite entry outside [lo, hi]?  -> *flag = 1 (the range guard's check of a new range)
+template <typename T>
+__global__ __launch_bounds__(256) void range_check_kernel(const T* __restrict__ f, int64_t n,
+                                                          double lo, double hi,
+                                                          int* __restrict__ flag) {
+  bool bad = false;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const double v = (double)__builtin_nontemporal_load(f + i);
+    bad |= (v < lo || v > hi) && __builtin_fabs(v) < __builtin_inf();
+  }
+  if (bad) *flag = 1;
+}
+
+hipError_t range_check_launch(const void* d_field, int64_t n, int dtype, double lo, double hi,
+                              int* d_flag, hipStream_t st) {
+  if (dtype == RJP_F64)
+    hipLaunchKernelGGL(range_check_kernel<double>, dim3(RJP_RANGE_BLOCKS * 4), dim3(256), 0, st,
+                       (const double*)d_field, n, lo, hi, d_flag);
+  else
+    hipLaunchKernelGGL(range_check_kernel<float>, dim3(RJP_RANGE_BLOCKS * 4), dim3(256), 0, st,
+                       (const float*)d_field, n, lo, hi, d_flag);
   return hipGetLastError();
 }
 
@@ -484,18 +516,15 @@ hipError_t moments_build(MomPlan& mp, const double* d_stage, hipStream_t st) {
 
 template <int K, int N>
 static hipError_t moments_pass(const rjp_fields* fl, const double* weights, const MomDev& md,
-                               int64_t npix, int64_t npixp, double* ws, hipStream_t st) {
+                               int64_t npix, int64_t npixp, double* ws, bool& attr_set,
+                               hipStream_t st) {
   const size_t shm = (size_t)2 * K * N * kMomSL * sizeof(double);
-  // (more than 64 KB of dynamic LDS must be allowed explicitly, once per device of the process)
-  static int attr_dev = -1;
-  int dev = -1;
-  hipError_t e = hipGetDevice(&dev);
-  if (e != hipSuccess) return e;
-  if (dev != attr_dev) {
-    e = hipFuncSetAttribute((const void*)moments_kernel<K, N>,
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+  // (more than 64 KB of dynamic LDS must be allowed explicitly: once per context, i.e. per device)
+  if (!attr_set) {
+    const hipError_t e = hipFuncSetAttribute((const void*)moments_kernel<K, N>,
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
     if (e != hipSuccess) return e;
-    attr_dev = dev;
+    attr_set = true;
   }
   hipLaunchKernelGGL((moments_kernel<K, N>), dim3((unsigned)(npixp / kMomSL)), dim3(kMomBS), shm,
                      st, weights, (const double*)fl->d_ts, fl->d_ylo, fl->d_yhi,
@@ -508,19 +537,20 @@ static hipError_t moments_pass(const rjp_fields* fl, const double* weights, cons
 // constant factor of the result (1 for the sums of a0).
 hipError_t moments_run(const rjp_fields* fl, const MomPlan& mp, int n_epochs,
                        double* sumA, double* ws, hipStream_t st, const double* weights,
-                       double scale, bool skip_pass) {
+                       double scale, int* d_guard, bool skip_pass) {
   const double* d_W = mp.d_Wsel;
   const int64_t npix = (int64_t)fl->nx * fl->nz;
   const int64_t npixp = (npix + kMomSL - 1) / kMomSL * kMomSL;
   MomDev md;
   md.s0 = mp.s0; md.inv_h = mp.inv_h;
   md.has_bursts[0] = mp.has_bursts[0]; md.has_bursts[1] = mp.has_bursts[1];
+  md.guard = d_guard;
   // `skip_pass`: `ws` already holds this model's moment maps of this shape (a caller-kept cache)
   hipError_t err = skip_pass ? hipSuccess : hipErrorInvalidValue;
   if (skip_pass) {}
-  else if (mp.K == 80 && mp.N == 8) err = moments_pass<80, 8>(fl, weights, md, npix, npixp, ws, st);
-  else if (mp.K == 53 && mp.N == 12) err = moments_pass<53, 12>(fl, weights, md, npix, npixp, ws, st);
-  else if (mp.K == 39 && mp.N == 16) err = moments_pass<39, 16>(fl, weights, md, npix, npixp, ws, st);
+  else if (mp.K == 80 && mp.N == 8) err = moments_pass<80, 8>(fl, weights, md, npix, npixp, ws, mp.attr_set[0], st);
+  else if (mp.K == 53 && mp.N == 12) err = moments_pass<53, 12>(fl, weights, md, npix, npixp, ws, mp.attr_set[1], st);
+  else if (mp.K == 39 && mp.N == 16) err = moments_pass<39, 16>(fl, weights, md, npix, npixp, ws, mp.attr_set[2], st);
   if (err != hipSuccess) return err;
   const int nidx = 2 * mp.K * mp.N;
   for (int c = 0; c < mp.nchunk; ++c) {

@@ -503,6 +503,8 @@ size_t ff_scan_workspace_bytes(int nx, int ny, int nz, int n_epochs) {
   }
   // (an n_epochs that is no tile size itself is cut into tiles no larger than it)
   size_t bytes = (size_t)need * npix * sizeof(double) + 256;
+  // the single-epoch table scan has its own y-range rule and keeps its table here (ff_scan_tab.hip)
+  bytes = std::max(bytes, chi_table_workspace_bytes(npix, ny));
   // sweeps long enough for the moment path (ff_moments.hip) keep its transposed moments here
   // (10 KiB per sightline; maps so large that this passes 6 GiB stay on the epoch tiles)
   if (n_epochs >= RJP_MOM_MIN_EPOCHS && moments_workspace_bytes(npix) <= ((size_t)6 << 30))

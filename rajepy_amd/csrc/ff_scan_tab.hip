@@ -59,7 +59,18 @@ struct ChiTabDev {
   double lo, inv_h;
   double wmax;     // the largest double below ni: a cell launched exactly at ts_lo (w == ni)
                    // belongs to the last interval, xi -> 1
+  // range guard (include/rjprt.h "Launch-time range guard"): the table covers the times since
+  // launch of [ts_lo, ts_hi] only and the lookup clamps -- a lane that meets a finite launch time
+  // outside the range poisons its sums with NaN and raises the context's flag
+  double ts_lo, ts_hi;
+  int* guard;
 };
+
+// one lane's verdict at the end of its column: `tmin` / `tmax` = fmin / fmax over the launch
+// times it read (NaN ignored; an infinite launch time is the reference's chi == 1, not a breach)
+__device__ __forceinline__ bool ts_range_breach(const ChiTabDev& t, double tmin, double tmax) {
+  return (tmin < t.ts_lo && tmin > -__builtin_inf()) || (tmax > t.ts_hi && tmax < __builtin_inf());
+}
 
 // table builder: one thread per (jet, interval); tab[(jet * ni + k) * kChiStride + c]
 // stage = [Vandermonde inverse 8 x 8][nodes 8][jet 0: t0.., amp.., inv2s2..][jet 1: ...]
@@ -148,6 +159,7 @@ __global__ __launch_bounds__(kBlock) void ff_scan_table_kernel(
     return chi * chi;
   };
   double acc[VEC] = {0.0, 0.0}, accE[VEC] = {0.0, 0.0};
+  double tmin = __builtin_inf(), tmax = -__builtin_inf();
   int64_t off = (x * ny + y0) * (int64_t)nz + z;
   int y = y0;
   for (; y + U <= y1; y += U) {
@@ -163,6 +175,8 @@ __global__ __launch_bounds__(kBlock) void ff_scan_table_kernel(
 #pragma unroll
       for (int v = 0; v < VEC; ++v) {
         const double c2 = chi2(a[u][v], tt[u][v]);
+        tmin = __builtin_fmin(tmin, tt[u][v]);
+        tmax = __builtin_fmax(tmax, tt[u][v]);
         acc[v] = __builtin_fma(keep_if_ordered(__builtin_fabs(a[u][v]), tt[u][v]), c2, acc[v]);
         if (EM) accE[v] = __builtin_fma(keep_if_ordered(__builtin_fabs(g[u][v]), tt[u][v]), c2, accE[v]);
       }
@@ -176,10 +190,17 @@ __global__ __launch_bounds__(kBlock) void ff_scan_table_kernel(
 #pragma unroll
     for (int v = 0; v < VEC; ++v) {
       const double c2 = chi2(a[v], tt[v]);
+      tmin = __builtin_fmin(tmin, tt[v]);
+      tmax = __builtin_fmax(tmax, tt[v]);
       acc[v] = __builtin_fma(keep_if_ordered(__builtin_fabs(a[v]), tt[v]), c2, acc[v]);
       if (EM) accE[v] = __builtin_fma(keep_if_ordered(__builtin_fabs(g[v]), tt[v]), c2, accE[v]);
     }
     off += nz;
+  }
+  if (ts_range_breach(t, tmin, tmax)) {
+    *t.guard = 1;
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) { acc[v] = __builtin_nan(""); accE[v] = __builtin_nan(""); }
   }
   double* w = out + (int64_t)split * out_split_stride + p0;
 #pragma unroll
@@ -248,6 +269,7 @@ __global__ __launch_bounds__(kBlock) void ff_scan_table_wide_kernel(
     return chi * chi;
   };
   double accA[VEC] = {0.0, 0.0}, accE[VEC] = {0.0, 0.0}, accT[VEC] = {0.0, 0.0};
+  double tmin = __builtin_inf(), tmax = -__builtin_inf();
   int cnt[VEC] = {0, 0};
   auto rows = [&](auto utag, int64_t off) __attribute__((always_inline)) {
     constexpr int UU = decltype(utag)::value;
@@ -278,6 +300,8 @@ __global__ __launch_bounds__(kBlock) void ff_scan_table_wide_kernel(
         const double n0 = __builtin_fabs(nd[u][v]) * xi[u][v];
         const double g = poison_unless(n0 * n0 * pf[u][v], tt[u][v] == tt[u][v]);
         const double c2 = chi2(signbit_d(nd[u][v]), tt[u][v]);
+        tmin = __builtin_fmin(tmin, tt[u][v]);
+        tmax = __builtin_fmax(tmax, tt[u][v]);
         accE[v] = __builtin_fma(nan_to_zero<false>(g), c2, accE[v]);
         accA[v] = __builtin_fma(nan_to_zero<false>(g * tpw[u][v]), c2, accA[v]);
       }
@@ -291,6 +315,11 @@ __global__ __launch_bounds__(kBlock) void ff_scan_table_wide_kernel(
   for (; y < y1; ++y) {
     rows(std::integral_constant<int, 1>{}, off);
     off += nz;
+  }
+  if (ts_range_breach(t, tmin, tmax)) {
+    *t.guard = 1;
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) { accA[v] = __builtin_nan(""); accE[v] = __builtin_nan(""); }
   }
   if (nsplit == 1) {
 #pragma unroll
@@ -414,9 +443,30 @@ bool chi_table_plan(const rjp_fields* fl, const rjp_bursts* hb, const double* ep
   return true;
 }
 
+// y-ranges of the table scan on a map of `npix` sightlines and `ny` rows: one when the sightline
+// chunks alone give every CU two workgroups, else as many as it takes (powers of two, >= 64 rows
+// each; the partials are reduced in ff_reduce_kernel's fixed order)
+static int chi_table_nsplit(int64_t npix, int ny, bool wide) {
+  const int64_t wgs = (npix / 2 + kBlock - 1) / kBlock;
+  int nsplit = 1;
+  while (wgs * nsplit < RJP_TAB_WGS && nsplit * 2 * 64 <= ny && nsplit < (wide ? 8 : 16)) nsplit *= 2;
+  return nsplit;
+}
+
+// Workspace of the table path (part of rjp_ff_scan_workspace): the tau-layout scan writes planes
+// 0-1 of nacc(1) = 4 planes per y-range and keeps its table in planes 2-3 of the first range; the
+// wide scan fills all four planes of its <= 8 ranges and keeps the table behind them.
+size_t chi_table_workspace_bytes(int64_t npix, int ny) {
+  if (npix / 2 < 64 * 256 || ny < 64) return 0;            // (chi_table_plan's size rule)
+  const size_t tab = (size_t)2 * kChiMaxNI * kChiStride * sizeof(double);
+  const size_t tau = (size_t)chi_table_nsplit(npix, ny, false) * nacc(1) * npix * sizeof(double);
+  const size_t wide = (size_t)32 * npix * sizeof(double) + tab;
+  return std::max(tau, wide);
+}
+
 hipError_t chi_table_scan(const rjp_fields* fl, const ChiPlan& cp, const double* d_stage,
                           double t_epoch, int mode, double* sumA, double* em, double* tavg,
-                          double* ws, size_t work_bytes, hipStream_t st) {
+                          double* ws, size_t work_bytes, int* d_guard, hipStream_t st) {
   const int64_t npix = (int64_t)fl->nx * fl->nz;
   const int64_t nchunks = npix / 2;
   const size_t tab_doubles = (size_t)2 * cp.ni * kChiStride;
@@ -424,27 +474,25 @@ hipError_t chi_table_scan(const rjp_fields* fl, const ChiPlan& cp, const double*
     return hipErrorInvalidValue;
   // plane 2 of the first y-range (see the plan); behind the 8 x 4 planes of the wide scan
   double* d_tab = ws + (cp.wide ? 32 : 2) * npix;
-  ChiTabDev t{cp.ni, cp.lo, cp.inv_h, std::nextafter((double)cp.ni, 0.0)};
+  if (cp.wide && work_bytes < (32 * npix + tab_doubles) * sizeof(double)) return hipErrorInvalidValue;
+  ChiTabDev t{cp.ni, cp.lo, cp.inv_h, std::nextafter((double)cp.ni, 0.0), fl->ts_lo, fl->ts_hi,
+              d_guard};
   hipLaunchKernelGGL(chi_table_kernel, dim3((unsigned)((2 * cp.ni + 255) / 256)), dim3(256), 0, st,
                      d_stage, cp.n[0], cp.n[1], t, d_tab);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
-  // one y-range when the sightline chunks alone give every CU two workgroups; else as many ranges
-  // as it takes (partials reduced by ff_reduce_kernel's order: plane 0 of nacc(1) planes)
   const int64_t wgs = (nchunks + kBlock - 1) / kBlock;
-  int nsplit = 1;
-  while (wgs * nsplit < RJP_TAB_WGS && nsplit * 2 * 64 <= fl->ny && nsplit < (cp.wide ? 8 : 16))
-    nsplit *= 2;
+  // never more y-ranges than the CALLER'S workspace holds (a workspace of rjp_ff_scan_workspace()
+  // bytes holds them all; ADVICE r04: the rule used to be checked against nothing)
+  int nsplit = chi_table_nsplit(npix, fl->ny, cp.wide);
+  while (nsplit > 1 && (size_t)nsplit * nacc(1) * npix * sizeof(double) > work_bytes) nsplit /= 2;
   const int ylen = (fl->ny + nsplit - 1) / nsplit;
   const size_t shm = tab_doubles * sizeof(double);
   // em = sum (n x)^2 * csize*au/pc * pf  (classes.py:1116-1118)
   const double em_scale = fl->csize_au * 149597870700.0 / 3.085677581491367e+16;
-  static int attr_dev = -1;
-  int dev = -1;
-  e = hipGetDevice(&dev);
-  if (e != hipSuccess) return e;
+  // (per context = per device: a context is bound to one device and used by one host thread)
   constexpr int kMaxShm = 2 * kChiMaxNI * kChiStride * (int)sizeof(double);
-  if (dev != attr_dev) {
+  if (!cp.attr_set) {
     e = hipFuncSetAttribute((const void*)ff_scan_table_wide_kernel<RJP_TAB_U_WIDE, 0>,
                             hipFuncAttributeMaxDynamicSharedMemorySize, kMaxShm);
     if (e != hipSuccess) return e;
@@ -457,7 +505,7 @@ hipError_t chi_table_scan(const rjp_fields* fl, const ChiPlan& cp, const double*
     e = hipFuncSetAttribute((const void*)ff_scan_table_kernel<RJP_TAB_U_EM, true>,
                             hipFuncAttributeMaxDynamicSharedMemorySize, kMaxShm);
     if (e != hipSuccess) return e;
-    attr_dev = dev;
+    cp.attr_set = true;
   }
   const dim3 grid((unsigned)(wgs * nsplit));
   if (cp.wide) {

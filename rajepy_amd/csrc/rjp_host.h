@@ -71,12 +71,14 @@ struct ChiPlan {
   int ni = 0, n[2] = {0, 0};
   double lo = 0.0, inv_h = 0.0;
   std::vector<double> stage;      // Vandermonde inverse, nodes, burst parameters
+  mutable bool attr_set = false;  // the kernels' dynamic-LDS limit was raised on this context's device
 };
+size_t chi_table_workspace_bytes(int64_t npix, int ny);
 bool chi_table_plan(const rjp_fields* fl, const rjp_bursts* hb, const double* epochs, int n_epochs,
                     int mode, bool want_em, size_t work_bytes, ChiPlan& cp);
 hipError_t chi_table_scan(const rjp_fields* fl, const ChiPlan& cp, const double* d_stage,
                           double t_epoch, int mode, double* sumA, double* em, double* tavg,
-                          double* ws, size_t work_bytes, hipStream_t st);
+                          double* ws, size_t work_bytes, int* d_guard, hipStream_t st);
 
 // ---- ff_moments.hip: epoch sweeps by launch-time moments --------------------------------------
 #define RJP_MOM_MAX_IDX 1280      /* 2 jets x K bins x N Chebyshev moments <= this (160 KB of LDS
@@ -115,6 +117,7 @@ struct MomPlan {
   bool key_ok = false;
   double key_lo = 0.0, key_hi = 0.0;
   std::vector<double> key_epochs, key_bursts;
+  mutable bool attr_set[3] = {false, false, false};   // dynamic-LDS limit raised, per LDS shape
 };
 size_t moments_workspace_bytes(int64_t npix);
 // 0 = this scan keeps the epoch tiles, 1 = moment path with the tables already on the device,
@@ -128,18 +131,21 @@ hipError_t moments_build(MomPlan& mp, const double* d_stage, hipStream_t st);
 void moments_release(MomPlan& mp);
 hipError_t moments_run(const rjp_fields* fl, const MomPlan& mp, int n_epochs,
                        double* sumA, double* ws, hipStream_t st, const double* weights,
-                       double scale, bool skip_pass = false);
+                       double scale, int* d_guard, bool skip_pass = false);
 // launch-time-ordered layout (ff_lt.hip)
 #define RJP_LT_MAX_K 80
 #define RJP_LT_MAX_EPOCHS 32     /* one fused pass serves one contraction tile */
 size_t lt_rowoff_entries(int nx, int nz, int K);
-hipError_t lt_count_launch(const rjp_fields* fl, int K, int32_t* d_rowoff, hipStream_t st);
+hipError_t lt_count_launch(const rjp_fields* fl, int K, int32_t* d_rowoff, int* d_guard,
+                           hipStream_t st);
 hipError_t lt_fill_launch(const rjp_fields* fl, int K, const int32_t* d_rowoff, void* d_cells,
                           double* d_aux, hipStream_t st);
 hipError_t lt_run(const rjp_fields* fl, const MomPlan& mp, int n_epochs, double* sumA, double* ws,
-                  hipStream_t st);
+                  size_t work_bytes, hipStream_t st);
 hipError_t field_range_launch(const void* d_field, int64_t n, int dtype, double* d_part,
                               hipStream_t st);
+hipError_t range_check_launch(const void* d_field, int64_t n, int dtype, double lo, double hi,
+                              int* d_flag, hipStream_t st);
 
 // ---- ff_scan_inst.hip: one slice of the K1 kernel family per translation unit -------------
 #define RJP_SCAN_SLICE_ARGS                                                                  \

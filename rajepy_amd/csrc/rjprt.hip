@@ -36,6 +36,18 @@ struct rjp_ctx {
   int next_slot = 0;
   int cur_slot = 0;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  // Launch-time range guard (include/rjprt.h): one int in pinned, device-visible host memory.
+  // Kernels that bin or tabulate by launch time store 1 into it when they meet a finite launch
+  // time outside rjp_fields.ts_lo / ts_hi (and poison that sightline's sums with NaN); the next
+  // entry point of the context reports it.  `range_ok`: the ranges rjp_ff_scan has already
+  // checked against their launch-time field with a pass of its own (most recent first).
+  int* guard = nullptr;
+  struct RangeKey {
+    const void* d_ts = nullptr;
+    int64_t n = 0;
+    int dtype = 0;
+    double lo = 0.0, hi = 0.0;
+  } range_ok[4];
 };
 
 static std::string g_create_err;
@@ -56,10 +68,46 @@ static int fail(rjp_ctx* ctx, int code, const char* what, hipError_t e = hipSucc
     if (_e != hipSuccess) return fail((ctx), RJP_ERR_HIP, #call, _e);   \
   } while (0)
 
+static const char* const kGuardMsg =
+    "an earlier scan of this context met finite launch times outside fields.ts_lo / ts_hi: the "
+    "sums of those sightlines were set to NaN (pass what rjp_field_range returns for d_ts, or "
+    "zeros)";
+
 static int bind(rjp_ctx* ctx) {
   if (!ctx) return fail(nullptr, RJP_ERR_ARG, "null context");
   hipError_t e = hipSetDevice(ctx->device);
   if (e != hipSuccess) return fail(ctx, RJP_ERR_HIP, "hipSetDevice", e);
+  // the range guard is sticky until reported once (a kernel of an earlier, asynchronous call
+  // raised it; whatever this call would enqueue is refused)
+  if (ctx->guard && *(volatile int*)ctx->guard != 0) {
+    *(volatile int*)ctx->guard = 0;
+    for (auto& k : ctx->range_ok) k = rjp_ctx::RangeKey();
+    return fail(ctx, RJP_ERR_ARG, kGuardMsg);
+  }
+  return RJP_OK;
+}
+
+// A scan is about to bin / tabulate by launch time on the strength of fields.ts_lo / ts_hi: a
+// range this context has not seen with this launch-time field is CHECKED first -- one pass over
+// d_ts (8 B/cell: 1.3 ms for 1.07e9 cells) and one stream synchronisation, once per model -- so
+// that a wrong range is refused by the very call that passes it, before anything else is
+// enqueued.  (Later content changes under the same pointer are caught by the kernels' guard.)
+static int check_ts_range(rjp_ctx* ctx, const rjp_fields* f, hipStream_t st) {
+  const int64_t n = (int64_t)f->nx * f->ny * f->nz;
+  for (const auto& k : ctx->range_ok)
+    if (k.d_ts == f->d_ts && k.n == n && k.dtype == f->dtype && k.lo == f->ts_lo && k.hi == f->ts_hi)
+      return RJP_OK;
+  RJP_HIP(ctx, rjp::range_check_launch(f->d_ts, n, f->dtype, f->ts_lo, f->ts_hi, ctx->guard, st));
+  RJP_HIP(ctx, hipStreamSynchronize(st));
+  if (*(volatile int*)ctx->guard != 0) {
+    *(volatile int*)ctx->guard = 0;
+    return fail(ctx, RJP_ERR_ARG,
+                "fields.ts_lo / ts_hi do not contain every finite launch time of fields.d_ts "
+                "(pass what rjp_field_range returns for it, or zeros); nothing was enqueued");
+  }
+  for (int i = 3; i > 0; --i) ctx->range_ok[i] = ctx->range_ok[i - 1];
+  ctx->range_ok[0].d_ts = f->d_ts; ctx->range_ok[0].n = n; ctx->range_ok[0].dtype = f->dtype;
+  ctx->range_ok[0].lo = f->ts_lo; ctx->range_ok[0].hi = f->ts_hi;
   return RJP_OK;
 }
 
@@ -203,10 +251,13 @@ int rjp_ctx_create(int device, rjp_ctx** out) {
   bool ok = hipEventCreate(&c->ev0) == hipSuccess && hipEventCreate(&c->ev1) == hipSuccess;
   for (int i = 0; ok && i < rjp_ctx::kSlots; ++i)
     ok = hipEventCreateWithFlags(&c->slot[i].free_ev, hipEventDisableTiming) == hipSuccess;
+  ok = ok && hipHostMalloc((void**)&c->guard, sizeof(int), hipHostMallocDefault) == hipSuccess;
   if (!ok) {
+    if (c->guard) (void)hipHostFree(c->guard);
     delete c;
-    return fail(nullptr, RJP_ERR_HIP, "hipEventCreate failed");
+    return fail(nullptr, RJP_ERR_HIP, "hipEventCreate / hipHostMalloc failed");
   }
+  *c->guard = 0;
   *out = c;
   return RJP_OK;
 }
@@ -222,6 +273,7 @@ int rjp_ctx_destroy(rjp_ctx* ctx) {
   }
   if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
   if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+  if (ctx->guard) (void)hipHostFree(ctx->guard);
   rjp::moments_release(ctx->mom);
   delete ctx;
   return RJP_OK;
@@ -319,10 +371,11 @@ size_t rjp_ff_scan_workspace(int32_t nx, int32_t ny, int32_t nz, int32_t n_epoch
   return rjp::ff_scan_workspace_bytes(nx, ny, nz, n_epochs);
 }
 
-int rjp_ff_scan(rjp_ctx* ctx, const rjp_fields* fields, const rjp_bursts* bursts,
-                const double* h_epochs_s, int32_t n_epochs, int32_t gff_mode, double* d_sumA,
-                double* d_em, double* d_tavg, void* d_work, size_t work_bytes, void* stream) {
-  if (int r = bind(ctx)) return r;
+// (the body of rjp_ff_scan; also the first half of rjp_ff_step)
+static int ff_scan_impl(rjp_ctx* ctx, const rjp_fields* fields, const rjp_bursts* bursts,
+                        const double* h_epochs_s, int32_t n_epochs, int32_t gff_mode,
+                        double* d_sumA, double* d_em, double* d_tavg, void* d_work,
+                        size_t work_bytes, void* stream) {
   if (!mode_ok(gff_mode)) return fail(ctx, RJP_ERR_ARG, "bad gff_mode");
   if (int r = check_fields(ctx, fields, false, true, gff_mode)) return r;
   if (int r = check_bursts(ctx, bursts, fields)) return r;
@@ -355,6 +408,9 @@ int rjp_ff_scan(rjp_ctx* ctx, const rjp_fields* fields, const rjp_bursts* bursts
   // range and the host-side accuracy check of the expansion passes
   const int mr = rjp::moments_plan(fields, bursts, h_epochs_s, n_epochs, gff_mode, d_em != nullptr,
                                    work_bytes, ctx->mom);
+  if (mr) {
+    if (int r = check_ts_range(ctx, fields, st)) return r;
+  }
   if (mr == 2) {
     // a new (bursts, epochs) request: its coefficient tables are built and checked on the device
     const auto t0 = std::chrono::steady_clock::now();
@@ -375,7 +431,7 @@ int rjp_ff_scan(rjp_ctx* ctx, const rjp_fields* fields, const rjp_bursts* bursts
     }
     ctx->last_path = ctx->mom.path;
     if (ctx->mom.path == 2) {
-      RJP_HIP(ctx, rjp::lt_run(fields, ctx->mom, n_epochs, d_sumA, (double*)d_work, st));
+      RJP_HIP(ctx, rjp::lt_run(fields, ctx->mom, n_epochs, d_sumA, (double*)d_work, work_bytes, st));
       return RJP_OK;
     }
     // the moment maps of a0 are model state (they depend on the launch-time bins and on which
@@ -390,13 +446,13 @@ int rjp_ff_scan(rjp_ctx* ctx, const rjp_fields* fields, const rjp_bursts* bursts
     }
     if (cached) ctx->last_path = 4;
     hipError_t e = rjp::moments_run(fields, ctx->mom, n_epochs, d_sumA, mbuf, st,
-                                    (const double*)fields->d_a0, 1.0, cached);
+                                    (const double*)fields->d_a0, 1.0, ctx->guard, cached);
     if (e == hipSuccess && d_em) {
       // the emission measure of every epoch: the same pass and tables with em0 as the weight
       // (em = sum (n x)^2 * csize*au/pc * pf, classes.py:1116-1118)
       const double em_scale = fields->csize_au * 149597870700.0 / 3.085677581491367e+16;
       e = rjp::moments_run(fields, ctx->mom, n_epochs, d_em, (double*)d_work, st,
-                           (const double*)fields->d_em0, em_scale);
+                           (const double*)fields->d_em0, em_scale, ctx->guard);
     }
     if (e != hipSuccess) return fail(ctx, RJP_ERR_HIP, "moments_run", e);
     return RJP_OK;
@@ -405,6 +461,7 @@ int rjp_ff_scan(rjp_ctx* ctx, const rjp_fields* fields, const rjp_bursts* bursts
                           work_bytes, ctx->chi) &&
       (d_tavg == nullptr || ctx->chi.wide)) {      // (T_avg with the scan: the wide kernel only)
     // single epoch on the tau layout: the burst factor from a table in LDS (ff_scan_tab.hip)
+    if (int r = check_ts_range(ctx, fields, st)) return r;
     ctx->last_path = 3;
     const double* src[1] = {ctx->chi.stage.data()};
     const size_t len[1] = {ctx->chi.stage.size()};
@@ -412,7 +469,7 @@ int rjp_ff_scan(rjp_ctx* ctx, const rjp_fields* fields, const rjp_bursts* bursts
     if (int r = stage_tables(ctx, st, src, len, 1, dev)) return r;
     return finish_staged(ctx, st, rjp::chi_table_scan(fields, ctx->chi, dev[0], h_epochs_s[0],
                                                       gff_mode, d_sumA, d_em, d_tavg,
-                                                      (double*)d_work, work_bytes, st),
+                                                      (double*)d_work, work_bytes, ctx->guard, st),
                          "chi_table_scan");
   }
   ctx->last_path = 0;
@@ -433,6 +490,23 @@ int rjp_ff_scan(rjp_ctx* ctx, const rjp_fields* fields, const rjp_bursts* bursts
   if (d_ext) return finish_staged(ctx, st, e, "ff_scan_run");
   if (e != hipSuccess) return fail(ctx, RJP_ERR_HIP, "ff_scan_run", e);
   return RJP_OK;
+}
+
+int rjp_ff_scan(rjp_ctx* ctx, const rjp_fields* fields, const rjp_bursts* bursts,
+                const double* h_epochs_s, int32_t n_epochs, int32_t gff_mode, double* d_sumA,
+                double* d_em, double* d_tavg, void* d_work, size_t work_bytes, void* stream) {
+  if (int r = bind(ctx)) return r;
+  return ff_scan_impl(ctx, fields, bursts, h_epochs_s, n_epochs, gff_mode, d_sumA, d_em, d_tavg,
+                      d_work, work_bytes, stream);
+}
+
+int rjp_range_guard(rjp_ctx* ctx) {
+  if (!ctx || !ctx->guard) return RJP_ERR_ARG;
+  if (*(volatile int*)ctx->guard == 0) return 0;
+  *(volatile int*)ctx->guard = 0;
+  for (auto& k : ctx->range_ok) k = rjp_ctx::RangeKey();
+  ctx->err = kGuardMsg;
+  return 1;
 }
 
 int rjp_last_scan_path(const rjp_ctx* ctx, double* worst_rel_err, int32_t* moment_shape) {
@@ -479,11 +553,16 @@ int rjp_lt_count(rjp_ctx* ctx, const rjp_fields* fields, int32_t K, int32_t* d_r
   if (int r = check_lt(ctx, fields, K)) return r;
   if (!d_rowoff || !h_total_rows) return fail(ctx, RJP_ERR_ARG, "rjp_lt_count: NULL output");
   hipStream_t st = (hipStream_t)stream;
-  RJP_HIP(ctx, rjp::lt_count_launch(fields, K, d_rowoff, st));
+  RJP_HIP(ctx, rjp::lt_count_launch(fields, K, d_rowoff, ctx->guard, st));
   int32_t total = 0;
   const size_t n = rjp::lt_rowoff_entries(fields->nx, fields->nz, K);
   RJP_HIP(ctx, hipMemcpyAsync(&total, d_rowoff + (n - 1), sizeof(int32_t), hipMemcpyDeviceToHost, st));
   RJP_HIP(ctx, hipStreamSynchronize(st));
+  if (*(volatile int*)ctx->guard != 0) {
+    *(volatile int*)ctx->guard = 0;
+    return fail(ctx, RJP_ERR_ARG, "rjp_lt_count: fields.ts_lo / ts_hi do not contain every launch "
+                                  "time of the cells the layout keeps (rjp_field_range)");
+  }
   if (total < 0) return fail(ctx, RJP_ERR_ARG, "rjp_lt_count: more than 2^31 rows");
   *h_total_rows = total;
   return RJP_OK;
@@ -507,8 +586,8 @@ int rjp_time_ff_scan(rjp_ctx* ctx, const rjp_fields* fields, const rjp_bursts* b
   hipStream_t st = (hipStream_t)stream;
   RJP_HIP(ctx, hipEventRecord(ctx->ev0, st));
   for (int i = 0; i < reps; ++i) {
-    int r = rjp_ff_scan(ctx, fields, bursts, h_epochs_s, n_epochs, gff_mode, d_sumA, d_em,
-                        d_tavg, d_work, work_bytes, stream);
+    int r = ff_scan_impl(ctx, fields, bursts, h_epochs_s, n_epochs, gff_mode, d_sumA, d_em,
+                         d_tavg, d_work, work_bytes, stream);
     if (r != RJP_OK) return r;
   }
   RJP_HIP(ctx, hipEventRecord(ctx->ev1, st));
@@ -524,11 +603,10 @@ size_t rjp_ff_maps_workspace(int64_t n_pix, int32_t n_epochs, int32_t n_chan) {
   return rjp::ff_maps_workspace_bytes(n_pix, n_epochs, n_chan);
 }
 
-int rjp_ff_maps(rjp_ctx* ctx, const double* d_sumA, const double* d_tavg, int64_t n_pix,
-                int32_t n_epochs, const double* h_ctau, const double* h_cflux, int32_t n_chan,
-                double* d_tau, double* d_flux, double* d_ftot, void* d_work, size_t work_bytes,
-                void* stream) {
-  if (int r = bind(ctx)) return r;
+static int ff_maps_impl(rjp_ctx* ctx, const double* d_sumA, const double* d_tavg, int64_t n_pix,
+                        int32_t n_epochs, const double* h_ctau, const double* h_cflux,
+                        int32_t n_chan, double* d_tau, double* d_flux, double* d_ftot,
+                        void* d_work, size_t work_bytes, void* stream) {
   if (!d_sumA || !d_tavg || !h_ctau || !h_cflux)
     return fail(ctx, RJP_ERR_ARG, "rjp_ff_maps: NULL input");
   if (n_pix <= 0 || n_epochs <= 0 || n_chan <= 0)
@@ -542,6 +620,40 @@ int rjp_ff_maps(rjp_ctx* ctx, const double* d_sumA, const double* d_tavg, int64_
   if (int r = stage_tables(ctx, st, src, len, 2, dev)) return r;
   return finish_staged(ctx, st, rjp::ff_maps_launch(d_sumA, d_tavg, n_pix, n_epochs, dev[0], dev[1], n_chan, d_tau,
                                    d_flux, d_ftot, (double*)d_work, st), "ff_maps_launch");
+}
+
+int rjp_ff_maps(rjp_ctx* ctx, const double* d_sumA, const double* d_tavg, int64_t n_pix,
+                int32_t n_epochs, const double* h_ctau, const double* h_cflux, int32_t n_chan,
+                double* d_tau, double* d_flux, double* d_ftot, void* d_work, size_t work_bytes,
+                void* stream) {
+  if (int r = bind(ctx)) return r;
+  return ff_maps_impl(ctx, d_sumA, d_tavg, n_pix, n_epochs, h_ctau, h_cflux, n_chan, d_tau, d_flux,
+                      d_ftot, d_work, work_bytes, stream);
+}
+
+int rjp_ff_step(rjp_ctx* ctx, const rjp_fields* fields, const rjp_bursts* bursts,
+                const double* h_epochs_s, int32_t n_epochs, int32_t gff_mode,
+                const double* d_tavg, const double* h_ctau, const double* h_cflux, int32_t n_chan,
+                double* d_sumA, double* d_em, double* d_tau, double* d_flux, double* d_ftot,
+                void* d_work, size_t work_bytes, void* d_work_maps, size_t work_maps_bytes,
+                void* stream) {
+  if (int r = bind(ctx)) return r;
+  // every argument of the map stage is checked BEFORE the scan is enqueued: a step either runs
+  // whole or not at all
+  if (!fields) return fail(ctx, RJP_ERR_ARG, "fields is NULL");
+  if (!d_tavg || !h_ctau || !h_cflux || n_chan < 1)
+    return fail(ctx, RJP_ERR_ARG, "rjp_ff_step: NULL d_tavg / channel table or n_chan < 1");
+  if (fields->nx <= 0 || fields->nz <= 0 || n_epochs < 1)
+    return fail(ctx, RJP_ERR_ARG, "rjp_ff_step: bad grid or n_epochs < 1");
+  const int64_t n_pix = (int64_t)fields->nx * fields->nz;
+  if (d_ftot && (!d_work_maps ||
+                 work_maps_bytes < rjp::ff_maps_workspace_bytes(n_pix, n_epochs, n_chan)))
+    return fail(ctx, RJP_ERR_WORKSPACE, "rjp_ff_step: d_work_maps smaller than rjp_ff_maps_workspace()");
+  if (int r = ff_scan_impl(ctx, fields, bursts, h_epochs_s, n_epochs, gff_mode, d_sumA, d_em,
+                           nullptr, d_work, work_bytes, stream))
+    return r;
+  return ff_maps_impl(ctx, d_sumA, d_tavg, n_pix, n_epochs, h_ctau, h_cflux, n_chan, d_tau, d_flux,
+                      d_ftot, d_work_maps, work_maps_bytes, stream);
 }
 
 int rjp_rrl_scan(rjp_ctx* ctx, const rjp_fields* fields, const rjp_bursts* bursts,

@@ -240,6 +240,7 @@ class RTEngine:
         RJP_DEBUG=1 the variable RJP_NO_COMPACT=1 sets it)."""
         torch = _torch()
         fields.em0 = None
+        self._drop_derived_state(fields)
         if not self.use_compact:
             return fields
         em0 = self._empty(fields.ncells, fields.dtype)
@@ -259,6 +260,7 @@ class RTEngine:
         returns bit-identical maps.  f64 storage with the compact field attached; anything else
         keeps its layout."""
         fields.a0 = None
+        self._drop_derived_state(fields)
         if not self.use_tau or fields.dtype != RJP_F64 or fields.em0 is None:
             return fields
         a0 = self._f64(fields.ncells)
@@ -267,6 +269,16 @@ class RTEngine:
                                           self._stream()), self.ctx, "rjp_tau_field")
         fields.a0, fields.a0_mode = a0, int(gff_mode)
         return fields
+
+    @staticmethod
+    def _drop_derived_state(fields):
+        """What was built FROM a0 / em0 / ts goes whenever one of them is rebuilt: the
+        launch-time-ordered layout, the cached moment maps, the unmasked launch-time copy.  (The
+        caching allocator hands a rebuilt field the old one's address more often than not: these
+        are never validated by pointer alone.)"""
+        fields.lt = None
+        fields.mom_cache = None
+        fields._ts_unmasked = None
 
     def tavg(self, fields):
         """T_avg map of the model, nanmean_y(T where T > 0) -> device tensor [P] (rjp_tavg):
@@ -440,6 +452,24 @@ class RTEngine:
         out = self.compact(out)
         return self.tau_layout(out, tau_mode) if tau_mode is not None else out
 
+    def build_wide(self, fields, geom):
+        """Attach the wide fields a lean model left out (K4 again, writing nd / xi / pf / vy only):
+        what the RRL scan, the collapse=False kernels, the grid accessors and the `ion_fraction` /
+        `vel` setters need -- a continuum pipeline never asks (classes.JetModel._wide_fields)."""
+        n = fields.ncells
+        new = {k: self._empty(n, fields.dtype) for k in ("nd", "xi", "pf", "vy")
+               if getattr(fields, k) is None}
+        if not new:
+            return fields
+        ptr = lambda k: new[k].data_ptr() if k in new else None
+        _lib.check(self.lib.rjp_build_fields(
+            self.ctx, C.byref(geom), fields.dtype, ptr("nd"), ptr("xi"), None, ptr("pf"), None,
+            ptr("vy"), None, None, None, None, None, None, 0, self._stream()), self.ctx,
+            "rjp_build_fields")
+        for k, t in new.items():
+            setattr(fields, k, t)
+        return fields
+
     def synth_fields(self, shape, seed, temp_mode=0, dtype=RJP_F64, csize_au=0.5,
                      with_vy=False, cell0=0, wide=True, tau_mode=None, with_em0=True):
         """Measurement harness: dense synthetic fields generated on the device
@@ -545,6 +575,37 @@ class RTEngine:
             self._note_moment_sweep(fields, mkey)
         return sumA, em, tavg
 
+    def ff_step(self, fields, bursts, epochs_s, gff_mode, tavg, ctau, cflux, out):
+        """K1 + K2 from ONE call into the library (rjp_ff_step): the scan of `epochs_s` and the map
+        stage for the channels of (ctau, cflux), for callers whose step is shorter than two trips
+        through ctypes (x-slabs of a sharded grid, small models).  `tavg`: the model's T_avg map;
+        `out` = (sumA[E,P], em[E,P] | None, tau[E,F,P] | None, flux[E,F,P] | None,
+        ftot[E,F] | None) device tensors."""
+        sumA, em, tau, flux, ftot = out
+        E, P, F = len(epochs_s), fields.npix, len(ctau)
+        nx, ny, nz = fields.shape
+        work = self._workspace(self.lib.rjp_ff_scan_workspace(nx, ny, nz, E))
+        wm = self._workspace_maps(self.lib.rjp_ff_maps_workspace(P, E, F)) \
+            if ftot is not None else None
+        fs = self._scan_struct(fields, bursts, E)
+        mkey = self._attach_moment_cache(fields, bursts, fs, E, em is not None)
+        ptr = lambda t: t.data_ptr() if t is not None else None
+        _lib.check(self.lib.rjp_ff_step(
+            self.ctx, C.byref(fs), C.byref(bursts) if bursts is not None else None,
+            _lib.dbl_array(epochs_s), E, int(gff_mode), tavg.data_ptr(), _lib.dbl_array(ctau),
+            _lib.dbl_array(cflux), F, sumA.data_ptr(), ptr(em), ptr(tau), ptr(flux), ptr(ftot),
+            work.data_ptr(), work.numel(), ptr(wm), wm.numel() if wm is not None else 0,
+            self._stream()), self.ctx, "rjp_ff_step")
+        if mkey is not None:
+            self._note_moment_sweep(fields, mkey)
+        return out
+
+    def range_guard(self):
+        """True when a scan of this engine met finite launch times outside the range its fields
+        declared (rjp_range_guard; the sums of those sightlines are NaN).  Synchronises."""
+        self.synchronize()
+        return self.lib.rjp_range_guard(self.ctx) == 1
+
     def _attach_moment_cache(self, fields, bursts, fs, n_epochs, want_em):
         """The caller-kept moment maps of include/rjprt.h `rjp_fields.d_mom_cache`.  A long sweep
         of a densely filled model gets the buffer at once: its own pass fills it, and every later
@@ -568,6 +629,10 @@ class RTEngine:
                 mc["key"] = key
             fs.d_mom_cache = mc["buf"].data_ptr()
             fs.mom_cache_K, fs.mom_cache_N = mc["K"], mc["N"]
+            # the call may start rewriting the buffer in another shape and then fail: the recorded
+            # shape is void until `_note_moment_sweep` says what the buffer holds afterwards
+            mc["held"] = (mc["K"], mc["N"])
+            mc["K"] = mc["N"] = 0
         return key
 
     def _reserve_moment_cache(self, fields, key):
@@ -590,12 +655,11 @@ class RTEngine:
                 mc["K"], mc["N"] = self.last_moment_shape     # this sweep's pass filled it
                 mc["key"] = key
         elif mc is not None:
-            # another path ran (tiles, the launch-time-ordered layout): nothing was written; a
-            # buffer that has never held moments is given back
+            # another path ran (tiles, the launch-time-ordered layout): nothing was written -- the
+            # buffer holds what it held; one that has never held moments is given back
+            mc["K"], mc["N"] = mc.pop("held", (0, 0))
             if mc["K"] == 0:
                 fields.mom_cache = None
-            else:
-                mc["K"] = mc["N"] = 0
 
     def last_scan_path(self):
         """('tiles' | 'moments' | 'lt' | 'table', worst relative error of the expansion) of the

@@ -161,6 +161,50 @@ def gather_to_root(local, shards, rank, axis=0, root=0, group=None):
     return full.movedim(0, axis)
 
 
+def gather_slabs_to_root(local, shards, rank, axis, root=0, group=None, out=None):
+    """Slabs of a map cube (this rank's rows along `axis`, e.g. [E, F, n_x/N, n_z] with axis 2)
+    -> the whole cube on `root`, None on the other ranks: BASELINE config 4's "RCCL gather".
+    ONE `gather` of flat, equally padded buffers (no transposes on the senders), then the root
+    lays the slabs into the cube (`out`, if given, is the preallocated destination).  The root
+    ingests (world - 1) / world of the product over its xGMI links: 0.94 GB for the tau and flux
+    cubes of a 512 x 512 map x 256 channels -- link-bound, several times a slab's compute."""
+    import torch
+    dist = _dist()
+    counts = shards.counts()
+    if local.shape[axis] != counts[rank]:
+        raise ValueError("local block has %d rows on axis %d, plan says %d"
+                         % (local.shape[axis], axis, counts[rank]))
+    if not _talks(shards.world, group):
+        if out is not None:
+            out.copy_(local)
+            return out
+        return local
+    shape = list(local.shape)
+    per = 1
+    for i, n in enumerate(shape):
+        if i != axis:
+            per *= n
+    dev = local.device
+    buf = torch.zeros(max(counts) * per, dtype=local.dtype, device=dev)
+    buf[:local.numel()] = local.reshape(-1)
+    on_host = buf.is_cuda and dist.get_backend(group) == "gloo"
+    if on_host:
+        buf = buf.cpu()                      # rehearsal backend: gloo gathers host tensors
+    bufs = [torch.empty_like(buf) for _ in range(shards.world)] if rank == root else None
+    dist.gather(buf, bufs, dst=root, group=group)
+    if rank != root:
+        return None
+    if out is None:
+        shape[axis] = len(shards)
+        out = torch.empty(shape, dtype=local.dtype, device=dev)
+    for (s, e), b in zip(shards.bounds, bufs):
+        if e > s:
+            shp = list(out.shape)
+            shp[axis] = e - s
+            out.narrow(axis, s, e - s).copy_(b[:(e - s) * per].view(shp))
+    return out
+
+
 def sweep_flux_vs_time(model, epochs_s, freqs, rank=0, world=1, group=None):
     """Epoch-sharded continuum sweep through the JetModel API: every rank scans its epochs
     (8-32 per pass over HBM), reduces each (epoch, channel) map to its total flux on the
@@ -178,11 +222,10 @@ def sweep_flux_vs_time(model, epochs_s, freqs, rank=0, world=1, group=None):
     ctau, cflux = E.ff_channel_coeffs(freqs, model.csize, model.params["target"]["dist"],
                                       model.gff_mode, gv)
     if mine:
-        tavg = model._model_tavg()
-        sumA, _, _ = eng.ff_scan(dev, model._rjp_bursts(), mine, model.gff_mode,
-                                 want_em=False, want_tavg=False)
-        _, _, ftot = eng.ff_maps(sumA, tavg, ctau, cflux, want_tau=False, want_flux=False,
-                                 want_ftot=True)
+        # one call into the library per sweep: scan + light-curve stage (rjp_ff_step)
+        ftot = eng._f64(len(mine), len(freqs))
+        eng.ff_step(dev, model._rjp_bursts(), mine, model.gff_mode, model._model_tavg(), ctau,
+                    cflux, out=(eng._f64(len(mine), dev.npix), None, None, None, ftot))
     else:
         ftot = eng._f64(0, len(freqs))
     full = gather_flux_vs_time(ftot, shards, rank, group=group)
@@ -226,26 +269,32 @@ def xslab_local(model, epochs_s, freqs, rank, world, want_maps=True):
         return (x0, x1), empty, (empty.clone() if want_maps else None), eng._f64(Ep, F).zero_()
     geom = geometry_struct(model.params, x1 - x0, model.ny, model.nz, ix0=x0,
                            nx_total=model.nx)
-    # same degenerate-2F1 fallback as JetModel.device_fields (host launch times of the slab)
-    dev = build_model_fields(model, geom, want_vy=False, want_raw=False)
+    # same degenerate-2F1 fallback as JetModel.device_fields (host launch times of the slab);
+    # lean like it: the continuum sweep reads a0, em0, temp, ts only
+    lean = model._dtype == E.RJP_F64 and eng.use_compact and eng.use_tau
+    dev = build_model_fields(model, geom, want_vy=False, want_raw=False, want_wide=not lean)
     gv = None
     if model.gff_mode == E.RJP_GFF_SCALAR:
         gv = [mphys.gff(nu, model.params['properties']['T_0']) for nu in freqs]
     ctau, cflux = E.ff_channel_coeffs(freqs, model.csize, model.params["target"]["dist"],
                                       model.gff_mode, gv)
-    sumA, _, tavg = eng.ff_scan(dev, model._rjp_bursts(), epochs, model.gff_mode,
-                                want_em=False)
-    tau, flux, ftot = eng.ff_maps(sumA, tavg, ctau, cflux, want_tau=want_maps,
-                                  want_flux=want_maps, want_ftot=True)
+    P = dev.npix
+    tau = eng._f64(Ep, F, P) if want_maps else None
+    flux = eng._f64(Ep, F, P) if want_maps else None
+    ftot = eng._f64(Ep, F)
+    eng.ff_step(dev, model._rjp_bursts(), epochs, model.gff_mode, eng.tavg(dev), ctau, cflux,
+                out=(eng._f64(Ep, P), None, tau, flux, ftot))
     shp = (Ep, F, x1 - x0, model.nz)
     return ((x0, x1), tau.reshape(shp) if want_maps else None,
             flux.reshape(shp) if want_maps else None, ftot)
 
 
-def sweep_xslab(model, epochs_s, freqs, rank=0, world=1, gather_maps=False, group=None):
+def sweep_xslab(model, epochs_s, freqs, rank=0, world=1, gather_maps=False, group=None,
+                maps_on_root_only=False, root=0):
     """x-slab sharded sweep (strong scaling of one model): every rank scans n_x/world rows.
     The per-channel total fluxes are summed over ranks (one all_reduce of [E,F]); with
-    `gather_maps` the tau / flux slabs are all_gathered along x as well.
+    `gather_maps` the tau / flux slabs are all_gathered along x as well (`maps_on_root_only`:
+    gathered onto `root` alone -- the other ranks return None for them).
     Returns (ftot[E,F] host array, tau or None, flux or None)."""
     dist = _dist()
     _, tau, flux, ftot = xslab_local(model, epochs_s, freqs, rank, world, want_maps=gather_maps)
@@ -257,7 +306,13 @@ def sweep_xslab(model, epochs_s, freqs, rank=0, world=1, gather_maps=False, grou
         else:
             dist.all_reduce(ftot, group=group)
     out_t = out_f = None
-    if gather_maps:
+    if gather_maps and maps_on_root_only:
+        slabs = SlabShards(model.nx, world)
+        out_t = gather_slabs_to_root(tau, slabs, rank, 2, root=root, group=group)
+        out_f = gather_slabs_to_root(flux, slabs, rank, 2, root=root, group=group)
+        out_t = None if out_t is None else out_t.cpu().numpy()
+        out_f = None if out_f is None else out_f.cpu().numpy()
+    elif gather_maps:
         slabs = SlabShards(model.nx, world)
         out_t = all_gather_blocks(tau, slabs, rank, axis=2, group=group).cpu().numpy()
         out_f = all_gather_blocks(flux, slabs, rank, axis=2, group=group).cpu().numpy()

@@ -173,6 +173,38 @@ def test_cfg4_tau_layout_is_bit_identical_at_full_size(eng, temp_mode):
     ref = got[0][0]
     assert torch.equal(tab == 0, ref == 0)
     assert ((tab - ref).abs() / ref).max().item() < 3e-12
+    # round 5: the two HEADLINE kernels against the ORACLE at the headline
+    # size, in one assertion each -- ff_scan_table_kernel (a0, ts: what the timed step launches)
+    # and ff_scan_table_wide_kernel (the five model fields: SURVEY 8(d)'s byte model, tau + EM +
+    # T_avg in one pass) on 28 sampled sightlines incl. the corners of the map, both sides of the
+    # jet plane and the first / last lanes of a workgroup (classes.py:1101-1128, 1388-1432,
+    # 1471-1472); both Gaunt branches through the parametrisation
+    from rajepy_amd.maths import physics as ph
+    nx, ny, nz = shape
+    rng = np.random.default_rng(41 + temp_mode)
+    pix = [(int(rng.integers(nx)), int(rng.integers(nz))) for _ in range(20)]
+    pix += [(0, 0), (nx - 1, nz - 1), (17, nz // 2 - 1), (17, nz // 2), (0, 510), (1, 0),
+            (255, 511), (256, 0)]
+    idx = [x * nz + z for (x, z) in pix]
+    sj = _sample_jet(shape, pix, temp_mode, 0. if temp_mode == 0 else -0.5)
+    sj.time = e1[0]
+    nu = np.array([1e9, 5e10])
+    gv = [ph.gff(f, 1e4) for f in nu] if temp_mode == 0 else None
+    ctau, _ = E.ff_channel_coeffs(nu, 0.5, 120., mode, gv)
+    want_tau = sj.optical_depth_ff(nu)[:, :, 0]
+    np.testing.assert_allclose(ctau[:, None] * tab[0].cpu().numpy()[idx][None, :], want_tau,
+                               rtol=1e-10, err_msg="ff_scan_table_kernel vs oracle")
+    a0, em0, fields.a0, fields.em0 = fields.a0, fields.em0, None, None     # the five model fields
+    wA, wE, wT = eng.ff_scan(fields, bursts, e1, mode, want_em=True, want_tavg=True)
+    assert eng.last_scan_path()[0] == "table"
+    eng.synchronize()
+    fields.a0, fields.em0 = a0, em0
+    np.testing.assert_allclose(ctau[:, None] * wA[0].cpu().numpy()[idx][None, :], want_tau,
+                               rtol=1e-10, err_msg="ff_scan_table_wide_kernel vs oracle (tau)")
+    np.testing.assert_allclose(wE[0].cpu().numpy()[idx], sj.emission_measure()[:, 0], rtol=1e-10,
+                               err_msg="ff_scan_table_wide_kernel vs oracle (EM)")
+    # (T_avg of the same pass: one y-range here, eight in rjp_tavg -- equal to rounding)
+    assert ((wT - tav).abs() / tav).max().item() < 1e-13
 
 
 def test_cfg5_epoch_sweep_by_launch_time_moments_full_size(eng):

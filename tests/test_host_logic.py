@@ -202,6 +202,14 @@ def test_workspace_queries_are_host_arithmetic():
     assert lib.rjp_ff_scan_workspace(64, 128, 64, 12) == 1280 * 64 * 64 * 8 + 256
     assert lib.rjp_ff_scan_workspace(64, 128, 64, 11) < 1024 * 64 * 64 * 8
     assert lib.rjp_ff_scan_workspace(0, 4, 4, 1) == 0
+    # round 5: the single-epoch table scan cuts mid-size maps into its OWN y-ranges
+    # (until 512 workgroups exist, >= 64 rows each) -- 4 planes per range -- and the scan of the
+    # five model fields keeps its table behind 8 x 4 planes: both inside the workspace now
+    p2 = 256 * 256
+    assert lib.rjp_ff_scan_workspace(256, 128, 256, 1) >= max(2 * 4 * p2 * 8, 32 * p2 * 8 + 73600)
+    assert lib.rjp_ff_scan_workspace(256, 256, 256, 1) >= max(4 * 4 * p2 * 8, 32 * p2 * 8 + 73600)
+    assert lib.rjp_ff_scan_workspace(100, 400, 700, 1) >= 32 * 70000 * 8 + 73600
+    assert lib.rjp_ff_scan_workspace(64, 4096, 512, 1) >= 8 * 4 * 64 * 512 * 8     # an x-slab of cfg4
     assert lib.rjp_ff_maps_workspace(npix, 1, 256) > 0
     assert lib.rjp_ff_maps_workspace(0, 1, 1) == 0
 
