@@ -21,17 +21,20 @@ emission-measure map to the step (a third field, em0: 24 B/cell); `--layout comp
 3 / 5 fields per cell (the line always prices SURVEY 8(d)'s five-field byte model on the wide
 kernel, live, as `frac_8d`).
 
-N > 1 (no data-path collective, one gather/reduce per step over RCCL):
-  cfg4 / cfg2  timed region: burst-time epochs shard embarrassingly -- every rank holds the
-               grid (generated on its own GPU from the same hash) and scans a different epoch
-               per step, flux-vs-time vectors are all_gathered ("scaling": "weak").  The same
-               line carries two more measured legs, each labelled: `strong_xslab` (the ONE
-               grid split into n_x/N row slabs, per-channel fluxes all_reduced) and
+N > 1 (no data-path collective, one gather/reduce per step over RCCL; "scaling": "strong"):
+  every config timed region = BASELINE's workload itself, the ONE grid split into n_x/N row slabs
+               (x-slabs: sightlines are independent), every rank runs the whole step on its
+               rows, per-channel fluxes all_reduced.  For cfg4 / cfg2 the same line carries
+               three more measured legs, each labelled: `strong_xslab_gather_maps` (the step
+               ends with BASELINE config 4's "RCCL gather": the tau and flux slabs of every
+               rank gathered into whole cubes on rank 0 -- compute, gather and total reported
+               separately), `weak_epochs` (every rank holds the whole grid and scans another
+               burst-time epoch per step, flux-vs-time vectors all_gathered) and
                `channel_sharded` (the north star's frequency-sharded sweep: every rank scans
                the whole grid and maps F/N channels -- continuum channels share the grid
                pass, SURVEY finding 2, so this cannot scale the scan).
-  cfg5 / cfg3  x-slabs (strong scaling): every rank keeps the 32-epoch tile / the 256-lane
-               RRL kernel on its n_x/N rows; per-channel fluxes all_reduced.
+N = 1, default config: `rank_share` prices rank 0's share of a 2- / 4- / 8-way split of cfg4, cfg5
+and cfg3 as a stand-alone workload on this one GPU (projected strong-scaling speedup).
 
 Prints ONE JSON line (rank 0) with the driver's contract fields plus `roofline`,
 `cpu_baseline` (N = 1), `sustained`, `ranks_seen` and, for N > 1, `n1` and `legs`.
@@ -100,9 +103,10 @@ def parse(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--sharding", default="auto",
                     choices=("auto", "epochs", "xslab", "channels"),
-                    help="N>1.  auto = epochs for single-epoch continuum configs (weak scaling, "
-                         "plus the strong_xslab and channel_sharded legs in the same line), "
-                         "xslab for cfg5 / RRL.  epochs = one epoch of the full grid per rank; "
+                    help="N>1.  auto = xslab (strong scaling of the ONE grid; single-epoch "
+                         "continuum configs add the strong_xslab_gather_maps, weak_epochs and "
+                         "channel_sharded legs to the same line).  epochs = one epoch of the "
+                         "full grid per rank (weak scaling); "
                          "xslab = the ONE grid split into n_x/N row slabs (strong scaling, "
                          "per-channel fluxes all_reduced); channels = every rank scans the whole "
                          "grid and maps 1/N of the channels")
@@ -358,7 +362,8 @@ def resolve_sharding(args, world):
         if args.sharding == "channels" and kind == "rrl":
             return "xslab"
         return args.sharding
-    return "xslab" if (n_ep_cfg or kind == "rrl") else "epochs"
+    # BASELINE's workload itself on N GPUs: the ONE grid in n_x/N row slabs (strong scaling)
+    return "xslab"
 
 
 def plan(config, sharding, rank, world):
@@ -373,7 +378,7 @@ def plan(config, sharding, rank, world):
     else:
         freqs = np.geomspace(1e9, 5e10, nchan)
     lshape, cell0 = shape, 0
-    if sharding == "xslab":
+    if sharding in ("xslab", "xslab_gather_maps"):
         x0, x1 = SlabShards(shape[0], world).bounds[rank]
         lshape, cell0 = (x1 - x0, shape[1], shape[2]), x0 * shape[1] * shape[2]
     cshards = None
@@ -398,7 +403,19 @@ def plan(config, sharding, rank, world):
 
 GATHER = {"none": "none", "epochs": "all_gather of flux-vs-time [E,F]",
           "xslab": "all_reduce of per-channel fluxes [E,F]",
+          "xslab_gather_maps": "all_reduce of per-channel fluxes [E,F] + gather of the tau and "
+                               "flux slabs into whole cubes [E,F,n_x,n_z] on rank 0",
           "channels": "all_gather of per-channel fluxes along F"}
+
+
+def gather_cubes(tau, flux, pl, rank, world, out=None):
+    """BASELINE config 4's "RCCL gather": this rank's tau / flux slabs [E, F, n_x/N, n_z] ->
+    the whole cubes on rank 0 (None elsewhere).  `out`: rank 0's preallocated (tau, flux)."""
+    from rajepy_amd.parallel import SlabShards, gather_slabs_to_root
+    slabs = SlabShards(pl["shape"][0], world)
+    o_t, o_f = out if out is not None else (None, None)
+    return (gather_slabs_to_root(tau, slabs, rank, 2, out=o_t),
+            gather_slabs_to_root(flux, slabs, rank, 2, out=o_f))
 
 
 def collect(res, pl, rank, world, backend, force=False):
@@ -409,6 +426,8 @@ def collect(res, pl, rank, world, backend, force=False):
     sh = pl["sharding"]
     if (world == 1 and not force) or sh == "none":
         return res
+    if sh == "xslab_gather_maps":
+        sh = "xslab"
     if sh == "channels":                  # [E, F/N] per rank -> [E, F]
         return all_gather_blocks(res, pl["cshards"], rank, axis=1)
     if sh == "xslab":                     # partial per-channel fluxes of this slab -> totals
@@ -433,8 +452,10 @@ def rehearse_cpu(args, rank, world):
     legs = {}
     main_sh = resolve_sharding(args, world)
     order = [main_sh]
-    if world > 1 and main_sh == "epochs" and not args.no_extra_legs:
-        order += ["xslab", "channels"]
+    _, _, n_ep_cfg, kind = CONFIGS[args.config]
+    if world > 1 and main_sh == "xslab" and not (n_ep_cfg or kind == "rrl") and \
+            not args.no_extra_legs:
+        order += ["xslab_gather_maps", "epochs", "channels"]
     for sh in order:
         pl = plan(args.config, sh, rank, world)
         nx = pl["shape"][0]
@@ -446,14 +467,27 @@ def rehearse_cpu(args, rank, world):
             loc = full[pl["eshards"].slice(rank)]
         elif sh == "channels":
             loc = full[:, pl["cshards"].slice(rank)]
-        elif sh == "xslab":
+        elif sh in ("xslab", "xslab_gather_maps"):
             loc = full * (pl["lshape"][0] / nx)
         else:
             loc = full
+        cube_ok = True
         for _ in range(args.warmup + args.steps):
             out = collect(torch.from_numpy(np.ascontiguousarray(loc)).clone(), pl, rank, world,
                           "gloo")
-        ok = bool(np.allclose(out.numpy(), full, rtol=1e-12, atol=0))
+            if sh == "xslab_gather_maps":
+                # placeholder cubes: every rank contributes its rows of arange-filled maps
+                nz = pl["shape"][2]
+                x0 = pl["cell0"] // (pl["shape"][1] * nz)
+                whole = torch.arange(E_tot * F_tot * nx * nz, dtype=torch.float64).reshape(
+                    E_tot, F_tot, nx, nz)
+                mine = whole[:, :, x0:x0 + pl["lshape"][0]].contiguous()
+                ct, cf = gather_cubes(mine, -mine, pl, rank, world)
+                if rank == 0:
+                    cube_ok = bool(torch.equal(ct, whole) and torch.equal(cf, -whole))
+                else:
+                    cube_ok = ct is None and cf is None
+        ok = bool(np.allclose(out.numpy(), full, rtol=1e-12, atol=0)) and cube_ok
         legs[sh] = {"ok": ok, "shape": list(out.shape), "gather": GATHER[sh]}
     seen = torch.ones(1, dtype=torch.float64)
     if world > 1:
@@ -461,18 +495,23 @@ def rehearse_cpu(args, rank, world):
         dist.barrier()
     result = {"metric": "Mvoxel-freq/s", "value": None, "unit": "Mvoxel-freq/s",
               "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": None,
-              "higher_is_better": True, "scaling": "weak" if main_sh in ("epochs", "none")
+              "higher_is_better": True, "scaling": "weak" if main_sh == "epochs"
               else "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
               "rehearsal": True, "ranks_seen": int(seen.item()),
               "config": {"workload": args.config + " (CPU rehearsal of launcher, planners and "
                                                    "collectives; no kernels run)",
                          "sharding": main_sh, "gather": GATHER[main_sh]},
               "legs": legs}
+    # every rank's verdict counts (rank 0 checks the gathered cubes, the others that they got none)
+    allok = torch.tensor([1.0 if all(v["ok"] for v in legs.values()) else 0.0],
+                         dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(allok, op=dist.ReduceOp.MIN)
     if rank == 0:
         print(json.dumps(result), flush=True)
     if world > 1:
         dist.destroy_process_group()
-    return 0 if all(v["ok"] for v in legs.values()) and result["ranks_seen"] == world else 1
+    return 0 if allok.item() == 1.0 and result["ranks_seen"] == world else 1
 
 
 # ---------------------------------------------------------------------------------------
@@ -547,6 +586,13 @@ class Workload:
         else:
             self.tau = eng._f64(E_loc, self.nchan, self.P)
             self.flux = eng._f64(E_loc, self.nchan, self.P)
+        # BASELINE config 4's gather: the step ends with the slabs of every rank laid into whole
+        # cubes on rank 0 (preallocated there, like every other output of the step)
+        self.gather_maps = sharding == "xslab_gather_maps"
+        self.cubes = None
+        if self.gather_maps and rank == 0:
+            nx, _, nz = pl["shape"]
+            self.cubes = (eng._f64(E_loc, self.nchan, nx, nz), eng._f64(E_loc, self.nchan, nx, nz))
 
     @property
     def total_epochs(self):
@@ -556,10 +602,9 @@ class Workload:
     def local_step(self):
         """The hot path on this rank's shard; returns its per-channel fluxes [E_loc, F_loc]."""
         eng = self.eng
-        eng.ff_scan(self.fields, self.bursts, self.my_epochs, self.gmode,
-                    out=(self.sumA, self.em, None))
-        eng.ff_maps(self.sumA, self.tavg, self.ctau, self.cflux,
-                    out=(self.tau, self.flux, self.ftot))
+        # K1 + K2 from ONE call into the library (rjp_ff_step)
+        eng.ff_step(self.fields, self.bursts, self.my_epochs, self.gmode, self.tavg, self.ctau,
+                    self.cflux, out=(self.sumA, self.em, self.tau, self.flux, self.ftot))
         res = self.ftot
         if self.rrl:
             tau_rrl = eng.rrl_scan(self.fields, self.bursts, self.my_epochs[0], self.line,
@@ -571,7 +616,17 @@ class Workload:
         return res
 
     def step(self):
-        return collect(self.local_step(), self.pl, self.rank, self.world, self.args.backend)
+        res = collect(self.local_step(), self.pl, self.rank, self.world, self.args.backend)
+        if self.gather_maps:
+            self.gather_only()
+        return res
+
+    def gather_only(self):
+        """The map gather of a `xslab_gather_maps` step alone (timed on its own for the leg)."""
+        lx, _, nz = self.pl["lshape"]
+        shp = (self.E_loc, self.nchan, lx, nz)
+        return gather_cubes(self.tau.view(shp), self.flux.view(shp), self.pl, self.rank,
+                            self.world, out=self.cubes)
 
     def release(self, to_driver=True):
         """Drop this workload's device buffers; `to_driver=False` leaves them in PyTorch's
@@ -579,7 +634,7 @@ class Workload:
         if self.fields is not None:
             self.fields.lt = None
             self.fields.mom_cache = None
-        self.fields = self._em0 = self.sumA = self.em = self.tau = self.flux = None
+        self.fields = self._em0 = self.sumA = self.em = self.tau = self.flux = self.cubes = None
         if to_driver:
             import torch
             torch.cuda.empty_cache()
@@ -828,6 +883,70 @@ def measure_other_configs(eng, args, torch):
     except Exception as exc:
         out["cfg3"] = {"error": "%s: %s" % (type(exc).__name__, str(exc)[:300])}
     torch.cuda.empty_cache()
+    return out
+
+
+def measure_rank_share(eng, args, torch, base):
+    """what ONE rank of an N-way split has to do, run stand-alone on this one
+    GPU -- rank 0's plan of a 2- / 4- / 8-way x-slab split of cfg4, cfg5 (both sweep paths) and
+    cfg3 (x-slabs and channel shards) -- with `projected_speedup` = the N = 1 step of the same
+    config in this process / the share's step, and `efficiency` = that / N.  Compute only: the
+    per-step collective (an all_reduce of [E, F] doubles, latency-bound) and, where maps are
+    gathered, the link time of the gather are not in it -- `gather_bytes_into_root` says what the
+    map gather of the split would move.  `base`: ms per N = 1 step per variant."""
+    out = {"what": "rank 0's share of an N-way split as a stand-alone workload on ONE GPU "
+                   "(compute only; the collectives of the real N-rank step are not in it)",
+           "projected_speedup_is": "ms_per_step of the N = 1 workload in this process / "
+                                   "ms_per_step of the share"}
+
+    def wall(fn, steps, warm):
+        for _ in range(warm):
+            fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / steps * 1e3
+
+    variants = [("cfg4", "xslab", "xslab", False, (100, 10)),
+                ("cfg5", "xslab_lds_moments", "xslab", False, (30, 3)),
+                ("cfg5", "xslab_lt_layout", "xslab", True, (30, 3)),
+                ("cfg3", "xslab", "xslab", False, (3, 1)),
+                ("cfg3", "channels", "channels", False, (3, 1))]
+    for cfg, tag, sh, lt, (steps, warm) in variants:
+        t1 = base.get((cfg, tag))
+        rows = {}
+        try:
+            for n in (2, 4, 8):
+                w = Workload(eng, args, sh, 0, n, config=cfg, lt=lt)
+                ms = wall(w.local_step, steps, warm)
+                row = {"local_shape": list(w.pl["lshape"]), "local_channels": w.nchan,
+                       "ms_per_step": ms}
+                if w.rrl:
+                    ev0, ev1 = (torch.cuda.Event(enable_timing=True),
+                                torch.cuda.Event(enable_timing=True))
+                    ev0.record()
+                    eng.rrl_scan(w.fields, w.bursts, w.my_epochs[0], w.line, w.freqs)
+                    ev1.record()
+                    torch.cuda.synchronize()
+                    row["k3_ms"] = ev0.elapsed_time(ev1)
+                else:
+                    row["k1_stage_ms"] = eng.time_ff_scan(w.fields, w.bursts, w.my_epochs, w.gmode,
+                                                          reps=10, want_em=False, want_tavg=False)
+                    row["scan_path"] = eng.last_scan_path()[0]
+                if t1:
+                    row["projected_speedup"] = t1 / ms
+                    row["efficiency"] = t1 / ms / n
+                if w.tau is not None and sh == "xslab":
+                    row["gather_bytes_into_root"] = int((n - 1) * 2 * w.tau.numel() * 8)
+                rows[str(n)] = row
+                w.release(to_driver=False)
+                del w
+            out.setdefault(cfg, {})[tag] = {"n1_ms_per_step": t1, "split": rows}
+        except Exception as exc:                              # a leg must never void the line
+            out.setdefault(cfg, {})[tag] = {"error": "%s: %s" % (type(exc).__name__, str(exc)[:300])}
+        torch.cuda.empty_cache()
     return out
 
 
@@ -1097,8 +1216,10 @@ def main(argv=None):
             em0, a0 = fields.em0, fields.a0
             fields.em0 = fields.a0 = None
             eng.time_ff_scan(fields, wl.bursts, wl.my_epochs, wl.gmode, reps=1, want_em=True)
-            wide_ms = eng.time_ff_scan(fields, wl.bursts, wl.my_epochs, wl.gmode, reps=3,
-                                       want_em=True)
+            wide_ms = eng.time_ff_scan(fields, wl.bursts, wl.my_epochs, wl.gmode,
+                                       reps=3 if n_ep_cfg else 20, want_em=True)
+            wide_path = eng.last_scan_path()[0]
+            lt_keep = fields.lt                  # (rebuilding em0 / a0 below drops derived state)
 
             def ev_ms(fn):
                 ev0, ev1 = (torch.cuda.Event(enable_timing=True),
@@ -1114,12 +1235,13 @@ def main(argv=None):
             if a0 is not None:
                 build_ms += ev_ms(lambda: eng.tau_layout(fields, wl.gmode))
             fields.em0, fields.a0 = em0, a0
+            fields.lt = lt_keep
             roof_extra.update({
                 "wide_ms_per_launch": wide_ms, "layout_build_ms": build_ms,
+                "wide_scan_path": wide_path,
                 "frac_8d": alg_8d / (wide_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                 "frac_8d_kernel": "the wide-layout scan (5 fields/cell, tau + EM + T_avg sums; "
-                                  "path: %s), timed live on the same fields"
-                                  % eng.last_scan_path()[0],
+                                  "path: %s), timed live on the same fields" % wide_path,
                 "first_epoch_from_wide_fields_ms": {"scan_layout": build_ms + wl.tavg_ms + k_ms,
                                                     "wide": wide_ms}})
         elif nfld == 5:
@@ -1153,6 +1275,45 @@ def main(argv=None):
                 "ms_per_launch": k_ms, "algorithmic_bytes": alg_bytes,
                 "algorithmic_bytes_8d": alg_8d}
     roofline.update(roof_extra)
+    if not rrl and not n_ep_cfg and "wide_ms_per_launch" in roofline:
+        # the top-level figures of `roofline` are SURVEY 8(d)'s single figure --
+        # the five-field byte model (n, x, T, path factor, launch time: 40 B/cell + the tau and EM
+        # base maps) on the kernel that moves exactly those bytes, one epoch from the five MODEL
+        # fields (tau + EM + T_avg sums in one pass), timed live in this run on the same fields.
+        # The kernel of the TIMED step reads two derived per-model fields instead (a0 = (n x)^2 pf
+        # T^-1.5 and ts: 16 B/cell; their one-off build and the T_avg pass are
+        # `per_model_state_ms`) and sits beside it as `timed_step_kernel`, priced on ITS bytes.
+        step_keys = ("kernel", "achieved", "frac", "ms_per_launch", "algorithmic_bytes",
+                     "traffic", "traffic_source", "fields_streamed_per_cell", "scan_path",
+                     "chi_table", "grid_passes_per_launch", "epochs_per_launch",
+                     "timed_step_asks_for_em", "with_em")
+        roofline["timed_step_kernel"] = {k: roofline.pop(k) for k in step_keys if k in roofline}
+        w_ms = roofline["wide_ms_per_launch"]
+        w_kernel = ("ff_scan_table_wide_kernel" if roofline["wide_scan_path"] == "table"
+                    else "ff_scan_kernel (wide layout)")
+        w_traffic, w_src = None, None
+        pfw = _latest_profile("%s_%s_wide5_pmc.json" % (args.config, args.storage))
+        if pfw:
+            try:
+                w_traffic = json.load(open(pfw)).get("hbm_bytes_per_launch")
+                w_src = os.path.relpath(pfw, ROOT) + \
+                    " (rocprofv3 --pmc passes of `bench.py --layout wide --em`, an earlier run)"
+            except Exception:
+                pass
+        roofline.update({
+            "kernel": w_kernel, "achieved": alg_8d / (w_ms * 1e-3) / 1e9,
+            "frac": alg_8d / (w_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "ms_per_launch": w_ms,
+            "algorithmic_bytes": alg_8d, "fields_streamed_per_cell": 5,
+            "traffic": w_traffic, "traffic_source": w_src,
+            "what": "SURVEY 8(d)'s byte model (5 fields x 8 B per cell + tau and EM base maps) / "
+                    "the launch time of the kernel that moves those bytes -- one epoch from the "
+                    "five model fields: optical-depth sums, emission measure and T_avg in one "
+                    "pass -- timed live with HIP events on the launch stream in this run",
+            "per_model_state_ms": {"a0_and_em0_from_the_model_fields": roofline["layout_build_ms"],
+                                   "tavg_map": wl.tavg_ms,
+                                   "what": "one-off passes per MODEL that the timed step's "
+                                           "kernel relies on (K4 / the synthetic generator "
+                                           "write a0 and em0 in their own pass instead)"}})
     if not rrl:
         # whole step = K1 + K2: the bytes both really move against the step's wall time
         k2_bytes = 0 if wl.tau is None else E_loc * wl.nchan * P * 16
@@ -1229,19 +1390,53 @@ def main(argv=None):
         wl.release()
         other = measure_other_configs(eng, args, torch)
 
+    # ---- N = 1: one rank's share of a 2- / 4- / 8-way split, priced on this GPU --------------
+    rank_share = None
+    if other is not None:
+        base = {("cfg4", "xslab"): ms_step}
+        c5, c3 = other.get("cfg5", {}), other.get("cfg3", {})
+        if "lds_moments" in c5:
+            base[("cfg5", "xslab_lds_moments")] = c5["lds_moments"]["ms_per_step"]
+            base[("cfg5", "xslab_lt_layout")] = c5["lt_layout"]["ms_per_step"]
+        if "ms_per_step" in c3:
+            base[("cfg3", "xslab")] = base[("cfg3", "channels")] = c3["ms_per_step"]
+        rank_share = measure_rank_share(eng, args, torch, base)
+
     # ---- N > 1: the other labelled legs and the N = 1 reference --------------------------
     legs, n1 = {}, None
     if world > 1 and not args.no_extra_legs:
         wl.release()
-        if sharding == "epochs":
-            for name, sh in (("strong_xslab", "xslab"), ("channel_sharded", "channels")):
+        if sharding == "xslab" and not (n_ep_cfg or rrl):
+            # (1) BASELINE config 4 to the letter: the step ends with the gather of every rank's
+            # tau and flux slabs into whole cubes on rank 0; the gather is also timed alone
+            wg = Workload(eng, args, "xslab_gather_maps", rank, world)
+            dtg, _ = timed(wg.step, args.steps, args.warmup)
+            dto, _ = timed(wg.gather_only, args.steps, 1)
+            msg, mso = dtg / args.steps * 1e3, dto / args.steps * 1e3
+            legs["strong_xslab_gather_maps"] = {
+                "sharding": "xslab", "scaling": "strong", "ms_per_step": msg,
+                "value": rate(msg, wg.total_epochs), "gather": GATHER["xslab_gather_maps"],
+                "compute_ms": ms_step, "gather_only_ms": mso,
+                "bytes_into_root": int((world - 1) * 2 * wg.tau.numel() * 8),
+                "epochs_per_step": wg.total_epochs,
+                "what": "compute_ms = the timed region of this line (the same step without the "
+                        "map gather); gather_only_ms = the two gathers + the root's copy of the "
+                        "slabs into the cubes, back to back, nothing else in flight; "
+                        "ms_per_step = both in one step"}
+            wg.release()
+            # (2) weak scaling over burst-time epochs, (3) the frequency-sharded sweep as named
+            for name, sh, scal in (("weak_epochs", "epochs", "weak"),
+                                   ("channel_sharded", "channels", "strong")):
                 w2 = Workload(eng, args, sh, rank, world)
                 dt2, _ = timed(w2.step, args.steps, args.warmup)
                 ms2 = dt2 / args.steps * 1e3
-                legs[name] = {"sharding": sh, "scaling": "strong", "ms_per_step": ms2,
+                legs[name] = {"sharding": sh, "scaling": scal, "ms_per_step": ms2,
                               "value": rate(ms2, w2.total_epochs), "gather": GATHER[sh],
                               "epochs_per_step": w2.total_epochs}
                 w2.release()
+            legs["weak_epochs"]["note"] = (
+                "every rank holds the whole grid (generated on its own GPU from the same hash) "
+                "and scans another epoch per step: N epochs' worth of work per step")
             legs["channel_sharded"]["note"] = (
                 "every rank scans the whole grid (continuum channels share the grid pass, "
                 "SURVEY finding 2): only the map stage is divided")
@@ -1261,6 +1456,7 @@ def main(argv=None):
             w1.release()
         dist.barrier()
         for leg in legs.values():
+            # (a weak leg does N epochs per step: its ratio to the N = 1 value is its scaling)
             if n1:
                 leg["speedup_vs_n1"] = leg["value"] / n1["value"]
 
@@ -1268,7 +1464,8 @@ def main(argv=None):
         "metric": "Mvoxel-freq/s", "value": value, "unit": "Mvoxel-freq/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": ms_step, "higher_is_better": True,
-        "scaling": "weak" if sharding in ("epochs", "none") and not n_ep_cfg else "strong",
+        # (the same word at every N: the driver's N = 1, 2, 4, 8 values are one curve)
+        "scaling": "weak" if sharding == "epochs" else "strong",
         "vs_baseline": None, "dtype": "f64", "storage_dtype": args.storage,
         "data": "synthetic",
         "config": {"workload": "%s: %dx%dx%d grid x %d %s, %d epoch(s) per step, %s"
@@ -1278,7 +1475,12 @@ def main(argv=None):
                                    "K3 RRL scan + K1/K2 continuum + line flux cube" if rrl else
                                    "K1 scan + K2 flux-vs-time" if n_ep_cfg else
                                    "K1 scan + K2 tau/flux cubes" +
-                                   (" + EM map" if args.em else ""))),
+                                   (" + EM map" if args.em else ""))) + (
+                           "; the scan reads the per-MODEL scan fields a0 = (n x)^2 pf T^-1.5|-1.35 "
+                           "and ts (16 B/cell), T_avg is a per-model map: their one-off costs are "
+                           "roofline.per_model_state_ms, and value_from_model_fields is the same "
+                           "step from the five model fields (SURVEY 8(d))"
+                           if (not rrl and not n_ep_cfg and roofline.get("timed_step_kernel")) else ""),
                    "storage": args.storage, "gaunt": args.gaunt,
                    "arithmetic": "f64 accumulation and transcendental functions; storage "
                                  "dtype of the 3-D fields as given",
@@ -1289,12 +1491,8 @@ def main(argv=None):
         "devices": devices, "distinct_devices": distinct_devices,
         "roofline": roofline,
     }
-    if world > 1 and "strong_xslab" in legs:
-        # the figure that answers "how much faster is ONE model on N GPUs": the x-slab leg
-        # (`value` above is the weak, epoch-sharded aggregate)
-        result["strong_value"] = legs["strong_xslab"]["value"]
-        result["strong_speedup_vs_n1"] = legs["strong_xslab"].get("speedup_vs_n1")
-    elif world > 1 and result["scaling"] == "strong":
+    if world > 1 and result["scaling"] == "strong":
+        # "how much faster is ONE model on N GPUs": `value` itself (x-slabs of the one grid)
         result["strong_value"] = value
         result["strong_speedup_vs_n1"] = value / n1["value"] if n1 else None
     if rehearsal:
@@ -1318,9 +1516,10 @@ def main(argv=None):
             "stage of this step (%.3f ms): what one epoch costs without the per-model scan "
             "fields a0 / em0 and the per-model T_avg map" %
             (ms_wide_step, roofline["wide_ms_per_launch"], max(0.0, ms_step - k_ms)))
-    if not rrl and "with_em" in roofline and not n_ep_cfg:
+    tsk = roofline.get("timed_step_kernel", roofline)
+    if not rrl and "with_em" in tsk and not n_ep_cfg:
         # the step as rounds 1-2 defined it (EM map of the epoch and T_avg inside the step)
-        ms_r02 = roofline["with_em"]["ms_per_launch"] + wl.tavg_ms + max(0.0, ms_step - k_ms)
+        ms_r02 = tsk["with_em"]["ms_per_launch"] + wl.tavg_ms + max(0.0, ms_step - k_ms)
         result["value_r02_workload"] = rate(ms_r02, total_epochs)
         result["config"]["workload_version"] = (
             "r03+: the timed step produces tau and flux cubes; the emission-measure map (--em) and "
@@ -1328,6 +1527,8 @@ def main(argv=None):
             "with both inside (%.3f ms), comparable with BENCH_r02" % ms_r02)
     if other:
         result["configs"] = other
+    if rank_share:
+        result["rank_share"] = rank_share
     if sustained:
         result["sustained"] = sustained
     if api_level:

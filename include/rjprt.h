@@ -226,8 +226,10 @@ int rjp_tau_field(rjp_ctx* ctx, const rjp_fields* fields, int32_t gff_mode, void
  * rate whatever the launch time (classes.py:232-233, 442-448, 866-875): its cells keep chi = 1.
  * rjp_ff_scan masks EVERY cell with a NaN launch time once bursts are present (a per-cell jet
  * test there cost the single-epoch scan 2.7 %), so such a model scans the copy written here:
- * d_ts_out[i] = 0 where d_ts[i] is NaN and the cell belongs to `jet` (0 = red, 1 = blue: the one
- * WITHOUT bursts; the flag is read from the sign bit of d_a0, d_em0 or d_nd), d_ts[i] elsewhere.
+ * d_ts_out[i] = fields->ts_lo (0 when no range is given: any finite value gives chi = 1 there;
+ * this one lies inside the declared range, which the range guard holds the copy to as well) where
+ * d_ts[i] is NaN and the cell belongs to `jet` (0 = red, 1 = blue: the one WITHOUT bursts; the flag
+ * is read from the sign bit of d_a0, d_em0 or d_nd), d_ts[i] elsewhere.
  * (rjp_rrl_scan and the collapse=False entry points apply the rule themselves.) */
 int rjp_unmask_launch_times(rjp_ctx* ctx, const rjp_fields* fields, int32_t jet, void* d_ts_out,
                             void* stream);

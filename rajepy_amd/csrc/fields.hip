@@ -124,19 +124,19 @@ hipError_t tau_field_launch(const rjp_fields* fl, int gff_mode, void* d_a0, hipS
 // rate whatever the launch time (classes.py:232-233, 442-448): its cells keep chi = 1.  The
 // free-free scan masks every cell with a NaN launch time as soon as the model has a burst, so
 // a model with bursts in ONE jet only scans a copy of `ts` in which the NaNs of the other
-// jet's cells are replaced by 0 (any finite value gives chi = 1 there).  `flag`: a field that
+// jet's cells are replaced by fields.ts_lo (any finite value gives chi = 1 there).  `flag`: a field that
 // carries the red-jet flag in its sign bit (a0, em0 or nd).
 template <typename T>
 __global__ __launch_bounds__(kFB) void unmask_ts_kernel(const T* __restrict__ ts,
                                                         const T* __restrict__ flag, int jet,
-                                                        T* __restrict__ out, int64_t n) {
+                                                        T fill, T* __restrict__ out, int64_t n) {
   int64_t i = (int64_t)blockIdx.x * kFB + threadIdx.x;
   const int64_t step = (int64_t)gridDim.x * kFB;
   for (; i < n; i += step) {
     const double t = (double)ts[i];
     const bool red = signbit_d((double)flag[i]);
     const bool mine = red == (jet == 0);
-    out[i] = (!(t == t) && mine) ? (T)0 : ts[i];
+    out[i] = (!(t == t) && mine) ? fill : ts[i];
   }
 }
 
@@ -144,12 +144,15 @@ hipError_t unmask_ts_launch(const rjp_fields* fl, int jet, void* d_out, hipStrea
   const int64_t n = (int64_t)fl->nx * fl->ny * fl->nz;
   const unsigned blocks = (unsigned)std::min<int64_t>((n + kFB - 1) / kFB, 256 * 32);
   const void* flag = fl->d_a0 ? fl->d_a0 : fl->d_em0 ? fl->d_em0 : fl->d_nd;
+  // the replacement value lies INSIDE the declared launch-time range (its lower end; 0 when no
+  // range is given): the copy is scanned under the same range, and the range guard watches it
+  const double fill = fl->ts_lo;
   if (fl->dtype == RJP_F64)
     hipLaunchKernelGGL(unmask_ts_kernel<double>, dim3(blocks), dim3(kFB), 0, st,
-                       (const double*)fl->d_ts, (const double*)flag, jet, (double*)d_out, n);
+                       (const double*)fl->d_ts, (const double*)flag, jet, fill, (double*)d_out, n);
   else
     hipLaunchKernelGGL(unmask_ts_kernel<float>, dim3(blocks), dim3(kFB), 0, st,
-                       (const float*)fl->d_ts, (const float*)flag, jet, (float*)d_out, n);
+                       (const float*)fl->d_ts, (const float*)flag, jet, (float)fill, (float*)d_out, n);
   return hipGetLastError();
 }
 

@@ -536,11 +536,15 @@ class RTEngine:
         jet = 0 if n_r == 0 else 1
         flag = fields.a0 if fields.a0 is not None else (fields.em0 if fields.em0 is not None
                                                         else fields.nd)
-        key = (jet, fields.ts.data_ptr(), flag.data_ptr())
+        # (the copy's replacement value is the lower end of the launch-time range, so that the
+        # copy obeys the range it is scanned under: measure the range first, key the copy on it)
+        rng = self.launch_time_range(fields)
+        full = fields.struct()
+        key = (jet, fields.ts.data_ptr(), flag.data_ptr(), rng)
         cached = getattr(fields, "_ts_unmasked", None)
         if cached is None or cached[0] != key:
             out = self._empty(fields.ncells, fields.dtype)
-            _lib.check(self.lib.rjp_unmask_launch_times(self.ctx, C.byref(fs), jet,
+            _lib.check(self.lib.rjp_unmask_launch_times(self.ctx, C.byref(full), jet,
                                                         out.data_ptr(), self._stream()),
                        self.ctx, "rjp_unmask_launch_times")
             cached = fields._ts_unmasked = (key, out)

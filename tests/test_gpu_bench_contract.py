@@ -37,14 +37,20 @@ def test_bench_prints_one_contract_line(config):
     assert {"bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_source",
             "algorithmic_bytes", "algorithmic_bytes_8d"} <= set(rf)
     if config == "tiny":
-        # the tau layout: a0 and ts per cell; the step asks for optical depths and fluxes only,
-        # the same launch with the EM map (a third field) is timed beside it
-        assert rf["fields_streamed_per_cell"] == 2 and rf["timed_step_asks_for_em"] is False
-        assert rf["with_em"]["fields_streamed_per_cell"] == 3 and rf["with_em"]["ms_per_launch"] > 0
+        # round 5: the top-level figures of `roofline` are SURVEY 8(d)'s five-field byte model on
+        # the kernel that moves it (one epoch from the five model fields); the kernel of the timed
+        # step (tau layout: a0 and ts per cell, no EM map) sits beside it, priced on its own bytes
+        sk = rf["timed_step_kernel"]
+        assert rf["fields_streamed_per_cell"] == 5 and rf["algorithmic_bytes"] == rf["algorithmic_bytes_8d"]
+        assert abs(rf["frac"] - rf["frac_8d"]) < 1e-12 and rf["ms_per_launch"] == rf["wide_ms_per_launch"]
+        assert sk["fields_streamed_per_cell"] == 2 and sk["timed_step_asks_for_em"] is False
+        assert sk["with_em"]["fields_streamed_per_cell"] == 3 and sk["with_em"]["ms_per_launch"] > 0
+        assert abs(sk["frac"] - sk["achieved"] / rf["peak"]) < 1e-12
+        assert rf["algorithmic_bytes_8d"] > sk["algorithmic_bytes"] > 0
         assert rf["tavg"]["ms"] > 0 and "layout" in r["config"] and "tau" in r["config"]["layout"]
-        # 8(d)'s five-field byte model is priced on the kernel that moves those bytes
-        assert rf["algorithmic_bytes_8d"] > rf["algorithmic_bytes"]
-        assert rf["wide_ms_per_launch"] > 0 and rf["layout_build_ms"] > 0 and rf["frac_8d"] > 0
+        assert rf["per_model_state_ms"]["a0_and_em0_from_the_model_fields"] > 0
+        assert "per-MODEL" in r["config"]["workload"] and r["value_from_model_fields"] > 0
+        assert r["value_from_model_fields"] < r["value"]
         assert r["api_level"]["ms_per_step"] >= r["ms_per_step"] * 0.5
     assert "rehearsal" not in r and r["backend"] is None
     assert r["distinct_devices"] == 1 and len(r["devices"]) == 1 and r["devices"][0]["id"]
@@ -76,7 +82,7 @@ def test_bench_refuses_mismatched_world_size():
     assert out.returncode == 2 and "WORLD_SIZE" in out.stderr
 
 
-@pytest.mark.parametrize("config,sharding,scaling", [("tiny", "epochs", "weak"),
+@pytest.mark.parametrize("config,sharding,scaling", [("tiny", "xslab", "strong"),
                                                      ("tiny5", "xslab", "strong"),
                                                      ("tiny_rrl", "xslab", "strong")])
 def test_bench_launches_its_own_ranks(config, sharding, scaling):
@@ -102,10 +108,15 @@ def test_bench_launches_its_own_ranks(config, sharding, scaling):
     assert r["config"]["sharding"] == sharding
     assert r["n1"]["value"] > 0
     if config == "tiny":
-        # weak (timed region) + the labelled strong and channel-sharded legs, one line
-        assert set(r["legs"]) == {"strong_xslab", "channel_sharded"}
-        for leg in r["legs"].values():
-            assert leg["scaling"] == "strong" and leg["value"] > 0 and leg["speedup_vs_n1"] > 0
+        # round 5: the timed region is BASELINE's workload itself in x-slabs (strong); the step
+        # that ends with the map gather, the weak epoch leg and the channel-sharded leg beside it
+        assert set(r["legs"]) == {"strong_xslab_gather_maps", "weak_epochs", "channel_sharded"}
+        for name, leg in r["legs"].items():
+            assert leg["scaling"] == ("weak" if name == "weak_epochs" else "strong")
+            assert leg["value"] > 0 and leg["speedup_vs_n1"] > 0
+        g = r["legs"]["strong_xslab_gather_maps"]
+        assert g["gather_only_ms"] > 0 and g["compute_ms"] > 0 and g["bytes_into_root"] > 0
+        assert g["ms_per_step"] >= 0.5 * g["compute_ms"] and "gather" in g["gather"]
     elif config == "tiny5":
         assert "32 epoch(s) per step" in r["config"]["workload"]
         assert r["roofline"]["epochs_per_launch"] == 32 and r["roofline"]["grid_passes_per_launch"] == 1

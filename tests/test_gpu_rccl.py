@@ -44,11 +44,21 @@ CHILD = textwrap.dedent('''
         got = bench.collect(res.clone(), pl, 0, 1, "nccl", force=True)
         assert got.is_cuda and torch.equal(got, res), sh
         out["collect_" + sh] = list(got.shape)
+    # ... and the map gather that ends a `strong_xslab_gather_maps` step (BASELINE config 4's
+    # "RCCL gather"): dist.gather of the slab buffers on device tensors, the root's cubes
+    pl = bench.plan("tiny", "xslab_gather_maps", 0, 1)
+    nx, _, nz = pl["shape"]
+    tau = torch.rand(1, len(pl["my_freqs"]), nx, nz, dtype=torch.float64, device=dev)
+    pre = (torch.empty_like(tau), torch.empty_like(tau))
+    ct, cf = bench.gather_cubes(tau, -tau, pl, 0, 1, out=pre)
+    assert ct is pre[0] and cf is pre[1] and torch.equal(ct, tau) and torch.equal(cf, -tau)
+    out["gather_cubes"] = list(ct.shape)
 
     # 2. the gathers of rajepy_amd.parallel
     blk = torch.rand(3, 5, 7, dtype=torch.float64, device=dev)
     assert torch.equal(parallel.all_gather_blocks(blk, SlabShards(5, 1), 0, axis=1), blk)
     assert torch.equal(parallel.gather_to_root(blk, ChannelShards(np.arange(3.), 1), 0, axis=0), blk)
+    assert torch.equal(parallel.gather_slabs_to_root(blk, SlabShards(5, 1), 0, 1), blk)
     fl = torch.rand(4, 6, dtype=torch.float64, device=dev)
     assert torch.equal(parallel.gather_flux_vs_time(fl, EpochShards(np.arange(4.), 1), 0), fl)
     t = torch.ones(2, 3, dtype=torch.float64, device=dev)
@@ -66,6 +76,10 @@ CHILD = textwrap.dedent('''
     ftot, tau, flux = parallel.sweep_xslab(jm, times[:2], freqs, rank=0, world=1,
                                            gather_maps=True)      # all_reduce + all_gather
     np.testing.assert_allclose(ftot, lc[:2], rtol=1e-12)
+    f2, tau_r, flux_r = parallel.sweep_xslab(jm, times[:2], freqs, rank=0, world=1, gather_maps=True,
+                                             maps_on_root_only=True)     # all_reduce + gather
+    np.testing.assert_array_equal(tau_r, tau)
+    np.testing.assert_array_equal(flux_r, flux)
     cube = parallel.sweep_channel_sharded(jm, freqs, rank=0, world=1)   # gather to root
     jm.time = 0.0
     np.testing.assert_array_equal(cube, jm.flux_ff(freqs))
@@ -104,6 +118,7 @@ def test_every_collective_of_the_product_runs_over_rccl(tmp_path):
     r = json.loads(line[0][len("RCCL_CHILD "):])
     assert r["backend"] == "nccl"
     assert r["collect_epochs"] and r["collect_xslab"] and r["collect_channels"]
+    assert len(r["gather_cubes"]) == 4
     # the example jet's light curve at 5 GHz (reference anchors): the numbers
     # that went through RCCL are the model's
     ref = [1.158223515e-3, 1.279591671e-3, 1.379008153e-3, 1.429076011e-3]

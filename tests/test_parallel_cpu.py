@@ -52,6 +52,23 @@ def _worker(rank, world, port, n_epochs, ret):
         cube = torch.arange(4 * n_epochs * 3, dtype=torch.float64).reshape(4, n_epochs, 3)
         got2 = par.all_gather_blocks(cube[:, sh.slice(rank), :], sh, rank, axis=1)
         ok = ok and torch.equal(got2, cube)
+        # round 5: the map gather of BASELINE config 4 -- slabs along a middle axis of a 4-D cube
+        # laid into the whole cube on the root (into a preallocated buffer and without one);
+        # ragged and EMPTY slabs (more ranks than rows) included
+        c4 = torch.arange(2 * 3 * n_epochs * 5, dtype=torch.float64).reshape(2, 3, n_epochs, 5)
+        mine4 = c4[:, :, sh.slice(rank), :].contiguous()
+        g1 = par.gather_slabs_to_root(mine4, sh, rank, 2, root=0)
+        pre = torch.full_like(c4, -1.0) if rank == 0 else None
+        g2 = par.gather_slabs_to_root(mine4, sh, rank, 2, root=0, out=pre)
+        if rank == 0:
+            ok = ok and torch.equal(g1, c4) and g2 is pre and torch.equal(pre, c4)
+        else:
+            ok = ok and g1 is None and g2 is None
+        few = par.SlabShards(1, world)                  # one row, `world` ranks
+        row = torch.full((2, few.counts()[rank], 3), float(rank + 1), dtype=torch.float64)
+        g3 = par.gather_slabs_to_root(row, few, rank, 1, root=0)
+        ok = ok and ((rank == 0 and tuple(g3.shape) == (2, 1, 3) and bool((g3 == 1.0).all())) or
+                     (rank != 0 and g3 is None))
         bad = False
         try:
             par.all_gather_blocks(full, sh, rank)       # wrong local size must be refused
@@ -84,6 +101,7 @@ def _local_in_group_worker(rank, world, port, ret):
             x = torch.arange(12, dtype=torch.float64).reshape(4, 3)
             ok = ok and par.all_gather_blocks(x, one, 0) is x
             ok = ok and par.gather_to_root(x, one, 0) is x
+            ok = ok and par.gather_slabs_to_root(x, one, 0, 0) is x
             ok = ok and par.gather_flux_vs_time(x, one, 0) is x
             ok = ok and par._talks(1) is False and par._talks(2) is True
         try:
@@ -149,7 +167,10 @@ def test_pipeline_epoch_sharding_gloo(tmp_path):
     assert all(ret[r] for r in range(2)), dict(ret)
 
 
-@pytest.mark.parametrize("config,world,legs", [("tiny", 2, {"epochs", "xslab", "channels"}),
+@pytest.mark.parametrize("config,world,legs", [("tiny", 2, {"xslab", "xslab_gather_maps", "epochs",
+                                                           "channels"}),
+                                               ("tiny", 3, {"xslab", "xslab_gather_maps", "epochs",
+                                                           "channels"}),
                                                ("tiny5", 3, {"xslab"})])
 def test_bench_self_launch_rehearsal(config, world, legs):
     """`python bench.py --gpus N` with no WORLD_SIZE in the environment must start its own N
@@ -173,7 +194,7 @@ def test_bench_self_launch_rehearsal(config, world, legs):
     assert r["rehearsal"] is True and r["value"] is None
     assert r["n_gpus"] == world and r["ranks_seen"] == world
     assert set(r["legs"]) == legs and all(v["ok"] for v in r["legs"].values())
-    assert r["scaling"] == ("weak" if config == "tiny" else "strong")
+    assert r["scaling"] == "strong" and r["config"]["sharding"] == "xslab"
 
 
 def test_bench_refuses_mismatched_world_size_cpu():

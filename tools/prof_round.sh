@@ -32,8 +32,12 @@ for variant in tau2 tau3 wide5; do
   echo "bench $variant done"
   # (--no-other-configs: the `configs` object of the default line would add cfg2-size launches
   # of the same kernels to the per-kernel averages)
+  # (--no-api-level: that leg runs the step WHILE the previous step's cubes travel to the host --
+  # a blit kernel of ~10 ms on the same CUs and HBM: its eight scan launches take 15-20 ms each
+  # and showed up as the 20 ms MaxNs of round 4's summaries, profiles/r05_outlier_launches.json;
+  # they are no measure of the kernel and stay out of the per-kernel averages)
   rocprofv3 --kernel-trace --stats -d "$out/${tag}_cfg4${sfx}_stats" -o run --output-format csv -- \
-    "${B[@]}" --no-cpu-baseline --no-other-configs > "$out/${tag}_cfg4_f64${sfx}_bench_under_rocprof.json" 2> "$out/${tag}_cfg4${sfx}_stats.log"
+    "${B[@]}" --no-cpu-baseline --no-other-configs --no-api-level > "$out/${tag}_cfg4_f64${sfx}_bench_under_rocprof.json" 2> "$out/${tag}_cfg4${sfx}_stats.log"
   echo "stats $variant done"
   S=("${B[@]}" --steps 8 --warmup 2 --no-cpu-baseline --no-api-level --sustained-seconds 0 --no-other-configs)
   rocprofv3 --kernel-trace --pmc FETCH_SIZE -d "$out/${tag}_cfg4${sfx}_fetch" -o run --output-format csv -- "${S[@]}" > "$out/${tag}_cfg4${sfx}_fetch.log" 2>&1

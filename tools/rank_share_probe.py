@@ -14,14 +14,17 @@ import bench  # noqa: E402
 def main():
     import torch
     from rajepy_amd import engine as E
-    cfgs = sys.argv[1:] or ["cfg4", "cfg2", "cfg5", "cfg3"]
+    # arguments: config names, optionally "cfg5:8" = only the 8-way share of cfg5 (for a run under
+    # rocprofv3 --kernel-trace --stats: the per-kernel averages are then that share's)
+    only = {a.split(":")[0]: int(a.split(":")[1]) for a in sys.argv[1:] if ":" in a}
+    cfgs = [a.split(":")[0] for a in sys.argv[1:]] or ["cfg4", "cfg2", "cfg5", "cfg3"]
     args = bench.parse([])
     eng = E.RTEngine(0)
     eng.cache_moments = False
     out = {}
     for cfg in cfgs:
         rows = {}
-        for n in (1, 2, 4, 8):
+        for n in ((only[cfg],) if cfg in only else (1, 2, 4, 8)):
             w = bench.Workload(eng, args, "xslab" if n > 1 else "none", 0, n, config=cfg, lt=False)
             steps, warm = (3, 1) if cfg == "cfg3" else (50, 10)
             for _ in range(warm):
@@ -40,7 +43,7 @@ def main():
                        "path": eng.last_scan_path()[0]}
             w.release()
             del w
-        t1 = rows[1]["ms_per_step"]
+        t1 = rows[1]["ms_per_step"] if 1 in rows else float("nan")
         for n, r in rows.items():
             r["projected_speedup"] = t1 / r["ms_per_step"]
             r["efficiency"] = r["projected_speedup"] / n
