@@ -789,9 +789,14 @@ def measure_other_configs(eng, args, torch):
             fresh = {"model": "files/example-model-params.py jet on 512x4096x512 (cell size / %.2f)"
                               % scale,
                      "construct_ms": (t1 - t0) * 1e3,
-                     "construct_note": "JetModel() to resident fields: ten 8.6 GB arrays (taken from "
-                                       "PyTorch's cached blocks here; 0.25 s from the driver in "
-                                       "a fresh process), K4, occupied y-ranges",
+                     "construct_note": "JetModel() to resident fields: FOUR 8.6 GB arrays -- a0, em0, "
+                                       "temp, ts; nd / xi / pf / vy are built by the first call "
+                                       "that needs them -- taken from PyTorch's cached blocks here "
+                                       "(~1.1 s from the driver in a fresh process: "
+                                       "profiles/r05_fresh_model_probe.json), K4, occupied y-ranges",
+                     "grid_sized_arrays_resident": [
+                         k for k in ("nd", "xi", "temp", "pf", "ts", "vy", "em0", "a0")
+                         if getattr(jm.device_fields, k) is not None],
                      "first_light_curve_ms": (t2 - t1) * 1e3,
                      "second_light_curve_ms": (t3 - t2) * 1e3,
                      "scan_path": eng.last_scan_path()[0],

@@ -256,6 +256,11 @@ int rjp_tavg(rjp_ctx* ctx, const rjp_fields* fields, double* d_tavg, void* d_wor
 int rjp_y_bounds(rjp_ctx* ctx, const rjp_fields* fields, int32_t* d_ylo, int32_t* d_yhi,
                  void* stream);
 
+/* sum_p max(0, d_yhi[p] - d_ylo[p]) -> *h_count: the cells inside the occupied y-ranges, i.e.
+ * rjp_fields.occupied_cells (one small launch, an 8-byte copy back; synchronises the stream). */
+int rjp_occupied_cells(rjp_ctx* ctx, const int32_t* d_ylo, const int32_t* d_yhi, int64_t n_pix,
+                       int64_t* h_count, void* stream);
+
 /* ---- K1: free-free / emission-measure scan -------------------------------------------
  * Replaces the y-reductions of JetModel.emission_measure (classes.py:1116-1120),
  * .optical_depth_ff (1375-1432) and the nanmean of .intensity_ff (1471-1472, 1484-1485),

@@ -6,7 +6,7 @@ per-channel re-streaming structure, the same formulas in the same multiplication
 the same NaN conventions.  Every function cites the reference lines it follows (paths
 relative to the reference root).  Only `tests/`, `__graft_entry__.smoke()` and
 `bench.py`'s `cpu_baseline` leg may import this module; the product package `rajepy_amd`
-never does (tests/test_abi.py checks that).
+never does (tests/test_host_logic.py::test_product_never_imports_the_oracle checks that).
 
 Parity status: PINNED.  tests/test_oracle_golden.py checks every function here against
 golden vectors produced by importing the unmodified reference in the build container

@@ -93,6 +93,7 @@ SIGNATURES = {
     "rjp_field_range": (C.c_int, [_P, _P, C.c_int64, C.c_int, _P, _P]),
     "rjp_unmask_launch_times": (C.c_int, [_P, C.POINTER(Fields), C.c_int32, _P, _P]),
     "rjp_y_bounds": (C.c_int, [_P, C.POINTER(Fields), _P, _P, _P]),
+    "rjp_occupied_cells": (C.c_int, [_P, _P, _P, C.c_int64, C.POINTER(C.c_int64), _P]),
     "rjp_ff_scan_workspace": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
     "rjp_ff_scan": (C.c_int, [_P, C.POINTER(Fields), C.POINTER(Bursts), _DP, C.c_int32,
                               C.c_int32, _P, _P, _P, _P, C.c_size_t, _P]),

@@ -156,22 +156,37 @@ __global__ __launch_bounds__(kMomBS) void moments_kernel(const double* __restric
 // sumA[e][p] = sum_idx M_T[idx][p] * W[idx][e], e < ne <= 32; four moment rows in flight per
 // lane (one at a time left the loop latency-bound: 0.66 -> 0.47 ms at 512x512 sightlines x 1024;
 // round 4, same-buffer A/B on cfg5's 1272 rows: 2 / 4 / 8 / 12 rows 0.80 / 0.58 / 0.64 / 0.74 ms, two
-// register sets in ping-pong 0.89-1.07 ms: four plain rows stay)
+// register sets in ping-pong 0.89-1.07 ms: four plain rows stay).
+// Round 5: a lane walks ALL rows of its sightline, so a small map -- an x-slab of a sharded grid:
+// 64 x 512 sightlines = 512 waves -- left most of the chip idle and the contraction took as long
+// as on the whole map (0.48 ms of a 1.04 ms step, profiles/r05_share_cfg5_8_kernel_stats.csv).
+// gridDim.y now cuts the row range into `nsp` chunks (multiples of UI rows); with nsp > 1 the
+// chunk sums go to `part[(c * ET + e) * npix + p]` and moments_eval_sum_kernel adds them in a
+// fixed order (bit-reproducible for a given nsp).
 #ifndef RJP_EVAL_UI
 #define RJP_EVAL_UI 4
 #endif
+#ifndef RJP_EVAL_WAVES
+#define RJP_EVAL_WAVES 4096      /* row chunks are added until about this many waves exist */
+#endif
+constexpr int kEvalMaxSplit = 16;
+
 __global__ __launch_bounds__(256) void moments_eval_kernel(const double* __restrict__ MT,
                                                            int64_t npix, int64_t npixp, int nidx,
+                                                           int rows_per_chunk,
                                                            const double* __restrict__ W, int ne,
                                                            double scale,
-                                                           double* __restrict__ sumA) {
+                                                           double* __restrict__ sumA,
+                                                           double* __restrict__ part) {
   constexpr int ET = RJP_MOM_TILE, UI = RJP_EVAL_UI;
   const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (p >= npix) return;
+  const int i_lo = blockIdx.y * rows_per_chunk;
+  const int i_hi = min(nidx, i_lo + rows_per_chunk);
   double acc[ET];
 #pragma unroll
   for (int e = 0; e < ET; ++e) acc[e] = 0.0;
-  for (int i0 = 0; i0 < nidx; i0 += UI) {
+  for (int i0 = i_lo; i0 < i_hi; i0 += UI) {
     double m[UI];
 #pragma unroll
     for (int j = 0; j < UI; ++j) m[j] = MT[(int64_t)(i0 + j) * npixp + p];
@@ -182,9 +197,34 @@ __global__ __launch_bounds__(256) void moments_eval_kernel(const double* __restr
       for (int e = 0; e < ET; ++e) acc[e] = __builtin_fma(m[j], w[e], acc[e]);
     }
   }
+  if (part) {
+#pragma unroll
+    for (int e = 0; e < ET; ++e)
+      if (e < ne) part[((int64_t)blockIdx.y * ET + e) * npix + p] = acc[e];
+    return;
+  }
 #pragma unroll
   for (int e = 0; e < ET; ++e)
     if (e < ne) sumA[(int64_t)e * npix + p] = acc[e] * scale;      // (scale == 1: exact)
+}
+
+__global__ __launch_bounds__(256) void moments_eval_sum_kernel(const double* __restrict__ part,
+                                                               int nsp, int64_t npix, double scale,
+                                                               double* __restrict__ sumA) {
+  const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int e = blockIdx.y;
+  if (p >= npix) return;
+  double s = 0.0;
+  for (int c = 0; c < nsp; ++c) s += part[((int64_t)c * RJP_MOM_TILE + e) * npix + p];
+  sumA[(int64_t)e * npix + p] = s * scale;
+}
+
+// row chunks of the contraction on a map of `npix` sightlines (1 on maps that fill the chip)
+static int mom_eval_split(int64_t npix) {
+  const int64_t waves = (npix + RJP_WAVE - 1) / RJP_WAVE;
+  int nsp = 1;
+  while (nsp < kEvalMaxSplit && waves * nsp < RJP_EVAL_WAVES) nsp *= 2;
+  return nsp;
 }
 
 // ---- per-block min / max of a field, NaN ignored (rjp_field_range) -----------------------------
@@ -315,6 +355,13 @@ size_t moments_workspace_bytes(int64_t npix) {
   return (size_t)RJP_MOM_MAX_IDX * (size_t)npixp * sizeof(double) + 256;
 }
 
+// ... plus, on small maps, the chunk sums of the split contraction behind the moment maps
+size_t moments_scan_workspace_bytes(int64_t npix) {
+  const int nsp = mom_eval_split(npix);
+  return moments_workspace_bytes(npix) +
+         (nsp > 1 ? (size_t)nsp * RJP_MOM_TILE * (size_t)npix * sizeof(double) : 0);
+}
+
 void moments_release(MomPlan& mp) {
   if (mp.d_W) (void)hipFree(mp.d_W);
   if (mp.d_err) (void)hipFree(mp.d_err);
@@ -337,7 +384,7 @@ int moments_plan(const rjp_fields* fl, const rjp_bursts* hb, const double* epoch
   if (!(fl->ts_hi >= fl->ts_lo) || !std::isfinite(fl->ts_lo) || !std::isfinite(fl->ts_hi) ||
       (fl->ts_lo == 0.0 && fl->ts_hi == 0.0))
     return 0;                                                   // range not provided
-  if (work_bytes < moments_workspace_bytes((int64_t)fl->nx * fl->nz)) return 0;
+  if (work_bytes < moments_scan_workspace_bytes((int64_t)fl->nx * fl->nz)) return 0;
   for (int e = 0; e < n_epochs; ++e)
     if (!std::isfinite(epochs[e])) return 0;
   const bool lt = fl->d_lt_cells && fl->d_lt_rowoff && fl->d_lt_aux && fl->lt_K >= 1 &&
@@ -535,9 +582,12 @@ static hipError_t moments_pass(const rjp_fields* fl, const double* weights, cons
 // `weights` = the field whose launch-time moments are taken (a0 for the optical-depth sums,
 // em0 for the emission measure: both carry the jet flag in their sign bit), `scale` = the
 // constant factor of the result (1 for the sums of a0).
+// `ws`: the moment maps (the caller's workspace, or its moment cache); `part`: room for the chunk
+// sums of the split contraction (moments_scan_workspace_bytes() - moments_workspace_bytes() bytes;
+// inside the caller's workspace, never inside a moment cache).
 hipError_t moments_run(const rjp_fields* fl, const MomPlan& mp, int n_epochs,
-                       double* sumA, double* ws, hipStream_t st, const double* weights,
-                       double scale, int* d_guard, bool skip_pass) {
+                       double* sumA, double* ws, double* part, hipStream_t st,
+                       const double* weights, double scale, int* d_guard, bool skip_pass) {
   const double* d_W = mp.d_Wsel;
   const int64_t npix = (int64_t)fl->nx * fl->nz;
   const int64_t npixp = (npix + kMomSL - 1) / kMomSL * kMomSL;
@@ -553,13 +603,25 @@ hipError_t moments_run(const rjp_fields* fl, const MomPlan& mp, int n_epochs,
   else if (mp.K == 39 && mp.N == 16) err = moments_pass<39, 16>(fl, weights, md, npix, npixp, ws, mp.attr_set[2], st);
   if (err != hipSuccess) return err;
   const int nidx = 2 * mp.K * mp.N;
+  const int nsp = part ? mom_eval_split(npix) : 1;
+  // (chunks of whole UI-row groups; nidx is a multiple of 4)
+  const int rows = ((nidx + nsp - 1) / nsp + RJP_EVAL_UI - 1) / RJP_EVAL_UI * RJP_EVAL_UI;
+  const int nsp_used = (nidx + rows - 1) / rows;
   for (int c = 0; c < mp.nchunk; ++c) {
     const int ne = std::min(RJP_MOM_TILE, n_epochs - c * RJP_MOM_TILE);
-    hipLaunchKernelGGL(moments_eval_kernel, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, st,
-                       ws, npix, npixp, nidx, d_W + (size_t)c * nidx * RJP_MOM_TILE, ne, scale,
-                       sumA + (int64_t)c * RJP_MOM_TILE * npix);
+    double* out = sumA + (int64_t)c * RJP_MOM_TILE * npix;
+    hipLaunchKernelGGL(moments_eval_kernel, dim3((unsigned)((npix + 255) / 256), (unsigned)nsp_used),
+                       dim3(256), 0, st, ws, npix, npixp, nidx, rows,
+                       d_W + (size_t)c * nidx * RJP_MOM_TILE, ne, scale, out,
+                       nsp_used > 1 ? part : (double*)nullptr);
     err = hipGetLastError();
     if (err != hipSuccess) return err;
+    if (nsp_used > 1) {
+      hipLaunchKernelGGL(moments_eval_sum_kernel, dim3((unsigned)((npix + 255) / 256), (unsigned)ne),
+                         dim3(256), 0, st, part, nsp_used, npix, scale, out);
+      err = hipGetLastError();
+      if (err != hipSuccess) return err;
+    }
   }
   return hipSuccess;
 }

@@ -354,6 +354,27 @@ __global__ __launch_bounds__(kBlock) void y_bounds_kernel(FieldPtrs<T> f, int ny
   yhi[p] = hi;
 }
 
+// sum_p max(0, yhi[p] - ylo[p]) -> *count (zeroed by the caller): rjp_fields.occupied_cells
+__global__ __launch_bounds__(kBlock) void occupied_kernel(const int32_t* __restrict__ ylo,
+                                                          const int32_t* __restrict__ yhi,
+                                                          int64_t npix,
+                                                          unsigned long long* __restrict__ count) {
+  long long v = 0;
+  for (int64_t p = (int64_t)blockIdx.x * kBlock + threadIdx.x; p < npix;
+       p += (int64_t)gridDim.x * kBlock)
+    v += max(0, yhi[p] - ylo[p]);
+#pragma unroll
+  for (int d = RJP_WAVE / 2; d > 0; d >>= 1) v += __shfl_down(v, d, RJP_WAVE);
+  if ((threadIdx.x & (RJP_WAVE - 1)) == 0 && v != 0) atomicAdd(count, (unsigned long long)v);
+}
+
+hipError_t occupied_launch(const int32_t* ylo, const int32_t* yhi, int64_t npix,
+                           unsigned long long* d_count, hipStream_t st) {
+  const unsigned blocks = (unsigned)std::min<int64_t>((npix + kBlock - 1) / kBlock, 1024);
+  hipLaunchKernelGGL(occupied_kernel, dim3(blocks), dim3(kBlock), 0, st, ylo, yhi, npix, d_count);
+  return hipGetLastError();
+}
+
 hipError_t y_bounds_launch(const rjp_fields* fl, int32_t* ylo, int32_t* yhi, hipStream_t st) {
   const int64_t npix = (int64_t)fl->nx * fl->nz;
   const dim3 grid((unsigned)((npix + kBlock - 1) / kBlock)), blk(kBlock);
@@ -508,7 +529,7 @@ size_t ff_scan_workspace_bytes(int nx, int ny, int nz, int n_epochs) {
   // sweeps long enough for the moment path (ff_moments.hip) keep its transposed moments here
   // (10 KiB per sightline; maps so large that this passes 6 GiB stay on the epoch tiles)
   if (n_epochs >= RJP_MOM_MIN_EPOCHS && moments_workspace_bytes(npix) <= ((size_t)6 << 30))
-    bytes = std::max(bytes, moments_workspace_bytes(npix));
+    bytes = std::max(bytes, moments_scan_workspace_bytes(npix));
   return bytes;
 }
 

@@ -48,6 +48,8 @@ hipError_t ff_scan_run(const rjp_fields* fl, const rjp_bursts* hb, const ScanPla
                        double* sumA, double* em, double* tavg, double* ws, hipStream_t st);
 hipError_t tavg_launch(const rjp_fields* fl, double* tavg, double* ws, hipStream_t st);
 hipError_t y_bounds_launch(const rjp_fields* fl, int32_t* ylo, int32_t* yhi, hipStream_t st);
+hipError_t occupied_launch(const int32_t* ylo, const int32_t* yhi, int64_t npix,
+                           unsigned long long* d_count, hipStream_t st);
 hipError_t ff_cells_launch(const rjp_fields* fl, const rjp_bursts* hb, const double* d_ext,
                            double time_s, int mode, const double* d_ctau, int nchan, double* out,
                            hipStream_t st);
@@ -120,6 +122,7 @@ struct MomPlan {
   mutable bool attr_set[3] = {false, false, false};   // dynamic-LDS limit raised, per LDS shape
 };
 size_t moments_workspace_bytes(int64_t npix);
+size_t moments_scan_workspace_bytes(int64_t npix);
 // 0 = this scan keeps the epoch tiles, 1 = moment path with the tables already on the device,
 // 2 = moment path after moments_build() (mp.stage has to be staged first)
 int moments_plan(const rjp_fields* fl, const rjp_bursts* hb, const double* epochs, int n_epochs,
@@ -130,8 +133,8 @@ int moments_plan(const rjp_fields* fl, const rjp_bursts* hb, const double* epoch
 hipError_t moments_build(MomPlan& mp, const double* d_stage, hipStream_t st);
 void moments_release(MomPlan& mp);
 hipError_t moments_run(const rjp_fields* fl, const MomPlan& mp, int n_epochs,
-                       double* sumA, double* ws, hipStream_t st, const double* weights,
-                       double scale, int* d_guard, bool skip_pass = false);
+                       double* sumA, double* ws, double* part, hipStream_t st,
+                       const double* weights, double scale, int* d_guard, bool skip_pass = false);
 // launch-time-ordered layout (ff_lt.hip)
 #define RJP_LT_MAX_K 80
 #define RJP_LT_MAX_EPOCHS 32     /* one fused pass serves one contraction tile */

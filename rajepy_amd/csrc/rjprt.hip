@@ -42,6 +42,7 @@ struct rjp_ctx {
   // entry point of the context reports it.  `range_ok`: the ranges rjp_ff_scan has already
   // checked against their launch-time field with a pass of its own (most recent first).
   int* guard = nullptr;
+  unsigned long long* d_count = nullptr;      // device word of rjp_occupied_cells
   struct RangeKey {
     const void* d_ts = nullptr;
     int64_t n = 0;
@@ -274,6 +275,7 @@ int rjp_ctx_destroy(rjp_ctx* ctx) {
   if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
   if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
   if (ctx->guard) (void)hipHostFree(ctx->guard);
+  if (ctx->d_count) (void)hipFree(ctx->d_count);
   rjp::moments_release(ctx->mom);
   delete ctx;
   return RJP_OK;
@@ -371,6 +373,22 @@ size_t rjp_ff_scan_workspace(int32_t nx, int32_t ny, int32_t nz, int32_t n_epoch
   return rjp::ff_scan_workspace_bytes(nx, ny, nz, n_epochs);
 }
 
+int rjp_occupied_cells(rjp_ctx* ctx, const int32_t* d_ylo, const int32_t* d_yhi, int64_t n_pix,
+                       int64_t* h_count, void* stream) {
+  if (int r = bind(ctx)) return r;
+  if (!d_ylo || !d_yhi || !h_count || n_pix <= 0)
+    return fail(ctx, RJP_ERR_ARG, "rjp_occupied_cells: NULL argument or n_pix <= 0");
+  hipStream_t st = (hipStream_t)stream;
+  if (!ctx->d_count) RJP_HIP(ctx, hipMalloc((void**)&ctx->d_count, sizeof(unsigned long long)));
+  RJP_HIP(ctx, hipMemsetAsync(ctx->d_count, 0, sizeof(unsigned long long), st));
+  RJP_HIP(ctx, rjp::occupied_launch(d_ylo, d_yhi, n_pix, ctx->d_count, st));
+  unsigned long long v = 0;
+  RJP_HIP(ctx, hipMemcpyAsync(&v, ctx->d_count, sizeof(v), hipMemcpyDeviceToHost, st));
+  RJP_HIP(ctx, hipStreamSynchronize(st));
+  *h_count = (int64_t)v;
+  return RJP_OK;
+}
+
 // (the body of rjp_ff_scan; also the first half of rjp_ff_step)
 static int ff_scan_impl(rjp_ctx* ctx, const rjp_fields* fields, const rjp_bursts* bursts,
                         const double* h_epochs_s, int32_t n_epochs, int32_t gff_mode,
@@ -445,13 +463,20 @@ static int ff_scan_impl(rjp_ctx* ctx, const rjp_fields* fields, const rjp_bursts
       cached = fields->mom_cache_K == ctx->mom.K && fields->mom_cache_N == ctx->mom.N;
     }
     if (cached) ctx->last_path = 4;
-    hipError_t e = rjp::moments_run(fields, ctx->mom, n_epochs, d_sumA, mbuf, st,
+    // (the chunk sums of a small map's split contraction: behind the moment maps' room in the
+    // workspace -- moments_plan has checked that the workspace holds both)
+    const int64_t npix_ = (int64_t)fields->nx * fields->nz;
+    double* part = nullptr;
+    if (rjp::moments_scan_workspace_bytes(npix_) > rjp::moments_workspace_bytes(npix_) &&
+        work_bytes >= rjp::moments_scan_workspace_bytes(npix_))
+      part = (double*)((char*)d_work + rjp::moments_workspace_bytes(npix_));
+    hipError_t e = rjp::moments_run(fields, ctx->mom, n_epochs, d_sumA, mbuf, part, st,
                                     (const double*)fields->d_a0, 1.0, ctx->guard, cached);
     if (e == hipSuccess && d_em) {
       // the emission measure of every epoch: the same pass and tables with em0 as the weight
       // (em = sum (n x)^2 * csize*au/pc * pf, classes.py:1116-1118)
       const double em_scale = fields->csize_au * 149597870700.0 / 3.085677581491367e+16;
-      e = rjp::moments_run(fields, ctx->mom, n_epochs, d_em, (double*)d_work, st,
+      e = rjp::moments_run(fields, ctx->mom, n_epochs, d_em, (double*)d_work, part, st,
                            (const double*)fields->d_em0, em_scale, ctx->guard);
     }
     if (e != hipSuccess) return fail(ctx, RJP_ERR_HIP, "moments_run", e);

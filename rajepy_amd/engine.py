@@ -369,8 +369,13 @@ class RTEngine:
         _lib.check(self.lib.rjp_y_bounds(self.ctx, C.byref(fs), lo.data_ptr(), hi.data_ptr(),
                                          self._stream()), self.ctx, "rjp_y_bounds")
         fields.ylo, fields.yhi = lo, hi
-        # (hint for the tiles-or-moments choice of long epoch sweeps, include/rjprt.h)
-        fields.occupied_cells = int((hi - lo).clamp_(min=0).sum(dtype=torch.int64).item())
+        # (hint for the tiles-or-moments choice of long epoch sweeps, include/rjprt.h; summed by
+        # the library: the first use of the equivalent torch ops costs ~0.2 s of lazy loading)
+        n = C.c_int64()
+        _lib.check(self.lib.rjp_occupied_cells(self.ctx, lo.data_ptr(), hi.data_ptr(),
+                                               fields.npix, C.byref(n), self._stream()),
+                   self.ctx, "rjp_occupied_cells")
+        fields.occupied_cells = int(n.value)
         return lo, hi
 
     def replace_field(self, fields, name, host_array):

@@ -198,8 +198,10 @@ def test_workspace_queries_are_host_arithmetic():
     # 4x the sightlines: 32 ranges of a 32-epoch tile would need 17.7 GB -> halved until < 6 GiB
     big = lib.rjp_ff_scan_workspace(1024, 4096, 1024, 32)
     assert big == 16 * (2 * 16 + 2) * 4 * npix * 8 + 256           # its 16-epoch tiles decide
-    # sweeps of >= 12 epochs may take the moment path: up to 1280 moments per sightline
-    assert lib.rjp_ff_scan_workspace(64, 128, 64, 12) == 1280 * 64 * 64 * 8 + 256
+    # sweeps of >= 12 epochs may take the moment path: up to 1280 moments per sightline (+ on
+    # maps of fewer than 4096 waves the chunk sums of the split contraction: 16 x 32 planes here)
+    assert lib.rjp_ff_scan_workspace(64, 128, 64, 12) == (1280 + 16 * 32) * 64 * 64 * 8 + 256
+    assert lib.rjp_ff_scan_workspace(512, 4096, 512, 12) >= 1280 * npix * 8 + 256
     assert lib.rjp_ff_scan_workspace(64, 128, 64, 11) < 1024 * 64 * 64 * 8
     assert lib.rjp_ff_scan_workspace(0, 4, 4, 1) == 0
     # round 5: the single-epoch table scan cuts mid-size maps into its OWN y-ranges
