@@ -47,6 +47,9 @@ namespace rjp {
 #ifndef RJP_TAB_WGS
 #define RJP_TAB_WGS 512          /* y-ranges are added until this many workgroups exist (1024 / 2048 at cfg4: 2.518 / 2.524 ms) */
 #endif
+#ifndef RJP_TAB_GUARD
+#define RJP_TAB_GUARD 1          /* 0: a build without the launch-time range guard, for A/B only (2 vector instructions per cell; same-buffer A/B at cfg4: profiles/r05_guard_ab.log) */
+#endif
 constexpr int kChiNC = 8;                    // coefficients per interval (degree 7)
 constexpr int kChiStride = 10;               // doubles between intervals (80 B)
 constexpr int kChiMaxNI = 460;               // 2 jets x 460 x 80 B = 73600 B of LDS
@@ -175,8 +178,10 @@ __global__ __launch_bounds__(kBlock) void ff_scan_table_kernel(
 #pragma unroll
       for (int v = 0; v < VEC; ++v) {
         const double c2 = chi2(a[u][v], tt[u][v]);
-        tmin = __builtin_fmin(tmin, tt[u][v]);
-        tmax = __builtin_fmax(tmax, tt[u][v]);
+        if (RJP_TAB_GUARD) {
+          tmin = __builtin_fmin(tmin, tt[u][v]);
+          tmax = __builtin_fmax(tmax, tt[u][v]);
+        }
         acc[v] = __builtin_fma(keep_if_ordered(__builtin_fabs(a[u][v]), tt[u][v]), c2, acc[v]);
         if (EM) accE[v] = __builtin_fma(keep_if_ordered(__builtin_fabs(g[u][v]), tt[u][v]), c2, accE[v]);
       }
@@ -190,8 +195,10 @@ __global__ __launch_bounds__(kBlock) void ff_scan_table_kernel(
 #pragma unroll
     for (int v = 0; v < VEC; ++v) {
       const double c2 = chi2(a[v], tt[v]);
-      tmin = __builtin_fmin(tmin, tt[v]);
-      tmax = __builtin_fmax(tmax, tt[v]);
+      if (RJP_TAB_GUARD) {
+        tmin = __builtin_fmin(tmin, tt[v]);
+        tmax = __builtin_fmax(tmax, tt[v]);
+      }
       acc[v] = __builtin_fma(keep_if_ordered(__builtin_fabs(a[v]), tt[v]), c2, acc[v]);
       if (EM) accE[v] = __builtin_fma(keep_if_ordered(__builtin_fabs(g[v]), tt[v]), c2, accE[v]);
     }
@@ -300,8 +307,10 @@ __global__ __launch_bounds__(kBlock) void ff_scan_table_wide_kernel(
         const double n0 = __builtin_fabs(nd[u][v]) * xi[u][v];
         const double g = poison_unless(n0 * n0 * pf[u][v], tt[u][v] == tt[u][v]);
         const double c2 = chi2(signbit_d(nd[u][v]), tt[u][v]);
-        tmin = __builtin_fmin(tmin, tt[u][v]);
-        tmax = __builtin_fmax(tmax, tt[u][v]);
+        if (RJP_TAB_GUARD) {
+          tmin = __builtin_fmin(tmin, tt[u][v]);
+          tmax = __builtin_fmax(tmax, tt[u][v]);
+        }
         accE[v] = __builtin_fma(nan_to_zero<false>(g), c2, accE[v]);
         accA[v] = __builtin_fma(nan_to_zero<false>(g * tpw[u][v]), c2, accA[v]);
       }

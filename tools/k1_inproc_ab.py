@@ -54,6 +54,7 @@ def main():
     sumA = eng._f64(nep, P)
     em = eng._f64(nep, P) if want_em else None
     work = eng._workspace(eng.lib.rjp_ff_scan_workspace(nx, ny, nz, nep))
+    eng.launch_time_range(fields)       # (single-epoch scans then take the LDS table path)
     fs = fields.struct()
     epa = _lib.dbl_array(ep)
 
