@@ -214,11 +214,11 @@ struct LtDirect {
   int ne, hb_red, hb_blue;
 };
 
-#ifndef RJP_LT_WAVES
-#define RJP_LT_WAVES 32768      /* small maps: key ranges are split until about this many waves exist ... */
+#ifndef RJP_LT_ONE_WAVE_GROUPS
+#define RJP_LT_ONE_WAVE_GROUPS 1024   /* maps of at least this many groups: one wave per group */
 #endif
-#ifndef RJP_LT_MIN_WAVES
-#define RJP_LT_MIN_WAVES 2048   /* ... but not once this many do */
+#ifndef RJP_LT_WAVES
+#define RJP_LT_WAVES 4096             /* smaller maps: row shares until about this many waves exist */
 #endif
 #ifndef RJP_LT_OCC
 #define RJP_LT_OCC 1            /* minimum waves per SIMD asked of the register allocator */
@@ -233,7 +233,6 @@ void lt_moments_kernel(const rjp_d2* __restrict__ cells,
   constexpr int ET = RJP_MOM_TILE, C = kLtChunk;
   const int Q = 2 * b.K;
   const int g = blockIdx.x / nsplit, sp = blockIdx.x % nsplit;
-  const int q0 = (int)((long long)Q * sp / nsplit), q1 = (int)((long long)Q * (sp + 1) / nsplit);
   const int lane = threadIdx.x;
   const int32_t* go = off + (int64_t)g * Q;
   double acc[ET], M[N];
@@ -243,8 +242,18 @@ void lt_moments_kernel(const rjp_d2* __restrict__ cells,
   for (int n = 0; n < N; ++n) M[n] = 0.0;
   const double c1 = 2.0 * b.inv_h;                     // xi = ts * c1 + c0(bin)
   const double cb = -(2.0 * b.s0 * b.inv_h + 1.0);
-  const int R0 = go[q0], R1 = go[q1];
-  int q = q0, rnext = go[q0 + 1];
+  // This wave's share of the group: an equal share of its ROWS (in whole chunks of C -- every
+  // bin starts at a multiple of C), whatever bins they fall in.  (Round 4 cut the KEY range
+  // evenly instead: a sightline group usually belongs to ONE jet, so half the key range was
+  // empty -- with two ranges one wave did all the work, profiles/r05_slab_ab.log.)  A bin cut in
+  // two is no problem: each wave contracts its part of the bin's moments with the same rows of W.
+  const int Rg0 = go[0];
+  const int nch = (go[Q] - Rg0) / C;
+  const int R0 = Rg0 + (int)((long long)nch * sp / nsplit) * C;
+  const int R1 = Rg0 + (int)((long long)nch * (sp + 1) / nsplit) * C;
+  int q = 0;
+  while (q + 1 < Q && go[q + 1] <= R0) ++q;            // the bin R0 lies in (empty ones skipped)
+  int rnext = go[q + 1];
   double c0 = cb - 2.0 * (q >= b.K ? q - b.K : q);
   const rjp_d2* base = cells + lane;
   // the moments of the bin that just ended -> 32 epoch sums (coefficient rows: scalar loads)
@@ -266,7 +275,7 @@ void lt_moments_kernel(const rjp_d2* __restrict__ cells,
     if (r >= R1) return;
     while (r == rnext) {                               // bins that ended here (empty ones too)
       flush();
-      ++q;
+      ++q;                                             // (r < R1 <= go[Q]: q stays below Q)
       rnext = go[q + 1];
       c0 = cb - 2.0 * (q >= b.K ? q - b.K : q);
     }
@@ -294,7 +303,7 @@ void lt_moments_kernel(const rjp_d2* __restrict__ cells,
       issue(B, r + 4 * C); step(D, r + 2 * C);
     }
   }
-  if (q < q1) flush();                                 // the last bin (empty ones after it add nothing)
+  if (R0 < R1) flush();                                // the last (part of a) bin
   const int64_t p = (int64_t)g * kLtLanes + lane;
   if (dir.sumA) {
     // one wave per group (nsplit == 1): the epoch sums are final -- add the cells that never
@@ -346,20 +355,20 @@ hipError_t lt_run(const rjp_fields* fl, const MomPlan& mp, int n_epochs, double*
   const int64_t npix = (int64_t)fl->nx * fl->nz;
   const int64_t G = (npix + kLtLanes - 1) / kLtLanes, npixp = G * kLtLanes;
   const LtBins b{mp.s0, mp.inv_h, mp.K};
-  // Waves: ONE per group when that already gives ~2/3 of the chip's resident waves (2048 of
-  // 256 CUs x 4 SIMDs x 3): each streams its group's contiguous rows end to end and writes the
-  // final sums itself.  Same-buffer A/B at cfg5's size (4096 groups, 20 bins): 1 / 2 / 3 / 4 / 6
-  // / 8 key ranges per group = 3.15 / 3.57 / 4.58 / 3.74 / 4.85 / 3.42 ms (profiles/
-  // r04_lt_waves_ab.md) -- the split costs partial planes, a reduction and ragged last rounds.
-  // Smaller maps split the key range (powers of two, never finer than two keys per wave; the
-  // partial sums are nsplit x 32 planes of npixp = 64 G doubles: never more than the CALLER'S
-  // workspace holds -- on tiny maps 64 G exceeds the 16-sightline padding the moment paths'
-  // workspace is sized with).
+  // Waves: ONE per group from RJP_LT_ONE_WAVE_GROUPS groups on (each streams its group's
+  // contiguous rows end to end and writes the final sums itself: no partial planes, no reduction);
+  // smaller maps -- the x-slabs of a sharded grid -- cut every group's ROWS into equal shares
+  // until about RJP_LT_WAVES waves exist.  Same-buffer A/B on 1 / 2 / 4 / 8-way slabs of cfg5's
+  // grid (4096 / 2048 / 1024 / 512 groups, 20 bins; profiles/r05_slab_ab2.log): 1024 groups --
+  // 1 / 2 / 4 / 8 shares 0.79 / 0.90 / 0.85 / 0.92 ms; 512 groups -- 2 / 4 / 8 / 16 shares 0.50 /
+  // 0.46 / 0.44 / 0.49 ms; the whole map 3.11 ms with 1, 3.28 with 2.  The partial sums are
+  // nsplit x 32 planes of npixp = 64 G doubles: never more than the CALLER'S workspace holds (on
+  // tiny maps 64 G exceeds the 16-sightline padding the workspace is sized with).
   int nsplit = 1;
-  while (G * nsplit < RJP_LT_MIN_WAVES && 2 * nsplit <= mp.K &&
-         2 * nsplit <= RJP_MOM_MAX_IDX / RJP_MOM_TILE && G * nsplit < RJP_LT_WAVES &&
-         (size_t)2 * nsplit * RJP_MOM_TILE * npixp * sizeof(double) <= work_bytes)
-    nsplit *= 2;
+  if (G < RJP_LT_ONE_WAVE_GROUPS)
+    while (G * nsplit < RJP_LT_WAVES && 2 * nsplit <= RJP_MOM_MAX_IDX / RJP_MOM_TILE &&
+           (size_t)2 * nsplit * RJP_MOM_TILE * npixp * sizeof(double) <= work_bytes)
+      nsplit *= 2;
   if (nsplit > 1 && !ws) return hipErrorInvalidValue;
   const LtDirect dir{nsplit == 1 ? sumA : nullptr, fl->d_lt_aux, npix, n_epochs,
                      mp.has_bursts[0], mp.has_bursts[1]};

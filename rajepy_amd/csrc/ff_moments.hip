@@ -43,6 +43,9 @@
 
 namespace rjp {
 
+#ifndef RJP_MOM_XCD
+#define RJP_MOM_XCD 1
+#endif
 constexpr int kMomSL = 16;                 // sightlines per workgroup
 constexpr int kMomBS = 1024;               // threads per workgroup: 16 sightlines x 64 y-rows (16
                                            // waves per CU keep more atomics in flight: 5.2 ms
@@ -74,7 +77,19 @@ __global__ __launch_bounds__(kMomBS) void moments_kernel(const double* __restric
   __syncthreads();
   const int sl = threadIdx.x % SL, yr = threadIdx.x / SL;
   constexpr int YR = kMomBS / SL;
-  const int64_t p = (int64_t)blockIdx.x * SL + sl;
+  // tile of 16 sightlines this workgroup owns.  RJP_MOM_XCD (A/B switch, profiles/r05_mom_xcd_ab.log):
+  // workgroups are dealt round-robin to the 8 XCDs, so with the identity map z-adjacent tiles
+  // (the 128-byte neighbours of a row) run on different XCDs at different times; the XCD-aware
+  // map gives every XCD a contiguous range of tiles in dispatch order -- the 32 CUs of an XCD
+  // then read 4 KiB-contiguous rows at about the same time
+  unsigned tile = blockIdx.x;
+#if RJP_MOM_XCD
+  {
+    const unsigned per = gridDim.x / 8;                    // (the tail past 8 * per: identity)
+    if (blockIdx.x < 8 * per) tile = (blockIdx.x % 8) * per + blockIdx.x / 8;
+  }
+#endif
+  const int64_t p = (int64_t)tile * SL + sl;
   const bool live = p < npix;
   const int64_t x = live ? p / nz : 0;
   const int z = live ? (int)(p - x * nz) : 0;
@@ -149,7 +164,7 @@ __global__ __launch_bounds__(kMomBS) void moments_kernel(const double* __restric
   // transposed flush: M_T[idx][p] (a full 128-byte segment per 16 lanes)
   for (int i = threadIdx.x; i < TOT; i += kMomBS) {
     const int idx = i / SL, s = i % SL;
-    MT[(int64_t)idx * npixp + (int64_t)blockIdx.x * SL + s] = s_mom[i];
+    MT[(int64_t)idx * npixp + (int64_t)tile * SL + s] = s_mom[i];
   }
 }
 
