@@ -53,8 +53,9 @@ def main():
     bursts = E.make_bursts(red, blue)
     eng.launch_time_range(fields)
     P = fields.npix
-    work = eng._workspace(max(eng.lib.rjp_ff_scan_workspace(*shape, 1),
-                              eng.lib.rjp_ff_scan_workspace(*shape, 32)))
+    # (the largest workspace any of the builds asks for: their split rules may differ)
+    work = eng._workspace(max(max(lib.rjp_ff_scan_workspace(*shape, 1),
+                                  lib.rjp_ff_scan_workspace(*shape, 32)) for _, lib, _ in libs))
     sumA = eng._f64(32, P)
 
     def time(lib, ctx, fs, ep, reps):
