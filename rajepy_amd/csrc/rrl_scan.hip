@@ -1068,7 +1068,10 @@ template <typename T>
 static hipError_t rrl_launch_lf(const rjp_fields* fl, const BurstsDev& b, bool bursts,
                                 double time_s, const LineDev& ln, const double* d_nu,
                                 int nchan, double* tau, hipStream_t st) {
-  if (nchan > 64) return rrl_launch_t<T, 256>(fl, b, bursts, time_s, ln, d_nu, nchan, tau, st);
+  // 65-128 channels: two blocks of the 64-lane layout (phase 1 runs twice: ~9 % more work) beat
+  // one 256-lane block with half its lanes idle (a channel shard of a 256-channel cube on 2 ranks:
+  // 338 -> see profiles/r05_cfg4_f64_tau2_bench.json rank_share.cfg3.channels)
+  if (nchan > 128) return rrl_launch_t<T, 256>(fl, b, bursts, time_s, ln, d_nu, nchan, tau, st);
   if (nchan > 16) return rrl_launch_t<T, 64>(fl, b, bursts, time_s, ln, d_nu, nchan, tau, st);
   return rrl_launch_t<T, 16>(fl, b, bursts, time_s, ln, d_nu, nchan, tau, st);
 }

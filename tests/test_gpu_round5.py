@@ -373,3 +373,28 @@ def test_jetmodel_builds_the_wide_fields_lazily(tmp_path):
     jm3.ion_fraction = xi * 0.5                          # (n x)^2: a quarter of the optical depth
     after = jm3.optical_depth_ff(nu)
     np.testing.assert_allclose(after, 0.25 * before, rtol=1e-12)
+
+
+@pytest.mark.parametrize("nchan", [65, 128, 129])
+def test_rrl_channel_shards_of_65_to_128_channels(eng, nchan):
+    """A channel shard of a 256-channel cube on two ranks is 128 channels: such blocks run as two
+    64-lane blocks since round 5 (one 256-lane block would leave half its lanes idle); 129 keeps
+    the 256-lane layout.  Against the oracle's wofz cube (rrls.py:350-389) at K3's bound."""
+    from rajepy_amd import _lib, engine as E
+    from rajepy_amd.maths import rrls
+    shape = (4, 48, 32)
+    fields = eng.synth_fields(shape, SEED + 6, 0, 8, csize_au=0.5, with_vy=True)
+    g = U.synth_host(shape, SEED + 6, 0)
+    p = U.load_golden("cfg1_example")[2]
+    p["ejection"] = U.example_bursts_params()
+    p["grid"].update(n_x=shape[0], n_y=shape[1], n_z=shape[2])
+    jet = orc.OracleJet.from_fields(p, g["nd"], g["xi"], g["temp"], g["ff"], g["areas"],
+                                    g["ts"], g["rr"], g["vy"])
+    jet.time = 1.0 * orc.YEAR
+    line = _lib.Line(**rrls.line_constants("H66a"))
+    rf = orc.chan_freqs(line.nu_rest, nchan * 1e5, 1e5)
+    assert len(rf) == nchan
+    got = eng.rrl_scan(fields, U.bursts_from_oracle(jet), jet.time, line, rf)
+    eng.synchronize()
+    np.testing.assert_allclose(got.cpu().numpy().reshape(nchan, shape[0], shape[2]),
+                               jet.optical_depth_rrl("H66a", rf), rtol=U.K3_RTOL_WAVE)
