@@ -186,6 +186,7 @@ __global__ __launch_bounds__(kMomBS) void moments_kernel(const double* __restric
 #endif
 constexpr int kEvalMaxSplit = 16;
 
+template <bool SPLIT>
 __global__ __launch_bounds__(256) void moments_eval_kernel(const double* __restrict__ MT,
                                                            int64_t npix, int64_t npixp, int nidx,
                                                            int rows_per_chunk,
@@ -196,8 +197,9 @@ __global__ __launch_bounds__(256) void moments_eval_kernel(const double* __restr
   constexpr int ET = RJP_MOM_TILE, UI = RJP_EVAL_UI;
   const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (p >= npix) return;
-  const int i_lo = blockIdx.y * rows_per_chunk;
-  const int i_hi = min(nidx, i_lo + rows_per_chunk);
+  // (the unsplit instance is round 4's kernel to the instruction: one range, no partial sums)
+  const int i_lo = SPLIT ? blockIdx.y * rows_per_chunk : 0;
+  const int i_hi = SPLIT ? min(nidx, i_lo + rows_per_chunk) : nidx;
   double acc[ET];
 #pragma unroll
   for (int e = 0; e < ET; ++e) acc[e] = 0.0;
@@ -212,7 +214,7 @@ __global__ __launch_bounds__(256) void moments_eval_kernel(const double* __restr
       for (int e = 0; e < ET; ++e) acc[e] = __builtin_fma(m[j], w[e], acc[e]);
     }
   }
-  if (part) {
+  if (SPLIT) {
 #pragma unroll
     for (int e = 0; e < ET; ++e)
       if (e < ne) part[((int64_t)blockIdx.y * ET + e) * npix + p] = acc[e];
@@ -625,10 +627,14 @@ hipError_t moments_run(const rjp_fields* fl, const MomPlan& mp, int n_epochs,
   for (int c = 0; c < mp.nchunk; ++c) {
     const int ne = std::min(RJP_MOM_TILE, n_epochs - c * RJP_MOM_TILE);
     double* out = sumA + (int64_t)c * RJP_MOM_TILE * npix;
-    hipLaunchKernelGGL(moments_eval_kernel, dim3((unsigned)((npix + 255) / 256), (unsigned)nsp_used),
-                       dim3(256), 0, st, ws, npix, npixp, nidx, rows,
-                       d_W + (size_t)c * nidx * RJP_MOM_TILE, ne, scale, out,
-                       nsp_used > 1 ? part : (double*)nullptr);
+    if (nsp_used > 1)
+      hipLaunchKernelGGL(moments_eval_kernel<true>, dim3((unsigned)((npix + 255) / 256), (unsigned)nsp_used),
+                         dim3(256), 0, st, ws, npix, npixp, nidx, rows,
+                         d_W + (size_t)c * nidx * RJP_MOM_TILE, ne, scale, out, part);
+    else
+      hipLaunchKernelGGL(moments_eval_kernel<false>, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0,
+                         st, ws, npix, npixp, nidx, rows, d_W + (size_t)c * nidx * RJP_MOM_TILE, ne,
+                         scale, out, (double*)nullptr);
     err = hipGetLastError();
     if (err != hipSuccess) return err;
     if (nsp_used > 1) {
