@@ -1429,6 +1429,33 @@ def main(argv=None):
                         "slabs into the cubes, back to back, nothing else in flight; "
                         "ms_per_step = both in one step"}
             wg.release()
+            # (1b) the alternative the sweep API is built around: the map slabs stay RANK-LOCAL
+            # and every rank hands its own slab cubes to the host over its own PCIe link (as
+            # Pipeline does per run: each rank writes the FITS files of its products) -- nothing
+            # crosses xGMI but the [E, F] all_reduce.  PCIe-inclusive, never `value`.
+            try:
+                wh = Workload(eng, args, "xslab", rank, world)
+                ht = torch.empty(wh.tau.shape, dtype=torch.float64, pin_memory=True)
+                hf = torch.empty(wh.flux.shape, dtype=torch.float64, pin_memory=True)
+
+                def host_step():
+                    r = wh.step()
+                    ht.copy_(wh.tau, non_blocking=True)
+                    hf.copy_(wh.flux, non_blocking=True)
+                    return r
+                dth, _ = timed(host_step, args.steps, args.warmup)
+                msh = dth / args.steps * 1e3
+                legs["strong_xslab_rank_local_host_maps"] = {
+                    "sharding": "xslab", "scaling": "strong", "ms_per_step": msh,
+                    "value": rate(msh, wh.total_epochs),
+                    "gather": GATHER["xslab"] + "; every rank copies its own tau / flux slabs to "
+                              "pinned host memory (its own PCIe link)",
+                    "bytes_to_host_per_rank": int(2 * wh.tau.numel() * 8),
+                    "epochs_per_step": wh.total_epochs}
+                del ht, hf
+                wh.release()
+            except RuntimeError as exc:                      # (pinned allocation refused)
+                legs["strong_xslab_rank_local_host_maps"] = {"error": str(exc)[:200]}
             # (2) weak scaling over burst-time epochs, (3) the frequency-sharded sweep as named
             for name, sh, scal in (("weak_epochs", "epochs", "weak"),
                                    ("channel_sharded", "channels", "strong")):
@@ -1462,7 +1489,7 @@ def main(argv=None):
         dist.barrier()
         for leg in legs.values():
             # (a weak leg does N epochs per step: its ratio to the N = 1 value is its scaling)
-            if n1:
+            if n1 and "value" in leg:
                 leg["speedup_vs_n1"] = leg["value"] / n1["value"]
 
     result = {

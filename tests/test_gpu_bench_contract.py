@@ -110,7 +110,9 @@ def test_bench_launches_its_own_ranks(config, sharding, scaling):
     if config == "tiny":
         # round 5: the timed region is BASELINE's workload itself in x-slabs (strong); the step
         # that ends with the map gather, the weak epoch leg and the channel-sharded leg beside it
-        assert set(r["legs"]) == {"strong_xslab_gather_maps", "weak_epochs", "channel_sharded"}
+        assert set(r["legs"]) == {"strong_xslab_gather_maps", "strong_xslab_rank_local_host_maps",
+                                  "weak_epochs", "channel_sharded"}
+        assert r["legs"]["strong_xslab_rank_local_host_maps"]["bytes_to_host_per_rank"] > 0
         for name, leg in r["legs"].items():
             assert leg["scaling"] == ("weak" if name == "weak_epochs" else "strong")
             assert leg["value"] > 0 and leg["speedup_vs_n1"] > 0
