@@ -818,8 +818,22 @@ __global__ __launch_bounds__(kRB, RJP_K3_WAVES) void rrl_scan_kernel(
   __shared__ double s_rng[NWC][4];
 
   const int ntz = (nz + ZT - 1) / ZT;
-  const int x = blockIdx.x / ntz;
-  const int z0 = (blockIdx.x - x * ntz) * ZT;
+  // XCD-aware tile map (round 5): a tile's rows are 64-byte runs (8 sightlines x 8 B), half of a
+  // 128-byte line; workgroups are dealt round-robin to the 8 XCDs, so with the identity map the
+  // z-neighbour that needs the other half ran on ANOTHER XCD (its own L2) and every line came
+  // from HBM twice -- FETCH_SIZE 71.7 GB raw for 26.3 GB algorithmic, profiles/r04_cfg3_f64_pmc.json.
+  // Every XCD now takes a contiguous range of tiles in dispatch order: neighbours share an L2.
+  // (K3 is FP64-vector-bound: this is about wasted traffic, not time.)
+#ifndef RJP_K3_XCD
+#define RJP_K3_XCD 1
+#endif
+  unsigned bx = blockIdx.x;
+  if (RJP_K3_XCD) {
+    const unsigned per = gridDim.x / 8;                    // (the tail past 8 * per: identity)
+    if (bx < 8 * per) bx = (bx % 8) * per + bx / 8;
+  }
+  const int x = (int)bx / ntz;
+  const int z0 = ((int)bx - x * ntz) * ZT;
   const int tid = threadIdx.x;
   // 256 channel lanes: the four waves of a workgroup hold four BANDS of |x| (the folded channel
   // order below), i.e. paths of very different cost (line core: lattice + pole term, 113
