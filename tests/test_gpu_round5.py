@@ -398,3 +398,20 @@ def test_rrl_channel_shards_of_65_to_128_channels(eng, nchan):
     eng.synchronize()
     np.testing.assert_allclose(got.cpu().numpy().reshape(nchan, shape[0], shape[2]),
                                jet.optical_depth_rrl("H66a", rf), rtol=U.K3_RTOL_WAVE)
+
+
+def test_occupied_cells_is_the_sum_of_the_y_ranges(eng):
+    """rjp_occupied_cells == sum_p max(0, yhi[p] - ylo[p]) of rjp_y_bounds (the hint the
+    tiles-or-moments cost model reads), on a sparse model with empty sightlines and on a dense one."""
+    import torch
+    from rajepy_amd import engine as E
+    z, meta, p, g, jet = U.golden_dense("cfg1_example")
+    fields = eng.upload_fields(g["nd"], g["xi"], g["temp"], g["ff"], g["areas"], g["ts"],
+                               g["rr"] < 0, vy=g["vy"], csize_au=jet.csize)
+    lo, hi = eng.compute_y_bounds(fields)
+    want = int((hi - lo).clamp(min=0).sum(dtype=torch.int64).item())
+    assert fields.occupied_cells == want and 0 < want < fields.ncells
+    assert int((hi <= lo).sum().item()) > 0                  # empty sightlines: [ny, 0)
+    dense = eng.synth_fields((8, 40, 64), SEED + 7, 0, 8, csize_au=0.5)
+    eng.compute_y_bounds(dense)
+    assert dense.occupied_cells == dense.ncells
