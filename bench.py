@@ -408,14 +408,15 @@ GATHER = {"none": "none", "epochs": "all_gather of flux-vs-time [E,F]",
           "channels": "all_gather of per-channel fluxes along F"}
 
 
-def gather_cubes(tau, flux, pl, rank, world, out=None):
+def gather_cubes(tau, flux, pl, rank, world, out=None, async_op=False):
     """BASELINE config 4's "RCCL gather": this rank's tau / flux slabs [E, F, n_x/N, n_z] ->
-    the whole cubes on rank 0 (None elsewhere).  `out`: rank 0's preallocated (tau, flux)."""
+    the whole cubes on rank 0 (None elsewhere).  `out`: rank 0's preallocated (tau, flux).
+    `async_op`: returns the two handles of gathers in flight (`.wait()` -> cube or None)."""
     from rajepy_amd.parallel import SlabShards, gather_slabs_to_root
     slabs = SlabShards(pl["shape"][0], world)
     o_t, o_f = out if out is not None else (None, None)
-    return (gather_slabs_to_root(tau, slabs, rank, 2, out=o_t),
-            gather_slabs_to_root(flux, slabs, rank, 2, out=o_f))
+    return (gather_slabs_to_root(tau, slabs, rank, 2, out=o_t, async_op=async_op),
+            gather_slabs_to_root(flux, slabs, rank, 2, out=o_f, async_op=async_op))
 
 
 def collect(res, pl, rank, world, backend, force=False):
@@ -483,10 +484,13 @@ def rehearse_cpu(args, rank, world):
                     E_tot, F_tot, nx, nz)
                 mine = whole[:, :, x0:x0 + pl["lshape"][0]].contiguous()
                 ct, cf = gather_cubes(mine, -mine, pl, rank, world)
-                if rank == 0:
-                    cube_ok = bool(torch.equal(ct, whole) and torch.equal(cf, -whole))
+                ha, hb = gather_cubes(mine, -mine, pl, rank, world, async_op=True)
+                at, af = ha.wait(), hb.wait()
+                if rank == 0:      # (the blocking gather and the asynchronous one)
+                    cube_ok = cube_ok and bool(torch.equal(ct, whole) and torch.equal(cf, -whole) and
+                                               torch.equal(at, whole) and torch.equal(af, -whole))
                 else:
-                    cube_ok = ct is None and cf is None
+                    cube_ok = cube_ok and all(v is None for v in (ct, cf, at, af))
         ok = bool(np.allclose(out.numpy(), full, rtol=1e-12, atol=0)) and cube_ok
         legs[sh] = {"ok": ok, "shape": list(out.shape), "gather": GATHER[sh]}
     seen = torch.ones(1, dtype=torch.float64)
@@ -627,6 +631,24 @@ class Workload:
         shp = (self.E_loc, self.nchan, lx, nz)
         return gather_cubes(self.tau.view(shp), self.flux.view(shp), self.pl, self.rank,
                             self.world, out=self.cubes)
+
+    def step_overlapped(self):
+        """A sweep over epochs with the map gather of epoch i running beside the scan of epoch
+        i + 1: the slabs are packed into send buffers at the end of a step, the collective is
+        asynchronous, and the NEXT step waits for it (and lets the root lay the slabs into the
+        cubes) only after its own compute has been enqueued."""
+        res = collect(self.local_step(), self.pl, self.rank, self.world, self.args.backend)
+        self.drain()
+        lx, _, nz = self.pl["lshape"]
+        shp = (self.E_loc, self.nchan, lx, nz)
+        self._pending = gather_cubes(self.tau.view(shp), self.flux.view(shp), self.pl, self.rank,
+                                     self.world, out=self.cubes, async_op=True)
+        return res
+
+    def drain(self):
+        for h in getattr(self, "_pending", None) or ():
+            h.wait()
+        self._pending = None
 
     def release(self, to_driver=True):
         """Drop this workload's device buffers; `to_driver=False` leaves them in PyTorch's
@@ -1428,6 +1450,24 @@ def main(argv=None):
                         "map gather); gather_only_ms = the two gathers + the root's copy of the "
                         "slabs into the cubes, back to back, nothing else in flight; "
                         "ms_per_step = both in one step"}
+            # ... and as a SWEEP over epochs: the gather of epoch i overlaps the scan of epoch
+            # i + 1 (per-step time -> max(compute, gather) instead of their sum)
+            for _ in range(args.warmup):
+                wg.step_overlapped()
+            wg.drain()
+            fence()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                wg.step_overlapped()
+            wg.drain()
+            fence()
+            mso = max_over_ranks(time.perf_counter() - t0) / args.steps * 1e3
+            legs["strong_xslab_gather_maps"]["overlapped_sweep"] = {
+                "ms_per_step": mso, "value": rate(mso, wg.total_epochs),
+                "what": "the same products per step in a sweep over epochs: the slabs of epoch i "
+                        "are packed and gathered asynchronously while epoch i + 1 is scanned; the "
+                        "next step waits for the gather (and the root lays the slabs into the "
+                        "cubes) after enqueueing its own compute"}
             wg.release()
             # (1b) the alternative the sweep API is built around: the map slabs stay RANK-LOCAL
             # and every rank hands its own slab cubes to the host over its own PCIe link (as

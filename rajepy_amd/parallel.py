@@ -161,13 +161,34 @@ def gather_to_root(local, shards, rank, axis=0, root=0, group=None):
     return full.movedim(0, axis)
 
 
-def gather_slabs_to_root(local, shards, rank, axis, root=0, group=None, out=None):
+class _SlabGather:
+    """A map gather in flight (`gather_slabs_to_root(..., async_op=True)`): `wait()` completes the
+    collective and, on the root, lays the slabs into the cube; returns the cube (None elsewhere).
+    The packed send buffer and the root's receive buffers live as long as this object."""
+
+    def __init__(self, work, finish, keep):
+        self._work, self._finish, self._keep, self._out, self._done = work, finish, keep, None, False
+
+    def wait(self):
+        if not self._done:
+            if self._work is not None:
+                self._work.wait()
+            self._out = self._finish()
+            self._keep = None
+            self._done = True
+        return self._out
+
+
+def gather_slabs_to_root(local, shards, rank, axis, root=0, group=None, out=None, async_op=False):
     """Slabs of a map cube (this rank's rows along `axis`, e.g. [E, F, n_x/N, n_z] with axis 2)
     -> the whole cube on `root`, None on the other ranks: BASELINE config 4's "RCCL gather".
     ONE `gather` of flat, equally padded buffers (no transposes on the senders), then the root
     lays the slabs into the cube (`out`, if given, is the preallocated destination).  The root
     ingests (world - 1) / world of the product over its xGMI links: 0.94 GB for the tau and flux
-    cubes of a 512 x 512 map x 256 channels -- link-bound, several times a slab's compute."""
+    cubes of a 512 x 512 map x 256 channels -- link-bound, several times a slab's compute.
+    `async_op`: the slab is packed at once (the caller may overwrite `local` as soon as this
+    returns), the collective runs beside whatever the caller enqueues next -- the next epoch's
+    scan -- and the returned handle's `wait()` finishes it (see `_SlabGather`)."""
     import torch
     dist = _dist()
     counts = shards.counts()
@@ -177,8 +198,10 @@ def gather_slabs_to_root(local, shards, rank, axis, root=0, group=None, out=None
     if not _talks(shards.world, group):
         if out is not None:
             out.copy_(local)
-            return out
-        return local
+            res = out
+        else:
+            res = local
+        return _SlabGather(None, lambda: res, None) if async_op else res
     shape = list(local.shape)
     per = 1
     for i, n in enumerate(shape):
@@ -191,18 +214,25 @@ def gather_slabs_to_root(local, shards, rank, axis, root=0, group=None, out=None
     if on_host:
         buf = buf.cpu()                      # rehearsal backend: gloo gathers host tensors
     bufs = [torch.empty_like(buf) for _ in range(shards.world)] if rank == root else None
-    dist.gather(buf, bufs, dst=root, group=group)
-    if rank != root:
-        return None
-    if out is None:
-        shape[axis] = len(shards)
-        out = torch.empty(shape, dtype=local.dtype, device=dev)
-    for (s, e), b in zip(shards.bounds, bufs):
-        if e > s:
-            shp = list(out.shape)
-            shp[axis] = e - s
-            out.narrow(axis, s, e - s).copy_(b[:(e - s) * per].view(shp))
-    return out
+    work = dist.gather(buf, bufs, dst=root, group=group, async_op=async_op)
+
+    def finish():
+        if rank != root:
+            return None
+        dst = out
+        if dst is None:
+            shp = list(shape)
+            shp[axis] = len(shards)
+            dst = torch.empty(shp, dtype=local.dtype, device=dev)
+        for (s, e), b in zip(shards.bounds, bufs):
+            if e > s:
+                shp = list(dst.shape)
+                shp[axis] = e - s
+                dst.narrow(axis, s, e - s).copy_(b[:(e - s) * per].view(shp))
+        return dst
+    if async_op:
+        return _SlabGather(work, finish, (buf, bufs))
+    return finish()
 
 
 def sweep_flux_vs_time(model, epochs_s, freqs, rank=0, world=1, group=None):

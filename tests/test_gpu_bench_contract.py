@@ -119,6 +119,7 @@ def test_bench_launches_its_own_ranks(config, sharding, scaling):
         g = r["legs"]["strong_xslab_gather_maps"]
         assert g["gather_only_ms"] > 0 and g["compute_ms"] > 0 and g["bytes_into_root"] > 0
         assert g["ms_per_step"] >= 0.5 * g["compute_ms"] and "gather" in g["gather"]
+        assert g["overlapped_sweep"]["ms_per_step"] > 0 and g["overlapped_sweep"]["value"] > 0
     elif config == "tiny5":
         assert "32 epoch(s) per step" in r["config"]["workload"]
         assert r["roofline"]["epochs_per_launch"] == 32 and r["roofline"]["grid_passes_per_launch"] == 1

@@ -52,6 +52,8 @@ CHILD = textwrap.dedent('''
     pre = (torch.empty_like(tau), torch.empty_like(tau))
     ct, cf = bench.gather_cubes(tau, -tau, pl, 0, 1, out=pre)
     assert ct is pre[0] and cf is pre[1] and torch.equal(ct, tau) and torch.equal(cf, -tau)
+    ha, hb = bench.gather_cubes(tau, -tau, pl, 0, 1, async_op=True)      # ... and asynchronously
+    assert torch.equal(ha.wait(), tau) and torch.equal(hb.wait(), -tau)
     out["gather_cubes"] = list(ct.shape)
 
     # 2. the gathers of rajepy_amd.parallel

@@ -64,6 +64,14 @@ def _worker(rank, world, port, n_epochs, ret):
             ok = ok and torch.equal(g1, c4) and g2 is pre and torch.equal(pre, c4)
         else:
             ok = ok and g1 is None and g2 is None
+        # ... asynchronously: the slab is packed at once (the source may be overwritten right
+        # away), wait() completes the gather and assembles the cube on the root
+        src = mine4.clone()
+        h = par.gather_slabs_to_root(src, sh, rank, 2, root=0, async_op=True)
+        src.fill_(-99.0)
+        g4 = h.wait()
+        ok = ok and ((rank == 0 and torch.equal(g4, c4) and h.wait() is g4) or
+                     (rank != 0 and g4 is None))
         few = par.SlabShards(1, world)                  # one row, `world` ranks
         row = torch.full((2, few.counts()[rank], 3), float(rank + 1), dtype=torch.float64)
         g3 = par.gather_slabs_to_root(row, few, rank, 1, root=0)
@@ -102,6 +110,7 @@ def _local_in_group_worker(rank, world, port, ret):
             ok = ok and par.all_gather_blocks(x, one, 0) is x
             ok = ok and par.gather_to_root(x, one, 0) is x
             ok = ok and par.gather_slabs_to_root(x, one, 0, 0) is x
+            ok = ok and par.gather_slabs_to_root(x, one, 0, 0, async_op=True).wait() is x
             ok = ok and par.gather_flux_vs_time(x, one, 0) is x
             ok = ok and par._talks(1) is False and par._talks(2) is True
         try:
