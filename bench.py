@@ -566,6 +566,8 @@ class Workload:
             self.cfl_rrl, self.hnu_k = E.rrl_channel_coeffs(freqs, 0.5, 120.)
         gv = None if self.plaw else [ph.gff(nu, 1e4) for nu in freqs]
         self.ctau, self.cflux = E.ff_channel_coeffs(freqs, 0.5, 120., self.gmode, gv)
+        # (the per-channel tables as ctypes arrays, converted once: a step is one library call)
+        self.ctau, self.cflux = _lib.dbl_array(self.ctau), _lib.dbl_array(self.cflux)
         self.freqs = freqs
         self.my_epochs = pl["my_epochs"]
         E_loc = self.E_loc = len(self.my_epochs)

@@ -165,6 +165,11 @@ def check(status, ctx=None, what=""):
 
 
 def dbl_array(values):
-    """Host table of float64 as a ctypes array (kept alive by the caller)."""
-    vals = [float(v) for v in values]
-    return (C.c_double * len(vals))(*vals)
+    """Host table of float64 as a ctypes array (kept alive by the caller).  A ctypes array of
+    doubles is returned as it is: a caller that repeats a step with the same tables (a sweep
+    over epochs at a fixed channel list) converts them once."""
+    if isinstance(values, C.Array) and values._type_ is C.c_double:
+        return values
+    import numpy as np
+    arr = np.ascontiguousarray(values, dtype=np.float64).ravel()
+    return (C.c_double * arr.size).from_buffer_copy(arr.tobytes()) if arr.size else (C.c_double * 0)()
