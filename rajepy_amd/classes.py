@@ -646,7 +646,12 @@ class JetModel:
         frequency) -> array (len(times), len(freq)).  The reference gets these numbers by
         looping `time` and summing `flux_ff` maps (Pipeline results, classes.py:2461-2467);
         here the maps are reduced on the device and up to 32 epochs share one pass over HBM.
-        Inside a torch.distributed group the epochs are shared out over the ranks."""
+        Inside a torch.distributed group the epochs are shared out over the ranks.
+        Memory: a DENSELY filled model keeps its launch-time moment maps after the first sweep of
+        >= 12 epochs (1280 doubles per sightline: 2.7 GB at 512 x 512 sightlines) so that later
+        sweeps -- other epochs, other burst parameters -- are contractions only; a pipeline that
+        holds many such models sets `model.engine.cache_moments = False` (every sweep then makes
+        its own pass over the grid), and a setter that replaces a field drops the maps."""
         from . import parallel
         rank, world, _ = _dist_info()
         return parallel.sweep_flux_vs_time(self, np.atleast_1d(np.asarray(times_s, float)),
